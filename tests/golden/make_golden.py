@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (runs ONLY in the build container, where /root/reference exists).
+
+Imports the reference (goldman-gp-ebi/BOSS-RUNS v0.4.0) through the import shims in
+`tests/golden/_shims/` (tomllib->tomli, stub mappy / minknow_api, Bottleneck `move_sum`
+restated), drives `BossRuns` exactly as `process_batch_runs` does minus the mapper
+(boss/runs/core.py:202-224) on seeded synthetic inputs, and stores inputs' digests and the
+reference's outputs as small `.npz` fixtures next to this script.
+
+    cd /tmp && python3 /root/repo/tests/golden/make_golden.py
+
+Fixtures whose values pass through `bottleneck.move_sum` carry `movesum_unpinned=1`
+(the shim restates Bottleneck 1.3.x; the real library is not installed).
+Nothing from /root/reference is copied: fixtures hold inputs (or their seeds) and outputs.
+"""
+import hashlib
+import os
+import sys
+import tempfile
+from io import StringIO
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [os.path.join(HERE, "_shims"), "/root/reference", REPO]
+
+from boss_runs_amd import synth  # noqa: E402
+
+SCENARIOS = [  # (tag, ploidy, nbarcodes)
+    ("p1_nb1", 1, 1), ("p2_nb1", 2, 1), ("p1_nb2", 1, 2), ("p2_nb2", 2, 2)]
+E2E_LENGTHS = [150_000, 260_000, 120_000, 60_000]
+E2E_NAMES = ["ctgA", "ctgB", "ctgREJ", "ctgSHORT"]
+E2E_REJECT = "ctgREJ"
+E2E_BATCHES = 5
+E2E_READS = 420
+
+
+def digest(*arrs):
+    h = hashlib.sha256()
+    for a in arrs:
+        h.update(a if isinstance(a, (bytes, bytearray)) else np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def e2e_reference(seed=1):
+    return synth.make_reference(E2E_LENGTHS, seed=seed, names=E2E_NAMES)
+
+
+def e2e_batch(contigs, b, nb):
+    # hot region on ctgB, thin coverage on ctgA; the rejected / short contigs still attract reads
+    return synth.make_batch(contigs, E2E_READS, seed=10 + b, mean_len=3000.0, nbarcodes=nb,
+                            start_weights=[0.6, 1.6, 0.5, 0.5])
+
+
+def carve_hole(batch, contigs):
+    """No-op hook kept for clarity: dropout is exercised by ctgA's thin coverage."""
+    return batch
+
+
+def gen_tables(out):
+    from boss.runs.sequences import Scoring
+    rng = np.random.default_rng(42)
+    pats = []
+    for _ in range(2000):
+        s = int(rng.integers(0, 30))
+        c = rng.multinomial(s, rng.dirichlet([3, .3, .3, .3, .3]))
+        pats.append(rng.permutation(c))
+    for s in range(0, 30):                      # edge patterns: everything on one state
+        for k in range(5):
+            p = [0] * 5
+            p[k] = s
+            pats.append(p)
+    pats = np.array(pats, dtype=np.uint16)
+    d = dict(patterns=pats)
+    for pl in (1, 2):
+        sc = Scoring(ploidy=pl)
+        ent, sco = sc.calc_posterior_and_scores(cov_patterns=pats.copy())
+        d["phi_p%d" % pl] = sc.priors.phi
+        d["priors_p%d" % pl] = sc.priors.priors
+        d["score0_p%d" % pl] = sc.score0
+        d["ent0_p%d" % pl] = sc.ent0
+        d["entropy_p%d" % pl] = ent
+        d["score_p%d" % pl] = sco
+    np.savez_compressed(os.path.join(out, "g_tables.npz"), **d)
+
+
+def gen_cigar(out):
+    from boss.paf import Paf
+    from boss.runs.sequences import CoverageConverter
+    contigs = synth.make_reference([5000, 4000], seed=3, names=["c1", "c2"])
+    b = synth.make_batch(contigs, 60, seed=77, mean_len=900.0, min_len=250, max_len=2500)
+    paf = Paf.parse_PAF(StringIO(b["paf"]), min_len=200)
+    inc = CoverageConverter().convert_records(paf_dict=paf, seqs=b["seqs"],
+                                              quals={k: "I" * len(v) for k, v in b["seqs"].items()})
+    d = dict(paf=np.frombuffer(b["paf"].encode(), dtype=np.uint8),
+             read_ids=np.array(list(b["seqs"].keys())),
+             read_seqs=np.array(list(b["seqs"].values())))
+    k = 0
+    for tname, lst in inc.items():
+        for (start, end, q, addition, bc) in lst:
+            assert np.all(addition == 1)
+            d["inc%03d_tname" % k] = np.array(tname)
+            d["inc%03d_range" % k] = np.array([start, end])
+            d["inc%03d_codes" % k] = q.astype(np.uint8)
+            k += 1
+    d["n_inc"] = np.array(k)
+    np.savez_compressed(os.path.join(out, "g_cigar.npz"), **d)
+
+
+def gen_dists(out):
+    from boss.readlengthdist import ReadlengthDist
+    r = ReadlengthDist()
+    d = dict(default_approx_ccl=r.approx_ccl.copy())
+    rng = np.random.default_rng(5)
+    for k in range(3):
+        lens = np.clip(rng.gamma(2.0, 3000.0, size=500), 100, 2_000_000).astype(np.int64)
+        r.update({"x%d" % i: int(v) for i, v in enumerate(lens)})
+        d["lens%d" % k] = lens
+        d["approx_ccl%d" % k] = r.approx_ccl.copy()
+        d["lam%d" % k] = np.array(r.lam)
+        d["time_cost%d" % k] = np.array(r.time_cost)
+    np.savez_compressed(os.path.join(out, "g_dists.npz"), **d)
+
+
+def run_scenario(out, tag, ploidy, nb):
+    import boss.config
+    import boss.runs.core
+    from boss.paf import Paf
+    contigs = e2e_reference()
+    tmp = tempfile.mkdtemp(prefix="golden_")
+    os.chdir(tmp)
+    fa = os.path.join(tmp, "ref.fa")
+    synth.write_fasta(fa, contigs)
+    open(os.path.join(tmp, "ref.mmi"), "w").close()
+    args = boss.config.BossConfig()
+    args.general.ref = fa
+    args.general.mmi = os.path.join(tmp, "ref.mmi")
+    args.general.name = "golden"
+    args.optional.ploidy = ploidy
+    args.optional.reject_refs = E2E_REJECT
+    if nb > 1:
+        args.general.barcodes = ["barcode%02d" % (i + 1) for i in range(nb)]
+    runs = boss.runs.core.BossRuns(args=args)
+    runs.init()
+    d = dict(movesum_unpinned=np.array(1), ploidy=np.array(ploidy), nb=np.array(nb),
+             ref_digest=np.array(digest(*[c[1] for c in contigs])))
+    for b in range(E2E_BATCHES):
+        batch = e2e_batch(contigs, b, nb)
+        d["b%d_input_digest" % b] = np.array(digest(batch["paf"].encode(),
+                                                    "".join(batch["seqs"].values()).encode()))
+        runs.rl_dist.update(read_lengths=batch["read_lengths"])
+        paf = Paf.parse_PAF(StringIO(batch["paf"]), min_len=200)
+        for recs in paf.values():
+            for r in recs:
+                r.barcode = batch["barcodes"][r.qname] if nb > 1 else None
+        inc = runs.cc.convert_records(paf_dict=paf, seqs=batch["seqs"],
+                                      quals={k: "I" * len(v) for k, v in batch["seqs"].items()})
+        runs._effect_increments(increments=inc)
+        runs.tracker.update(n=len(batch["seqs"]), paf_dict=paf)
+        runs.read_starts.count_read_starts(paf_dict=paf)
+        # capture the threshold chosen inside update_wrapper
+        captured = {}
+        orig = runs.scoring.find_strat_thread
+
+        def spy(benefit, smu, fhat, time_cost, _orig=orig, _cap=captured):
+            strat, thr = _orig(benefit=benefit, smu=smu, fhat=fhat, time_cost=time_cost)
+            _cap.update(threshold=thr, merged_strat=strat.copy(), benefit_adj=benefit.copy(),
+                        fhat_adj=fhat.copy())
+            return strat, thr
+        runs.scoring.find_strat_thread = spy
+        runs.update_wrapper()
+        runs.scoring.find_strat_thread = orig
+        d["b%d_updated" % b] = np.array(int(bool(captured)))
+        d["b%d_approx_ccl" % b] = runs.rl_dist.approx_ccl.copy()
+        d["b%d_time_cost" % b] = np.array(runs.rl_dist.time_cost)
+        if captured:
+            d["b%d_threshold" % b] = np.array(captured["threshold"])
+            d["b%d_merged_strat" % b] = np.packbits(captured["merged_strat"].reshape(-1))
+            d["b%d_merged_shape" % b] = np.array(captured["merged_strat"].shape)
+            d["b%d_benefit_adj" % b] = captured["benefit_adj"]
+            d["b%d_fhat_adj" % b] = captured["fhat_adj"]
+        for cname, c in runs.contigs.items():
+            key = "b%d_%s_" % (b, cname)
+            d[key + "strat"] = np.packbits(c.strat.reshape(-1))
+            d[key + "strat_shape"] = np.array(c.strat.shape)
+            if c.rej:
+                continue
+            d[key + "cov_digest"] = np.array(digest(c.coverage))
+            d[key + "cov_total"] = np.array(int(c.coverage.sum(dtype=np.uint64)))
+            d[key + "change_count"] = np.array(int(c.change_mask.sum()))
+            d[key + "scores_digest"] = np.array(digest(c.scores))
+            d[key + "entropy_digest"] = np.array(digest(c.entropy))
+            d[key + "n_zero_scores"] = np.array(int((c.scores == 0).sum()))
+            d[key + "n_tiny_scores"] = np.array(int((c.scores == np.finfo(float).tiny).sum()))
+            d[key + "bucket_switches"] = c.bucket_switches.copy()
+            d[key + "switched_on"] = c.switched_on.copy()
+            if captured:
+                d[key + "scores_ds"] = c.scores_ds.copy()
+                d[key + "smu"] = c.smu.copy()
+                d[key + "additional_benefit"] = c.additional_benefit.copy()
+        if b == E2E_BATCHES - 1:
+            c = runs.contigs["ctgA"]
+            d["final_ctgA_scores"] = c.scores.copy()
+            d["final_ctgA_entropy"] = c.entropy.copy()
+            d["final_ctgA_coverage"] = c.coverage.copy()
+            d["final_read_starts"] = runs.read_starts.merge()
+    np.savez_compressed(os.path.join(out, "g_e2e_%s.npz" % tag), **d)
+    return d
+
+
+def main():
+    out = HERE
+    gen_tables(out)
+    gen_cigar(out)
+    gen_dists(out)
+    for tag, pl, nb in SCENARIOS:
+        d = run_scenario(out, tag, pl, nb)
+        print(tag, "updated:", [int(d["b%d_updated" % b]) for b in range(E2E_BATCHES)],
+              "thr:", [float(d.get("b%d_threshold" % b, np.nan)) for b in range(E2E_BATCHES)])
+    for f in sorted(os.listdir(out)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(out, f)))
+
+
+if __name__ == "__main__":
+    main()
