@@ -1,0 +1,106 @@
+"""ctypes binding of the C-ABI in include/bossx.h (libbossx.so, built in-tree by
+`__graft_entry__.build()` / `make -C boss-runs_amd/csrc`).
+
+There is no CPU fallback: if the shared library is missing, or no HIP device is present,
+importing works but creating an engine raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbossx.so")
+
+HIST_BINS = 1088
+NCOMP = 278256
+NWIN = 11
+K_NAMES = ("ingest_scatter", "site_sweep", "benefit_chain", "threshold_hist", "strategy_mask")
+
+ERRORS = {-1: ValueError, -2: RuntimeError, -3: ValueError, -4: KeyError, -5: IndexError,
+          -6: ValueError, -7: ValueError}
+
+
+class BossxError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("nbarcodes", C.c_int32), ("track_entropy", C.c_int32),
+                ("reserved", C.c_int32), ("stream", C.c_void_p)]
+
+
+class BatchSummary(C.Structure):
+    _fields_ = [("read_idx", C.c_void_p), ("contig_idx", C.c_void_p), ("rev", C.c_void_p),
+                ("tstart", C.c_void_p), ("tend", C.c_void_p), ("qlen", C.c_void_p)]
+
+
+class FhatDesc(C.Structure):
+    _fields_ = [("fhat_c", C.c_void_p), ("n_windows", C.c_int64), ("rep", C.c_int64),
+                ("target_rs", C.c_int64), ("target", C.c_int64)]
+
+
+# name -> (restype, argtypes); every symbol include/bossx.h declares
+PROTOTYPES = {
+    "bossx_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
+    "bossx_destroy": (None, [C.c_void_p]),
+    "bossx_last_error": (C.c_char_p, [C.c_void_p]),
+    "bossx_version": (C.c_char_p, []),
+    "bossx_add_contig": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int64, C.c_int32]),
+    "bossx_finalize": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
+    "bossx_set_lut": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "bossx_stage_batch": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_void_p,
+                                    C.c_char_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                    C.POINTER(BatchSummary), C.POINTER(C.c_int32),
+                                    C.POINTER(C.c_int64)]),
+    "bossx_ingest_staged": (C.c_int, [C.c_void_p]),
+    "bossx_ingest_paf": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_void_p,
+                                   C.c_char_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                   C.POINTER(BatchSummary), C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_int64)]),
+    "bossx_sweep": (C.c_int, [C.c_void_p]),
+    "bossx_get_bucket_sums": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "bossx_set_bucket_switches": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "bossx_benefit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    "bossx_histogram": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(FhatDesc), C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
+    "bossx_apply_threshold": (C.c_int, [C.c_void_p, C.c_double]),
+    "bossx_get_strat": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "bossx_n_contigs": (C.c_int32, [C.c_void_p]),
+    "bossx_contig_length": (C.c_int64, [C.c_void_p, C.c_int32]),
+    "bossx_n_sites": (C.c_int64, [C.c_void_p]),
+    "bossx_merged_bins": (C.c_int64, [C.c_void_p]),
+    "bossx_export": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]),
+    "bossx_import": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]),
+    "bossx_preload_coverage": (C.c_int, [C.c_void_p, C.c_double, C.c_uint64]),
+    "bossx_enable_timing": (C.c_int, [C.c_void_p, C.c_int32]),
+    "bossx_kernel_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bossx_kernel_bytes": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bossx_synchronize": (C.c_int, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libbossx.so and attach prototypes.  Raises BossxError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BossxError(
+            "HIP extension not built: %s is missing. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `make -C boss-runs_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(lib, handle, rc):
+    if rc == 0:
+        return
+    msg = lib.bossx_last_error(handle)
+    msg = msg.decode("utf-8", "replace") if msg else "bossx error %d" % rc
+    raise ERRORS.get(rc, BossxError)(msg)

@@ -1,0 +1,35 @@
+"""Configuration objects with the reference's field names (boss/config.py:24-69), restricted to
+what the decision-update path reads.  Plain dataclasses: no TOML/CLI layer (out of scope)."""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+
+@dataclass
+class GeneralConfig:
+    name: str = 'boss'
+    ref: Optional[str] = None
+    mmi: Optional[str] = None
+    toml_readfish: Optional[str] = None
+    wait: int = 60
+    barcodes: Optional[List[str]] = None
+
+
+@dataclass
+class OptionalConfig:
+    reject_refs: Optional[str] = None
+    ploidy: int = 1
+    bucket_threshold: int = 5
+
+
+@dataclass
+class GpuConfig:
+    """Additions of this build (no reference counterpart)."""
+    device: int = 0
+    track_entropy: bool = True
+
+
+@dataclass
+class BossConfig:
+    general: GeneralConfig = field(default_factory=GeneralConfig)
+    optional: OptionalConfig = field(default_factory=OptionalConfig)
+    gpu: GpuConfig = field(default_factory=GpuConfig)

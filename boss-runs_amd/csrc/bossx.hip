@@ -1,0 +1,773 @@
+// bossx engine: C-ABI (include/bossx.h) over the HIP kernels in kernels.hip.inc.
+// gfx950 only; no CPU fallback — every entry point needs the device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+
+#include "engine.hpp"
+#include "kernels.hip.inc"
+
+using namespace bossx;
+
+struct bossx_engine {
+    bossx_config cfg{};
+    std::string err;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool finalized = false;
+    bool lut_set = false;
+    int32_t nb = 1;
+
+    std::vector<ContigInfo> contigs;                    // add order (rejected included)
+    std::unordered_map<std::string, int32_t> index;     // name -> add order
+    std::vector<int32_t> filt;                          // add-order indices of non-rejected contigs
+    std::vector<std::vector<uint8_t>> host_codes;       // per contig until finalize
+    int64_t n_sites_all = 0;                            // Reference.n_sites
+    int64_t Gp = 0, B = 0, rows = 0, NBK = 0, n_tiles = 0, strat_bytes = 0;
+    double score0 = 0, ent0 = 0;
+
+    // device state
+    uint16_t *d_cov = nullptr;
+    uint8_t *d_meta = nullptr, *d_touched = nullptr, *d_strat = nullptr, *d_bucket_on = nullptr;
+    double *d_entropy = nullptr, *d_ds = nullptr, *d_benefit = nullptr;
+    double *d_lut_score = nullptr, *d_lut_ent = nullptr, *d_fhat = nullptr;
+    unsigned long long *d_bucket_sums = nullptr, *d_drop_count = nullptr, *d_stats = nullptr;
+    int64_t fhat_cap = 0;
+    int32_t *d_err = nullptr;
+    // contig tables (device)
+    int64_t *d_tile_off = nullptr, *d_site_off = nullptr, *d_length = nullptr, *d_bin_off = nullptr,
+            *d_row_off = nullptr, *d_strat_off = nullptr, *d_bucket_off = nullptr;
+    int32_t *d_drop_thr = nullptr;
+    uint8_t *d_local = nullptr;
+    // staged batch
+    EmitOp *d_ops = nullptr; size_t ops_cap = 0;
+    uint32_t *d_tiles = nullptr; size_t tiles_cap = 0;
+    uint8_t *d_blob = nullptr; size_t blob_cap = 0;
+    ParsedBatch staged;
+    bool has_staged = false;
+    // pinned scratch
+    void *h_pin = nullptr; size_t pin_cap = 0;
+    // timing
+    bool timing = false;
+    hipEvent_t ev0[BOSSX_K_COUNT]{}, ev1[BOSSX_K_COUNT]{};
+    bool ev_pending[BOSSX_K_COUNT]{};
+    float ms_last[BOSSX_K_COUNT]{};
+    double ms_total[BOSSX_K_COUNT]{};
+    int64_t launches[BOSSX_K_COUNT]{};
+    double bytes_last[BOSSX_K_COUNT]{};
+};
+
+namespace {
+
+int fail(bossx_engine *h, int code, const std::string &msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(h, BOSSX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+int dev_alloc(bossx_engine *h, T **p, size_t count, bool zero = false) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T)));
+    if (zero) HIPCHK(hipMemsetAsync(*p, 0, count * sizeof(T), h->stream));
+    return BOSSX_OK;
+}
+
+int ensure_pin(bossx_engine *h, size_t bytes) {
+    if (h->pin_cap >= bytes) return BOSSX_OK;
+    if (h->h_pin) HIPCHK(hipHostFree(h->h_pin));
+    h->h_pin = nullptr; h->pin_cap = 0;
+    size_t cap = std::max<size_t>(bytes, 1 << 20);
+    HIPCHK(hipHostMalloc(&h->h_pin, cap, hipHostMallocDefault));
+    h->pin_cap = cap;
+    return BOSSX_OK;
+}
+
+template <typename T>
+int upload_vec(bossx_engine *h, T **dptr, const std::vector<T> &v) {
+    int rc = dev_alloc(h, dptr, v.size());
+    if (rc) return rc;
+    if (!v.empty()) HIPCHK(hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return BOSSX_OK;
+}
+
+ContigTable table_of(const bossx_engine *h) {
+    ContigTable t;
+    t.tile_off = h->d_tile_off; t.site_off = h->d_site_off; t.length = h->d_length;
+    t.bin_off = h->d_bin_off; t.row_off = h->d_row_off; t.strat_off = h->d_strat_off;
+    t.bucket_off = h->d_bucket_off; t.drop_thr = h->d_drop_thr; t.local = h->d_local;
+    t.n = int32_t(h->filt.size());
+    return t;
+}
+
+void time_begin(bossx_engine *h, int k) {
+    if (!h->timing) return;
+    if (h->ev_pending[k]) {      // collect the previous launch before re-recording
+        hipEventSynchronize(h->ev1[k]);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, h->ev0[k], h->ev1[k]) == hipSuccess) { h->ms_last[k] = ms; h->ms_total[k] += ms; }
+        h->ev_pending[k] = false;
+    }
+    hipEventRecord(h->ev0[k], h->stream);
+}
+
+void time_end(bossx_engine *h, int k, double bytes) {
+    h->launches[k]++;
+    h->bytes_last[k] = bytes;
+    if (!h->timing) return;
+    hipEventRecord(h->ev1[k], h->stream);
+    h->ev_pending[k] = true;
+}
+
+void time_collect(bossx_engine *h) {
+    for (int k = 0; k < BOSSX_K_COUNT; ++k) {
+        if (!h->ev_pending[k]) continue;
+        hipEventSynchronize(h->ev1[k]);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, h->ev0[k], h->ev1[k]) == hipSuccess) { h->ms_last[k] = ms; h->ms_total[k] += ms; }
+        h->ev_pending[k] = false;
+    }
+}
+
+SweepParams sweep_params(bossx_engine *h) {
+    SweepParams P;
+    P.cov = h->d_cov; P.meta = h->d_meta; P.touched = h->d_touched; P.entropy = h->d_entropy;
+    P.ds = h->d_ds; P.bucket_sums = h->d_bucket_sums; P.drop_count = h->d_drop_count;
+    P.lut_score = h->d_lut_score; P.lut_ent = h->d_lut_ent; P.ct = table_of(h);
+    P.Gp = h->Gp; P.B = h->B; P.NBK = h->NBK; P.nb = h->nb;
+    P.score0 = h->score0; P.tiny = std::numeric_limits<double>::min();
+    return P;
+}
+
+int check_contig(bossx_engine *h, int32_t c, bool need_filt) {
+    if (!h || c < 0 || c >= int32_t(h->contigs.size())) return fail(h, BOSSX_E_INVALID, "contig index out of range");
+    if (need_filt && h->contigs[size_t(c)].rejected) return fail(h, BOSSX_E_INVALID, "contig is rejected");
+    if (!h->finalized) return fail(h, BOSSX_E_INVALID, "engine not finalized");
+    return BOSSX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *bossx_version(void) { return "bossx 0.1.0 (gfx950)"; }
+
+const char *bossx_last_error(const bossx_engine *h) { return h ? h->err.c_str() : "null engine"; }
+
+int bossx_create(const bossx_config *cfg, bossx_engine **out) {
+    if (!cfg || !out) return BOSSX_E_INVALID;
+    *out = nullptr;
+    std::unique_ptr<bossx_engine> e(new bossx_engine());
+    bossx_engine *h = e.get();
+    h->cfg = *cfg;
+    if (cfg->nbarcodes < 1 || cfg->nbarcodes > 255) return BOSSX_E_INVALID;
+    h->nb = cfg->nbarcodes;
+    int ndev = 0;
+    hipError_t er = hipGetDeviceCount(&ndev);
+    if (er != hipSuccess || ndev <= 0) {
+        // no CPU fallback by design
+        fprintf(stderr, "bossx: no HIP device available (%s)\n", er == hipSuccess ? "count = 0" : hipGetErrorString(er));
+        return BOSSX_E_HIP;
+    }
+    if (hipSetDevice(cfg->device) != hipSuccess) return BOSSX_E_HIP;
+    if (cfg->stream) {
+        h->stream = static_cast<hipStream_t>(cfg->stream);
+    } else {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return BOSSX_E_HIP;
+        h->own_stream = true;
+    }
+    for (int k = 0; k < BOSSX_K_COUNT; ++k) {
+        if (hipEventCreate(&h->ev0[k]) != hipSuccess || hipEventCreate(&h->ev1[k]) != hipSuccess) return BOSSX_E_HIP;
+    }
+    *out = e.release();
+    return BOSSX_OK;
+}
+
+void bossx_destroy(bossx_engine *h) {
+    if (!h) return;
+    hipSetDevice(h->cfg.device);
+    hipStreamSynchronize(h->stream);
+    void *ptrs[] = {h->d_cov, h->d_meta, h->d_touched, h->d_strat, h->d_bucket_on, h->d_entropy, h->d_ds,
+                    h->d_benefit, h->d_lut_score, h->d_lut_ent, h->d_fhat, h->d_bucket_sums, h->d_drop_count,
+                    h->d_stats, h->d_err, h->d_tile_off, h->d_site_off, h->d_length, h->d_bin_off, h->d_row_off,
+                    h->d_strat_off, h->d_bucket_off, h->d_drop_thr, h->d_local, h->d_ops, h->d_tiles, h->d_blob};
+    for (void *p : ptrs) if (p) hipFree(p);
+    if (h->h_pin) hipHostFree(h->h_pin);
+    for (int k = 0; k < BOSSX_K_COUNT; ++k) { if (h->ev0[k]) hipEventDestroy(h->ev0[k]); if (h->ev1[k]) hipEventDestroy(h->ev1[k]); }
+    if (h->own_stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int bossx_add_contig(bossx_engine *h, const char *name, const char *seq, int64_t length, int32_t rejected) {
+    if (!h || !name) return BOSSX_E_INVALID;
+    if (h->finalized) return fail(h, BOSSX_E_INVALID, "add_contig after finalize");
+    ContigInfo c;
+    std::string nm(name);                       // Contig.name: first token (reference.py:29)
+    size_t b = nm.find_first_not_of(" \t\n\r"), e2 = nm.find_last_not_of(" \t\n\r");
+    nm = b == std::string::npos ? std::string() : nm.substr(b, e2 - b + 1);
+    size_t sp = nm.find(' ');
+    if (sp != std::string::npos) nm = nm.substr(0, sp);
+    c.name = nm;
+    c.rejected = rejected != 0;
+    std::vector<uint8_t> codes;
+    if (c.rejected) {
+        c.length = 4;                           // Contig(seq="ACGT", rej=True), reference.py:337
+    } else {
+        if (!seq || length < 1) return fail(h, BOSSX_E_INVALID, "contig needs a sequence");
+        c.length = length;
+        codes.resize(size_t(length));
+        for (int64_t i = 0; i < length; ++i) {  // reference.py:46-68 after .upper()
+            switch (seq[i]) {
+                case 'C': case 'c': codes[size_t(i)] = 1; break;
+                case 'G': case 'g': codes[size_t(i)] = 2; break;
+                case 'T': case 't': codes[size_t(i)] = 3; break;
+                default: codes[size_t(i)] = 0; break;
+            }
+        }
+    }
+    h->index[c.name] = int32_t(h->contigs.size());
+    h->contigs.push_back(c);
+    h->host_codes.push_back(std::move(codes));
+    return BOSSX_OK;
+}
+
+int bossx_finalize(bossx_engine *h, double score0, double ent0) {
+    if (!h) return BOSSX_E_INVALID;
+    if (h->finalized) return fail(h, BOSSX_E_INVALID, "already finalized");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    h->score0 = score0; h->ent0 = ent0;
+    const int64_t nb = h->nb;
+    std::vector<int64_t> tile_off{0}, site_off, length, bin_off{0}, row_off{0}, strat_off, bucket_off{0};
+    std::vector<uint8_t> local;
+    int64_t site = 0, sbytes = 0;
+    h->n_sites_all = 0;
+    for (size_t i = 0; i < h->contigs.size(); ++i) {
+        ContigInfo &c = h->contigs[i];
+        h->n_sites_all += c.length;
+        if (c.rejected) continue;
+        c.filt_index = int32_t(h->filt.size());
+        h->filt.push_back(int32_t(i));
+        c.site_off = site;
+        c.n_tiles = (c.length + kTileSites - 1) / kTileSites;
+        c.tile_off = tile_off.back();
+        c.T = c.length / kWindow;
+        c.bin_off = bin_off.back();
+        c.row_off = row_off.back();
+        c.strat_off = sbytes;
+        c.n_buckets = c.length / kBucket + 1;
+        c.bucket_off = bucket_off.back();
+        site += c.n_tiles * kTileSites;
+        sbytes += c.T * 2 * nb;
+        tile_off.push_back(c.tile_off + c.n_tiles);
+        site_off.push_back(c.site_off);
+        length.push_back(c.length);
+        bin_off.push_back(c.bin_off + c.T + 1);
+        row_off.push_back(c.row_off + c.T);
+        strat_off.push_back(c.strat_off);
+        bucket_off.push_back(c.bucket_off + c.n_buckets);
+        local.push_back(1);
+    }
+    if (h->filt.empty()) return fail(h, BOSSX_E_INVALID, "no non-rejected contig");
+    h->Gp = site; h->n_tiles = tile_off.back(); h->B = bin_off.back(); h->rows = row_off.back();
+    h->NBK = bucket_off.back(); h->strat_bytes = sbytes;
+    if (uint64_t(h->Gp) >= (1ull << 40)) return fail(h, BOSSX_E_INVALID, "reference too large");
+
+    int rc;
+    if ((rc = dev_alloc(h, &h->d_cov, size_t(nb * 5 * h->Gp), true))) return rc;
+    if ((rc = dev_alloc(h, &h->d_meta, size_t(nb * h->Gp), true))) return rc;
+    if ((rc = dev_alloc(h, &h->d_touched, size_t(h->Gp), true))) return rc;
+    if (h->cfg.track_entropy) {
+        if ((rc = dev_alloc(h, &h->d_entropy, size_t(nb * h->Gp)))) return rc;
+    }
+    if ((rc = dev_alloc(h, &h->d_ds, size_t(nb * h->B), true))) return rc;
+    if ((rc = dev_alloc(h, &h->d_benefit, size_t(nb * 2 * h->B), true))) return rc;
+    if ((rc = dev_alloc(h, &h->d_strat, size_t(h->strat_bytes)))) return rc;
+    HIPCHK(hipMemsetAsync(h->d_strat, 1, size_t(h->strat_bytes), h->stream));       // reference.py:118
+    if ((rc = dev_alloc(h, &h->d_bucket_on, size_t(nb * h->NBK), true))) return rc;
+    if ((rc = dev_alloc(h, &h->d_bucket_sums, size_t(nb * h->NBK), true))) return rc;
+    if ((rc = dev_alloc(h, &h->d_drop_count, h->filt.size(), true))) return rc;
+    if ((rc = dev_alloc(h, &h->d_stats, size_t(BOSSX_HIST_BINS * 3 + 4), true))) return rc;
+    if ((rc = dev_alloc(h, &h->d_err, 1, true))) return rc;
+    if ((rc = dev_alloc(h, &h->d_lut_score, size_t(BOSSX_NCOMP) * 4, true))) return rc;
+    if ((rc = dev_alloc(h, &h->d_lut_ent, size_t(BOSSX_NCOMP) * 4, true))) return rc;
+    if ((rc = upload_vec(h, &h->d_tile_off, tile_off))) return rc;
+    if ((rc = upload_vec(h, &h->d_site_off, site_off))) return rc;
+    if ((rc = upload_vec(h, &h->d_length, length))) return rc;
+    if ((rc = upload_vec(h, &h->d_bin_off, bin_off))) return rc;
+    if ((rc = upload_vec(h, &h->d_row_off, row_off))) return rc;
+    if ((rc = upload_vec(h, &h->d_strat_off, strat_off))) return rc;
+    if ((rc = upload_vec(h, &h->d_bucket_off, bucket_off))) return rc;
+    if ((rc = upload_vec(h, &h->d_local, local))) return rc;
+    std::vector<int32_t> thr(h->filt.size(), -1);
+    if ((rc = upload_vec(h, &h->d_drop_thr, thr))) return rc;
+    // reference base codes into the site-state bytes (bits 0-1), replicated per barcode
+    for (int32_t fi : h->filt) {
+        const ContigInfo &c = h->contigs[size_t(fi)];
+        const std::vector<uint8_t> &codes = h->host_codes[size_t(fi)];
+        for (int64_t b = 0; b < nb; ++b)
+            HIPCHK(hipMemcpy(h->d_meta + b * h->Gp + c.site_off, codes.data(), codes.size(), hipMemcpyHostToDevice));
+    }
+    if (h->d_entropy) {
+        // fill with ent0 (reference.py:105)
+        std::vector<double> fill(size_t(1) << 20, ent0);
+        const size_t total = size_t(nb * h->Gp);
+        for (size_t o = 0; o < total; o += fill.size()) {
+            const size_t nfill = std::min(fill.size(), total - o);
+            HIPCHK(hipMemcpy(h->d_entropy + o, fill.data(), nfill * sizeof(double), hipMemcpyHostToDevice));
+        }
+    }
+    h->host_codes.clear(); h->host_codes.shrink_to_fit();
+    // binomial table C(q, k), k = 2..5
+    uint32_t bn[4][36];
+    for (int k = 2; k <= 5; ++k)
+        for (int q = 0; q < 36; ++q) {
+            uint64_t v = 1;
+            if (q < k) v = 0;
+            else for (int i = 0; i < k; ++i) v = v * uint64_t(q - i) / uint64_t(i + 1);
+            bn[k - 2][q] = uint32_t(v);
+        }
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_binom), bn, sizeof(bn)));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->finalized = true;
+    return BOSSX_OK;
+}
+
+int bossx_set_lut(bossx_engine *h, const double *score, const double *entropy, int64_t n) {
+    if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "set_lut before finalize");
+    if (n != int64_t(BOSSX_NCOMP) * 4 || !score || !entropy) return fail(h, BOSSX_E_INVALID, "LUT must have NCOMP*4 entries");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipMemcpy(h->d_lut_score, score, size_t(n) * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_lut_ent, entropy, size_t(n) * sizeof(double), hipMemcpyHostToDevice));
+    h->lut_set = true;
+    return BOSSX_OK;
+}
+
+int bossx_stage_batch(bossx_engine *h, const char *paf, size_t paf_len, const char *names,
+                      const int64_t *name_off, const char *seqs, const int64_t *seq_off,
+                      const int32_t *barcodes, int32_t n_reads, int32_t min_len,
+                      bossx_batch_summary *summary, int32_t *n_rec, int64_t *aligned_bases) {
+    if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "stage_batch before finalize");
+    if (n_reads < 0 || (n_reads > 0 && (!names || !name_off || !seqs || !seq_off))) return fail(h, BOSSX_E_INVALID, "bad batch arrays");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    ParseInput in{paf ? paf : "", paf ? paf_len : 0, names, name_off, seq_off, barcodes, n_reads, min_len, h->nb};
+    ParsedBatch pb;
+    std::string err;
+    int rc = parse_paf_batch(in, h->contigs, h->index, summary, pb, err);
+    if (rc) return fail(h, rc, err);
+    if (n_rec) *n_rec = pb.n_rec;
+    if (aligned_bases) *aligned_bases = int64_t(pb.total_emit);
+    // the previous staged batch may still be read by an in-flight ingest kernel
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t blob_bytes = n_reads > 0 ? size_t(seq_off[n_reads]) : 0;
+    if (blob_bytes >= (size_t(1) << 32)) return fail(h, BOSSX_E_RANGE, "read blob larger than 4 GiB");
+    if (pb.ops.size() > h->ops_cap) {
+        if (h->d_ops) HIPCHK(hipFree(h->d_ops));
+        h->ops_cap = pb.ops.size() * 5 / 4 + 1024;
+        if ((rc = dev_alloc(h, &h->d_ops, h->ops_cap))) return rc;
+    }
+    if (pb.tile_first_op.size() > h->tiles_cap) {
+        if (h->d_tiles) HIPCHK(hipFree(h->d_tiles));
+        h->tiles_cap = pb.tile_first_op.size() * 5 / 4 + 64;
+        if ((rc = dev_alloc(h, &h->d_tiles, h->tiles_cap))) return rc;
+    }
+    if (blob_bytes + 16 > h->blob_cap) {
+        if (h->d_blob) HIPCHK(hipFree(h->d_blob));
+        h->blob_cap = (blob_bytes + 16) * 5 / 4;
+        if ((rc = dev_alloc(h, &h->d_blob, h->blob_cap))) return rc;
+    }
+    if (!pb.ops.empty()) {
+        HIPCHK(hipMemcpyAsync(h->d_ops, pb.ops.data(), pb.ops.size() * sizeof(EmitOp), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_tiles, pb.tile_first_op.data(), pb.tile_first_op.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+        if (blob_bytes) HIPCHK(hipMemcpyAsync(h->d_blob, seqs, blob_bytes, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));   // inputs are borrowed for the call only
+    }
+    h->staged = std::move(pb);
+    h->has_staged = true;
+    return BOSSX_OK;
+}
+
+int bossx_ingest_staged(bossx_engine *h) {
+    if (!h || !h->has_staged) return fail(h, BOSSX_E_INVALID, "no staged batch");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const ParsedBatch &pb = h->staged;
+    for (size_t i = 0; i < h->contigs.size(); ++i) h->contigs[i].cov_total += pb.emitted_per_contig[i];
+    if (pb.total_emit == 0) return BOSSX_OK;
+    const uint32_t n_tiles = uint32_t((pb.total_emit + kEmitTile - 1) / kEmitTile);
+    time_begin(h, BOSSX_K_INGEST);
+    hipLaunchKernelGGL(ingest_scatter_kernel, dim3(n_tiles), dim3(256), 0, h->stream, h->d_ops, h->d_tiles,
+                       uint32_t(pb.ops.size()), pb.total_emit, h->d_blob, reinterpret_cast<uint32_t *>(h->d_cov),
+                       h->d_touched, uint64_t(h->Gp / 2), h->d_err);
+    // algorithmic bytes: 1 B read base + 2 B counter read + 2 B counter write + 1 B touched flag
+    time_end(h, BOSSX_K_INGEST, 6.0 * double(pb.total_emit) + 16.0 * double(pb.ops.size()));
+    HIPCHK(hipGetLastError());
+    return BOSSX_OK;
+}
+
+int bossx_ingest_paf(bossx_engine *h, const char *paf, size_t paf_len, const char *names,
+                     const int64_t *name_off, const char *seqs, const int64_t *seq_off,
+                     const int32_t *barcodes, int32_t n_reads, int32_t min_len,
+                     bossx_batch_summary *summary, int32_t *n_rec, int64_t *aligned_bases) {
+    int rc = bossx_stage_batch(h, paf, paf_len, names, name_off, seqs, seq_off, barcodes, n_reads, min_len,
+                               summary, n_rec, aligned_bases);
+    if (rc) return rc;
+    return bossx_ingest_staged(h);
+}
+
+int bossx_sweep(bossx_engine *h) {
+    if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "sweep before finalize");
+    if (!h->lut_set) return fail(h, BOSSX_E_INVALID, "sweep before set_lut");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    // dropout thresholds of this update: mean depth per contig (reference.py:157-158, 174-176)
+    int rc = ensure_pin(h, h->filt.size() * sizeof(int32_t));
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));            // pinned scratch reuse
+    int32_t *thr = static_cast<int32_t *>(h->h_pin);
+    for (size_t k = 0; k < h->filt.size(); ++k) {
+        const ContigInfo &c = h->contigs[size_t(h->filt[k])];
+        const double mean = double(c.cov_total) / double(c.length * int64_t(h->nb));
+        thr[k] = mean > 5 ? int32_t(mean / 8) : -1;
+    }
+    HIPCHK(hipMemcpyAsync(h->d_drop_thr, thr, h->filt.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_bucket_sums, 0, size_t(h->nb * h->NBK) * sizeof(unsigned long long), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_drop_count, 0, h->filt.size() * sizeof(unsigned long long), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_ds, 0, size_t(h->nb * h->B) * sizeof(double), h->stream));
+    SweepParams P = sweep_params(h);
+    time_begin(h, BOSSX_K_SWEEP);
+    hipLaunchKernelGGL(site_sweep_kernel, dim3(uint32_t(h->n_tiles)), dim3(256), 0, h->stream, P);
+    // algorithmic bytes per site*barcode: 10 B counters + 1 B state read; per site: 1 B touched
+    // read; per 100-site bin: 8 B downsampled score write (entropy and state write-backs are
+    // data dependent and not counted)
+    double sites = 0;
+    for (int32_t fi : h->filt) sites += double(h->contigs[size_t(fi)].length);
+    time_end(h, BOSSX_K_SWEEP, sites * h->nb * 11.0 + sites * 1.0 + double(h->B) * h->nb * 8.0);
+    HIPCHK(hipGetLastError());
+    return BOSSX_OK;
+}
+
+int bossx_get_bucket_sums(bossx_engine *h, int32_t contig, uint64_t *dst) {
+    int rc = check_contig(h, contig, true);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const ContigInfo &c = h->contigs[size_t(contig)];
+    const int64_t nfull = c.length / kBucket;
+    for (int32_t b = 0; b < h->nb; ++b)
+        HIPCHK(hipMemcpyAsync(dst + int64_t(b) * nfull, h->d_bucket_sums + int64_t(b) * h->NBK + c.bucket_off,
+                              size_t(nfull) * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    int32_t flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, h->d_err, sizeof(flag), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (flag) {
+        HIPCHK(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
+        return fail(h, BOSSX_E_RANGE, "a read contains a base other than A/C/G/T inside an aligned segment");
+    }
+    return BOSSX_OK;
+}
+
+int bossx_set_bucket_switches(bossx_engine *h, int32_t contig, const uint8_t *sw) {
+    int rc = check_contig(h, contig, true);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const ContigInfo &c = h->contigs[size_t(contig)];
+    std::vector<uint8_t> plane(size_t(c.n_buckets));
+    for (int32_t b = 0; b < h->nb; ++b) {
+        for (int64_t i = 0; i < c.n_buckets; ++i) plane[size_t(i)] = sw[i * h->nb + b] ? 1 : 0;
+        HIPCHK(hipMemcpy(h->d_bucket_on + int64_t(b) * h->NBK + c.bucket_off, plane.data(), plane.size(), hipMemcpyHostToDevice));
+    }
+    return BOSSX_OK;
+}
+
+int bossx_benefit(bossx_engine *h, const int32_t *windows, const double *mult, double *max_benefit) {
+    if (!h || !h->finalized || !windows || !mult) return fail(h, BOSSX_E_INVALID, "bad benefit call");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    ChainParams P;
+    int32_t wmax = 0;
+    for (int k = 0; k < BOSSX_NWIN; ++k) { P.w[k] = windows[k]; wmax = std::max(wmax, windows[k]); }
+    for (int i = 0; i < 10; ++i) P.m[i] = mult[i];
+    for (int32_t fi : h->filt) {
+        const ContigInfo &c = h->contigs[size_t(fi)];
+        for (int k = 0; k < BOSSX_NWIN; ++k)
+            if (windows[k] < 1 || windows[k] > c.T + 1)       // Bottleneck: window must be in [1, n]
+                return fail(h, BOSSX_E_WINDOW, "Moving window (=" + std::to_string(windows[k]) + ") must between 1 and " +
+                                                  std::to_string(c.T + 1) + ", inclusive");
+    }
+    int32_t ring = 128;
+    while (ring < wmax + 64) ring <<= 1;
+    if (size_t(ring) * 8 > 150 * 1024) return fail(h, BOSSX_E_WINDOW, "read-length window exceeds the LDS ring");
+    P.ds = h->d_ds; P.benefit = h->d_benefit; P.max_bits = h->d_stats; P.ct = table_of(h);
+    P.B = h->B; P.nb = h->nb; P.ring = ring;
+    const int64_t target = h->n_sites_all / kWindow;
+    P.max_limit = std::min<int64_t>(h->B, target);
+    HIPCHK(hipMemsetAsync(h->d_stats, 0, sizeof(unsigned long long), h->stream));
+    const size_t lds = size_t(ring) * sizeof(double);
+    if (lds > 48 * 1024)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    time_begin(h, BOSSX_K_BENEFIT);
+    hipLaunchKernelGGL(benefit_chain_kernel, dim3(uint32_t(h->filt.size() * size_t(h->nb) * 2)), dim3(64), lds,
+                       h->stream, P);
+    time_end(h, BOSSX_K_BENEFIT, double(h->B) * h->nb * (2 * 8.0 + 2 * 8.0));
+    HIPCHK(hipGetLastError());
+    unsigned long long bits = 0;
+    HIPCHK(hipMemcpyAsync(&bits, h->d_stats, sizeof(bits), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double mx;
+    memcpy(&mx, &bits, sizeof(mx));
+    if (max_benefit) *max_benefit = mx;
+    return BOSSX_OK;
+}
+
+int bossx_histogram(bossx_engine *h, double normaliser, const bossx_fhat_desc *fh, int64_t *counts,
+                    uint64_t *fgrid_fx, uint64_t *ubar0_fx) {
+    if (!h || !h->finalized || !fh || !fh->fhat_c || !counts || !fgrid_fx || !ubar0_fx) return fail(h, BOSSX_E_INVALID, "bad histogram call");
+    if (!(normaliser > 0)) return fail(h, BOSSX_E_EMPTY, "no non-zero benefit (np.max of an empty array)");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int64_t target = h->n_sites_all / kWindow;
+    if (fh->target != target) return fail(h, BOSSX_E_INVALID, "fhat target does not match Reference.n_sites // 100");
+    if (fh->rep != 20) return fail(h, BOSSX_E_INVALID, "fhat repeat factor must be 20");
+    int rc;
+    if (fh->n_windows * 2 > h->fhat_cap) {
+        if (h->d_fhat) HIPCHK(hipFree(h->d_fhat));
+        h->fhat_cap = fh->n_windows * 2 + 64;
+        if ((rc = dev_alloc(h, &h->d_fhat, size_t(h->fhat_cap)))) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(h->d_fhat, fh->fhat_c, size_t(fh->n_windows) * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const size_t nstat = size_t(BOSSX_HIST_BINS) * 3 + 2;
+    HIPCHK(hipMemsetAsync(h->d_stats, 0, (nstat + 2) * sizeof(unsigned long long), h->stream));
+    HistParams P;
+    P.benefit = h->d_benefit; P.fhat_c = h->d_fhat;
+    P.counts = h->d_stats + 2; P.fgrid = h->d_stats + 2 + BOSSX_HIST_BINS; P.ubar = h->d_stats + 2 + BOSSX_HIST_BINS * 3;
+    P.ct = table_of(h); P.B = h->B; P.target = target; P.dpad = target > h->B ? target - h->B : 0;
+    P.target_rs = fh->target_rs; P.d2 = target - fh->target_rs;
+    P.fexp = fh->n_windows * fh->rep; P.d1 = fh->target_rs - P.fexp;
+    P.nb = h->nb; P.all_local = 1; P.norm = normaliser;
+    if (P.d2 < 0) P.d2 = 0;   // trimmed instead of padded: indices unchanged
+    if (P.d1 < 0) P.d1 = 0;
+    const int64_t blocks = std::min<int64_t>((target + 255) / 256, 2048);
+    time_begin(h, BOSSX_K_HIST);
+    hipLaunchKernelGGL(threshold_hist_kernel, dim3(uint32_t(std::max<int64_t>(blocks, 1)), uint32_t(h->nb * 2)), dim3(256), 0, h->stream, P);
+    time_end(h, BOSSX_K_HIST, double(target) * h->nb * 2 * 8.0);
+    HIPCHK(hipGetLastError());
+    std::vector<unsigned long long> host(nstat);
+    HIPCHK(hipMemcpyAsync(host.data(), h->d_stats + 2, nstat * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < BOSSX_HIST_BINS; ++i) counts[i] = int64_t(host[size_t(i)]);
+    memcpy(fgrid_fx, host.data() + BOSSX_HIST_BINS, size_t(BOSSX_HIST_BINS) * 2 * sizeof(uint64_t));
+    memcpy(ubar0_fx, host.data() + BOSSX_HIST_BINS * 3, 2 * sizeof(uint64_t));
+    return BOSSX_OK;
+}
+
+int bossx_apply_threshold(bossx_engine *h, double threshold) {
+    if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "bad apply_threshold call");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    MaskParams P;
+    P.benefit = h->d_benefit; P.bucket_on = h->d_bucket_on; P.strat = h->d_strat; P.ct = table_of(h);
+    P.B = h->B; P.NBK = h->NBK; P.rows = h->rows; P.nb = h->nb; P.threshold = threshold;
+    const int64_t blocks = std::min<int64_t>((h->rows + 255) / 256, 4096);
+    time_begin(h, BOSSX_K_MASK);
+    hipLaunchKernelGGL(strategy_mask_kernel, dim3(uint32_t(std::max<int64_t>(blocks, 1))), dim3(256), 0, h->stream, P);
+    time_end(h, BOSSX_K_MASK, double(h->rows) * h->nb * 2 * 9.0);
+    HIPCHK(hipGetLastError());
+    return BOSSX_OK;
+}
+
+int bossx_get_strat(bossx_engine *h, int32_t contig, uint8_t *dst) {
+    int rc = check_contig(h, contig, false);
+    if (rc) return rc;
+    const ContigInfo &c = h->contigs[size_t(contig)];
+    if (c.rejected) { dst[0] = 0; return BOSSX_OK; }
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipMemcpyAsync(dst, h->d_strat + c.strat_off, size_t(c.T * 2 * h->nb), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return BOSSX_OK;
+}
+
+int32_t bossx_n_contigs(const bossx_engine *h) { return h ? int32_t(h->contigs.size()) : 0; }
+int64_t bossx_contig_length(const bossx_engine *h, int32_t c) {
+    return (h && c >= 0 && c < int32_t(h->contigs.size())) ? h->contigs[size_t(c)].length : -1;
+}
+int64_t bossx_n_sites(const bossx_engine *h) { return h ? h->n_sites_all : 0; }
+int64_t bossx_merged_bins(const bossx_engine *h) { return h ? h->B : 0; }
+
+int bossx_export(bossx_engine *h, int32_t contig, int32_t which, void *dst, size_t dst_bytes) {
+    int rc = check_contig(h, contig, true);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const ContigInfo &c = h->contigs[size_t(contig)];
+    const int64_t L = c.length, nb = h->nb, nbin = c.T + 1;
+    auto need = [&](size_t n) { return dst_bytes >= n; };
+    switch (which) {
+        case 0: {
+            if (!need(size_t(nb * 5 * L) * 2)) return fail(h, BOSSX_E_INVALID, "export buffer too small");
+            for (int64_t p = 0; p < nb * 5; ++p)
+                HIPCHK(hipMemcpyAsync(static_cast<uint16_t *>(dst) + p * L, h->d_cov + p * h->Gp + c.site_off,
+                                      size_t(L) * 2, hipMemcpyDeviceToHost, h->stream));
+            break;
+        }
+        case 1: {
+            if (!need(size_t(nb * L) * 8)) return fail(h, BOSSX_E_INVALID, "export buffer too small");
+            double *tmp = nullptr;
+            if ((rc = dev_alloc(h, &tmp, size_t(nb * L)))) return rc;
+            SweepParams P = sweep_params(h);
+            const int64_t blocks = std::min<int64_t>((L + 255) / 256, 4096);
+            hipLaunchKernelGGL(export_scores_kernel, dim3(uint32_t(blocks)), dim3(256), 0, h->stream, P, c.filt_index, tmp);
+            hipError_t e1 = hipMemcpyAsync(dst, tmp, size_t(nb * L) * 8, hipMemcpyDeviceToHost, h->stream);
+            hipError_t e2 = hipStreamSynchronize(h->stream);
+            hipFree(tmp);
+            HIPCHK(e1); HIPCHK(e2);
+            break;
+        }
+        case 2: {
+            if (!h->d_entropy) return fail(h, BOSSX_E_INVALID, "entropy tracking is off");
+            if (!need(size_t(nb * L) * 8)) return fail(h, BOSSX_E_INVALID, "export buffer too small");
+            for (int64_t b = 0; b < nb; ++b)
+                HIPCHK(hipMemcpyAsync(static_cast<double *>(dst) + b * L, h->d_entropy + b * h->Gp + c.site_off,
+                                      size_t(L) * 8, hipMemcpyDeviceToHost, h->stream));
+            break;
+        }
+        case 3: {
+            if (!need(size_t(nb * nbin) * 8)) return fail(h, BOSSX_E_INVALID, "export buffer too small");
+            for (int64_t b = 0; b < nb; ++b)
+                HIPCHK(hipMemcpyAsync(static_cast<double *>(dst) + b * nbin, h->d_ds + b * h->B + c.bin_off,
+                                      size_t(nbin) * 8, hipMemcpyDeviceToHost, h->stream));
+            break;
+        }
+        case 4: {
+            if (!need(size_t(nb * 2 * nbin) * 8)) return fail(h, BOSSX_E_INVALID, "export buffer too small");
+            for (int64_t p = 0; p < nb * 2; ++p)
+                HIPCHK(hipMemcpyAsync(static_cast<double *>(dst) + p * nbin, h->d_benefit + p * h->B + c.bin_off,
+                                      size_t(nbin) * 8, hipMemcpyDeviceToHost, h->stream));
+            break;
+        }
+        case 5: {
+            if (!need(size_t(nb * L))) return fail(h, BOSSX_E_INVALID, "export buffer too small");
+            for (int64_t b = 0; b < nb; ++b)
+                HIPCHK(hipMemcpyAsync(static_cast<uint8_t *>(dst) + b * L, h->d_meta + b * h->Gp + c.site_off,
+                                      size_t(L), hipMemcpyDeviceToHost, h->stream));
+            break;
+        }
+        case 6: {
+            if (!need(size_t(L))) return fail(h, BOSSX_E_INVALID, "export buffer too small");
+            HIPCHK(hipMemcpyAsync(dst, h->d_touched + c.site_off, size_t(L), hipMemcpyDeviceToHost, h->stream));
+            break;
+        }
+        default:
+            return fail(h, BOSSX_E_INVALID, "unknown export selector");
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return BOSSX_OK;
+}
+
+int bossx_import(bossx_engine *h, int32_t contig, int32_t which, const void *src, size_t src_bytes) {
+    int rc = check_contig(h, contig, true);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    ContigInfo &c = h->contigs[size_t(contig)];
+    const int64_t L = c.length, nb = h->nb;
+    switch (which) {
+        case 0: {
+            if (src_bytes != size_t(nb * 5 * L) * 2) return fail(h, BOSSX_E_INVALID, "import size mismatch");
+            for (int64_t p = 0; p < nb * 5; ++p)
+                HIPCHK(hipMemcpy(h->d_cov + p * h->Gp + c.site_off, static_cast<const uint16_t *>(src) + p * L,
+                                 size_t(L) * 2, hipMemcpyHostToDevice));
+            unsigned long long *d_tot = h->d_stats;
+            HIPCHK(hipMemsetAsync(d_tot, 0, sizeof(unsigned long long), h->stream));
+            hipLaunchKernelGGL(contig_total_kernel, dim3(1024), dim3(256), 0, h->stream, h->d_cov, h->Gp, h->nb,
+                               c.site_off, L, d_tot);
+            unsigned long long tot = 0;
+            HIPCHK(hipMemcpyAsync(&tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            c.cov_total = tot;
+            break;
+        }
+        case 2: {
+            if (!h->d_entropy) return fail(h, BOSSX_E_INVALID, "entropy tracking is off");
+            if (src_bytes != size_t(nb * L) * 8) return fail(h, BOSSX_E_INVALID, "import size mismatch");
+            for (int64_t b = 0; b < nb; ++b)
+                HIPCHK(hipMemcpy(h->d_entropy + b * h->Gp + c.site_off, static_cast<const double *>(src) + b * L,
+                                 size_t(L) * 8, hipMemcpyHostToDevice));
+            break;
+        }
+        case 5: {
+            if (src_bytes != size_t(nb * L)) return fail(h, BOSSX_E_INVALID, "import size mismatch");
+            for (int64_t b = 0; b < nb; ++b)
+                HIPCHK(hipMemcpy(h->d_meta + b * h->Gp + c.site_off, static_cast<const uint8_t *>(src) + b * L,
+                                 size_t(L), hipMemcpyHostToDevice));
+            break;
+        }
+        case 6: {
+            if (src_bytes != size_t(L)) return fail(h, BOSSX_E_INVALID, "import size mismatch");
+            HIPCHK(hipMemcpy(h->d_touched + c.site_off, src, size_t(L), hipMemcpyHostToDevice));
+            break;
+        }
+        default:
+            return fail(h, BOSSX_E_INVALID, "unknown import selector");
+    }
+    return BOSSX_OK;
+}
+
+int bossx_preload_coverage(bossx_engine *h, double depth, uint64_t seed) {
+    if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "preload before finalize");
+    if (!(depth >= 0) || depth > 60) return fail(h, BOSSX_E_INVALID, "depth must be in [0, 60]");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    for (int32_t fi : h->filt) {
+        ContigInfo &c = h->contigs[size_t(fi)];
+        const int64_t blocks = std::min<int64_t>((c.length + 255) / 256, 8192);
+        hipLaunchKernelGGL(preload_kernel, dim3(uint32_t(blocks)), dim3(256), 0, h->stream, h->d_cov, h->d_meta,
+                           h->d_touched, h->Gp, h->nb, c.site_off, c.length, depth, seed);
+        unsigned long long *d_tot = h->d_stats;
+        HIPCHK(hipMemsetAsync(d_tot, 0, sizeof(unsigned long long), h->stream));
+        hipLaunchKernelGGL(contig_total_kernel, dim3(1024), dim3(256), 0, h->stream, h->d_cov, h->Gp, h->nb,
+                           c.site_off, c.length, d_tot);
+        unsigned long long tot = 0;
+        HIPCHK(hipMemcpyAsync(&tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        c.cov_total = tot;
+    }
+    HIPCHK(hipGetLastError());
+    return BOSSX_OK;
+}
+
+int bossx_enable_timing(bossx_engine *h, int32_t on) {
+    if (!h) return BOSSX_E_INVALID;
+    h->timing = on != 0;
+    return BOSSX_OK;
+}
+
+int bossx_kernel_ms(bossx_engine *h, float *ms_last, double *ms_total, int64_t *launches) {
+    if (!h) return BOSSX_E_INVALID;
+    time_collect(h);
+    for (int k = 0; k < BOSSX_K_COUNT; ++k) {
+        if (ms_last) ms_last[k] = h->ms_last[k];
+        if (ms_total) ms_total[k] = h->ms_total[k];
+        if (launches) launches[k] = h->launches[k];
+    }
+    return BOSSX_OK;
+}
+
+int bossx_kernel_bytes(bossx_engine *h, double *bytes_last) {
+    if (!h || !bytes_last) return BOSSX_E_INVALID;
+    for (int k = 0; k < BOSSX_K_COUNT; ++k) bytes_last[k] = h->bytes_last[k];
+    return BOSSX_OK;
+}
+
+int bossx_synchronize(bossx_engine *h) {
+    if (!h) return BOSSX_E_INVALID;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return BOSSX_OK;
+}
+
+}  // extern "C"

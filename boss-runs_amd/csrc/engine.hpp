@@ -1,0 +1,77 @@
+// Internal definitions shared by the host-side PAF/CIGAR front end (paf_host.cpp) and the
+// HIP engine (bossx.hip).  Not part of the C-ABI (that is include/bossx.h).
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "bossx.h"
+
+namespace bossx {
+
+constexpr int kWindow = BOSSX_WINDOW;      // 100-bp strategy window
+constexpr int kBucket = BOSSX_BUCKET;      // 20-kb activation bucket
+constexpr int kTileSites = 2000;           // sites per sweep tile: 20 bins, 1/10 bucket
+constexpr int kTileBins = kTileSites / kWindow;
+constexpr int kEmitTile = 2048;            // emitted reference bases per ingest tile
+
+// One emitting CIGAR run (M-like or D) of a chosen mapping, 16 bytes, loaded as one uint4.
+//   emit_start : index of its first emitted base in the batch-wide emit order
+//   site_lo    : low 32 bits of the padded global site index of that base
+//   qpos       : byte index into the uploaded read blob of the first query base (M-like);
+//                walks +1 per base on '+' mappings, -1 (and complemented) on '-' mappings
+//   meta       : bits 0-7 site_hi, 8-15 barcode, 16 reverse strand, 17 deletion run
+struct alignas(16) EmitOp {
+    uint32_t emit_start;
+    uint32_t site_lo;
+    uint32_t qpos;
+    uint32_t meta;
+};
+constexpr uint32_t kOpRev = 1u << 16;
+constexpr uint32_t kOpDel = 1u << 17;
+
+struct ContigInfo {
+    std::string name;
+    int64_t length = 0;       // Contig.length (4 for a rejected dummy)
+    bool rejected = false;
+    int32_t filt_index = -1;  // index among non-rejected contigs (merge order), -1 if rejected
+    // geometry of non-rejected contigs
+    int64_t site_off = 0;     // first padded global site (multiple of kTileSites)
+    int64_t n_tiles = 0;
+    int64_t tile_off = 0;
+    int64_t T = 0;            // length // 100  = strat rows
+    int64_t bin_off = 0;      // first merged bin (block of T+1 bins)
+    int64_t row_off = 0;      // first strat row = sum of T of predecessors (core.py:155)
+    int64_t strat_off = 0;    // byte offset in the strat buffer (rows*2*nb)
+    int64_t n_buckets = 0;    // length // 20000 + 1
+    int64_t bucket_off = 0;
+    uint64_t cov_total = 0;   // sum of all counters of this contig (all barcodes)
+};
+
+struct ParsedBatch {
+    std::vector<EmitOp> ops;
+    std::vector<uint32_t> tile_first_op;   // n_tiles + 1 entries
+    uint64_t total_emit = 0;
+    std::vector<uint64_t> emitted_per_contig;   // indexed by contig add order
+    int32_t n_rec = 0;
+};
+
+struct ParseInput {
+    const char *paf; size_t paf_len;
+    const char *names; const int64_t *name_off;
+    const int64_t *seq_off;
+    const int32_t *barcodes;
+    int32_t n_reads;
+    int32_t min_len;
+    int32_t nbarcodes;
+};
+
+// Parses the PAF text, picks the best mapping per read and expands CIGARs into emit runs.
+// Returns BOSSX_OK or an error code with `err` filled.  Nothing is produced on error.
+int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs,
+                    const std::unordered_map<std::string, int32_t> &contig_index,
+                    bossx_batch_summary *summary, ParsedBatch &out, std::string &err);
+
+}  // namespace bossx

@@ -1,0 +1,223 @@
+"""numpy-friendly wrapper around one bossx engine handle (one GPU)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+EXPORT = dict(coverage=0, scores=1, entropy=2, scores_ds=3, benefit=4, state=5, touched=6)
+
+
+class Engine:
+    def __init__(self, nbarcodes=1, device=0, track_entropy=True, stream=None):
+        self.lib = _lib.load()
+        self.nb = int(nbarcodes)
+        cfg = _lib.Config(device=int(device), nbarcodes=self.nb, track_entropy=int(bool(track_entropy)),
+                          reserved=0, stream=stream)
+        h = C.c_void_p()
+        rc = self.lib.bossx_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise _lib.BossxError(
+                "bossx_create failed (%d): no usable HIP device. The decision-update path has no "
+                "CPU fallback." % rc)
+        self.h = h
+        self.names = []
+        self.lengths = []
+        self.rejected = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bossx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        _lib.check(self.lib, self.h, rc)
+
+    # ---- set-up --------------------------------------------------------------------------
+    def add_contig(self, name, seq, rejected=False):
+        """seq: str/bytes (ASCII) or None for a rejected contig."""
+        if rejected:
+            self._ck(self.lib.bossx_add_contig(self.h, name.encode(), None, 0, 1))
+            self.lengths.append(4)
+        else:
+            raw = seq.encode("ascii") if isinstance(seq, str) else bytes(seq)
+            self._ck(self.lib.bossx_add_contig(self.h, name.encode(), raw, len(raw), 0))
+            self.lengths.append(len(raw))
+        self.names.append(name.strip().split(" ")[0])
+        self.rejected.append(bool(rejected))
+        return len(self.names) - 1
+
+    def finalize(self, score0, ent0):
+        self._ck(self.lib.bossx_finalize(self.h, float(score0), float(ent0)))
+
+    def set_lut(self, score, entropy):
+        score = np.ascontiguousarray(score, dtype=np.float64).reshape(-1)
+        entropy = np.ascontiguousarray(entropy, dtype=np.float64).reshape(-1)
+        self._ck(self.lib.bossx_set_lut(self.h, score.ctypes.data, entropy.ctypes.data, score.size))
+
+    # ---- ingestion -----------------------------------------------------------------------
+    @staticmethod
+    def pack_reads(seqs):
+        """{read id: sequence} -> (names blob, name offsets, seq blob, seq offsets, ids)."""
+        ids = list(seqs.keys())
+        n = len(ids)
+        name_off = np.zeros(n + 1, dtype=np.int64)
+        seq_off = np.zeros(n + 1, dtype=np.int64)
+        if n:
+            np.cumsum([len(i.encode()) for i in ids], out=name_off[1:])
+            np.cumsum([len(s) for s in seqs.values()], out=seq_off[1:])
+        names = "".join(ids).encode()
+        blob = "".join(seqs.values()).encode("ascii")
+        return names, name_off, blob, seq_off, ids
+
+    def stage_batch(self, paf_text, seqs, barcodes=None, min_len=200, ingest=False, packed=None):
+        """Parse + upload one batch.  Returns dict of per-mapping summary arrays."""
+        names, name_off, blob, seq_off, ids = packed if packed is not None else self.pack_reads(seqs)
+        n = len(ids)
+        paf = paf_text.encode() if isinstance(paf_text, str) else bytes(paf_text)
+        bc = None
+        if barcodes is not None:
+            bc = np.ascontiguousarray([barcodes[i] for i in ids] if isinstance(barcodes, dict) else barcodes,
+                                      dtype=np.int32)
+        s = dict(read_idx=np.zeros(max(n, 1), np.int32), contig_idx=np.zeros(max(n, 1), np.int32),
+                 rev=np.zeros(max(n, 1), np.uint8), tstart=np.zeros(max(n, 1), np.int64),
+                 tend=np.zeros(max(n, 1), np.int64), qlen=np.zeros(max(n, 1), np.int64))
+        summ = _lib.BatchSummary(*[s[k].ctypes.data for k in ("read_idx", "contig_idx", "rev", "tstart", "tend", "qlen")])
+        n_rec = C.c_int32(0)
+        aligned = C.c_int64(0)
+        fn = self.lib.bossx_ingest_paf if ingest else self.lib.bossx_stage_batch
+        self._ck(fn(self.h, paf, len(paf), names, name_off.ctypes.data, blob, seq_off.ctypes.data,
+                    None if bc is None else bc.ctypes.data, n, int(min_len), C.byref(summ),
+                    C.byref(n_rec), C.byref(aligned)))
+        k = n_rec.value
+        out = {key: v[:k] for key, v in s.items()}
+        out["aligned"] = aligned.value
+        out["ids"] = ids
+        return out
+
+    def ingest_paf(self, paf_text, seqs, barcodes=None, min_len=200):
+        return self.stage_batch(paf_text, seqs, barcodes, min_len, ingest=True)
+
+    def ingest_staged(self):
+        self._ck(self.lib.bossx_ingest_staged(self.h))
+
+    # ---- update stages -------------------------------------------------------------------
+    def sweep(self):
+        self._ck(self.lib.bossx_sweep(self.h))
+
+    def bucket_sums(self, contig):
+        nfull = self.lengths[contig] // 20000
+        dst = np.zeros((self.nb, nfull), dtype=np.uint64)
+        self._ck(self.lib.bossx_get_bucket_sums(self.h, contig, dst.ctypes.data))
+        return dst
+
+    def set_bucket_switches(self, contig, switches):
+        sw = np.ascontiguousarray(switches, dtype=np.uint8)
+        assert sw.shape == (self.lengths[contig] // 20000 + 1, self.nb)
+        self._ck(self.lib.bossx_set_bucket_switches(self.h, contig, sw.ctypes.data))
+
+    def benefit(self, windows, mult):
+        w = np.ascontiguousarray(windows, dtype=np.int32)
+        m = np.ascontiguousarray(mult, dtype=np.float64)
+        assert w.shape == (_lib.NWIN,) and m.shape == (10,)
+        mx = C.c_double(0.0)
+        self._ck(self.lib.bossx_benefit(self.h, w.ctypes.data, m.ctypes.data, C.byref(mx)))
+        return mx.value
+
+    def histogram(self, normaliser, fhat_c, target_rs, target):
+        f = np.ascontiguousarray(fhat_c, dtype=np.float64)
+        desc = _lib.FhatDesc(f.ctypes.data, f.shape[0], 20, int(target_rs), int(target))
+        counts = np.zeros(_lib.HIST_BINS, dtype=np.int64)
+        fg = np.zeros((_lib.HIST_BINS, 2), dtype=np.uint64)
+        ub = np.zeros(2, dtype=np.uint64)
+        self._ck(self.lib.bossx_histogram(self.h, float(normaliser), C.byref(desc), counts.ctypes.data,
+                                          fg.ctypes.data, ub.ctypes.data))
+        return counts, fg, ub
+
+    def apply_threshold(self, threshold):
+        self._ck(self.lib.bossx_apply_threshold(self.h, float(threshold)))
+
+    def get_strat(self, contig, out=None):
+        if self.rejected[contig]:
+            return np.zeros(1, dtype=bool)
+        shape = (self.lengths[contig] // 100, 2, self.nb)
+        if out is None:
+            out = np.empty(shape, dtype=bool)
+        assert out.shape == shape and out.flags.c_contiguous
+        self._ck(self.lib.bossx_get_strat(self.h, contig, out.ctypes.data))
+        return out
+
+    # ---- introspection -------------------------------------------------------------------
+    @property
+    def n_sites(self):
+        return self.lib.bossx_n_sites(self.h)
+
+    @property
+    def merged_bins(self):
+        return self.lib.bossx_merged_bins(self.h)
+
+    def export(self, contig, which):
+        """Device state of one contig in the REFERENCE's layout."""
+        L, nb = self.lengths[contig], self.nb
+        code = EXPORT[which]
+        if which == "coverage":
+            raw = np.empty((nb, 5, L), dtype=np.uint16)
+        elif which in ("scores", "entropy"):
+            raw = np.empty((nb, L), dtype=np.float64)
+        elif which == "scores_ds":
+            raw = np.empty((nb, L // 100 + 1), dtype=np.float64)
+        elif which == "benefit":
+            raw = np.empty((nb, 2, L // 100 + 1), dtype=np.float64)
+        elif which == "state":
+            raw = np.empty((nb, L), dtype=np.uint8)
+        else:
+            raw = np.empty(L, dtype=np.uint8)
+        self._ck(self.lib.bossx_export(self.h, contig, code, raw.ctypes.data, raw.nbytes))
+        if which == "coverage":
+            return np.ascontiguousarray(raw.transpose(2, 1, 0))          # [L,5,nb]
+        if which in ("scores", "entropy", "scores_ds", "state"):
+            return np.ascontiguousarray(raw.T)                           # [L,nb]
+        if which == "benefit":
+            return np.ascontiguousarray(raw.transpose(2, 1, 0))          # [T+1,2,nb]
+        return raw
+
+    def import_state(self, contig, which, arr):
+        L, nb = self.lengths[contig], self.nb
+        if which == "coverage":
+            raw = np.ascontiguousarray(np.asarray(arr, dtype=np.uint16).transpose(2, 1, 0))
+        elif which == "entropy":
+            raw = np.ascontiguousarray(np.asarray(arr, dtype=np.float64).T)
+        elif which == "state":
+            raw = np.ascontiguousarray(np.asarray(arr, dtype=np.uint8).T)
+        elif which == "touched":
+            raw = np.ascontiguousarray(arr, dtype=np.uint8)
+        else:
+            raise ValueError(which)
+        self._ck(self.lib.bossx_import(self.h, contig, EXPORT[which], raw.ctypes.data, raw.nbytes))
+
+    def preload_coverage(self, depth, seed=1):
+        self._ck(self.lib.bossx_preload_coverage(self.h, float(depth), int(seed)))
+
+    # ---- measurement ---------------------------------------------------------------------
+    def enable_timing(self, on=True):
+        self._ck(self.lib.bossx_enable_timing(self.h, int(on)))
+
+    def kernel_stats(self):
+        n = len(_lib.K_NAMES)
+        last = np.zeros(n, np.float32)
+        total = np.zeros(n, np.float64)
+        launches = np.zeros(n, np.int64)
+        nbytes = np.zeros(n, np.float64)
+        self._ck(self.lib.bossx_kernel_ms(self.h, last.ctypes.data, total.ctypes.data, launches.ctypes.data))
+        self._ck(self.lib.bossx_kernel_bytes(self.h, nbytes.ctypes.data))
+        return {k: dict(ms_last=float(last[i]), ms_total=float(total[i]), launches=int(launches[i]),
+                        bytes_last=float(nbytes[i])) for i, k in enumerate(_lib.K_NAMES)}
+
+    def synchronize(self):
+        self._ck(self.lib.bossx_synchronize(self.h))

@@ -1,0 +1,185 @@
+"""`BossRuns` — the reference's RUNS orchestrator (boss/runs/core.py:20-224) with its numerics
+on the GPU.  Same method names, argument meaning and call order:
+
+    init() -> process_batch_runs(new_reads, new_quals) -> update_wrapper()
+           -> _write_contig_strategies(strat_dict)            (boss.npz, tmp + rename)
+
+`process_batch_paf` is `process_batch_runs` minus the mapper call, for callers that already
+hold the PAF text (simulations, tests, benchmarks).  Without the HIP extension or a GPU this
+class raises at `init()`; there is no numpy fallback.
+"""
+import logging
+from pathlib import Path
+
+import numpy as np
+
+from . import _lib
+from .config import BossConfig
+from .engine import Engine
+from .readlengthdist import ReadlengthDist
+from .readstartdist import ReadStartDist
+from .reference import Reference
+from .scoring import SiteScoring
+
+FX_SHIFT = 100          # fixed-point scale of the histogram sums (kernels.hip.inc kFxShift)
+MULT = np.arange(0.05, 1, 0.1)[::-1].copy()       # reference.py:251
+
+
+def fx_to_float(lo, hi):
+    """Exact 128-bit fixed-point accumulator -> correctly rounded float64."""
+    return ((int(hi) << 64) + int(lo)) / (1 << FX_SHIFT)
+
+
+def choose_threshold(normaliser, counts_all, fgrid_all, ubar0, time_cost):
+    """The host tail of Scoring.find_strat_thread (sequences.py:607-646) from the binned
+    statistics.  Returns (threshold, strat_size, exponents_unique)."""
+    window = 100
+    tbar0 = 300 // window + 300 // window + 400 // window
+    tc = time_cost // window
+    uniq = np.nonzero(counts_all)[0]
+    counts = counts_all[uniq]
+    f_grid = fgrid_all[uniq]
+    f_mean = f_grid / counts
+    benefit_bin = np.power(2.0, -uniq) * normaliser
+    cs_u = np.cumsum(benefit_bin * f_mean * counts) + ubar0
+    cs_t = np.cumsum(tc * counts * f_mean) + tbar0
+    size = int(np.argmax(cs_u / cs_t)) + 1
+    threshold = benefit_bin[size] if size < benefit_bin.shape[0] else benefit_bin[-1]
+    return float(threshold), size, uniq
+
+
+class Boss:
+    """Slice of boss/core.py:13-176 the RUNS path depends on: run name, output directory tree,
+    the global read-length distribution and the batch counter.  Live FASTQ discovery
+    (`_get_new_data`, MinKNOW, readfish) is out of scope and left to the caller."""
+
+    def __init__(self, args: BossConfig):
+        self.args = args
+        self.name = args.general.name
+        self.batch = 0
+        assert ' ' not in self.name
+        self.out_dir = f'./out_{self.name}'
+        (Path(self.out_dir) / "masks").mkdir(parents=True, exist_ok=True)
+        self.rl_dist = ReadlengthDist()
+
+    def _get_new_data(self):
+        raise NotImplementedError("live FASTQ scanning is outside the decision-update path")
+
+    def process_batch(self, main_processing_func):
+        """boss/core.py:137-157 without the sleep bookkeeping."""
+        new_reads, new_quals = self._get_new_data()
+        if not new_reads:
+            return self.args.general.wait
+        main_processing_func(new_reads=new_reads, new_quals=new_quals)
+        self.batch += 1
+        return 0
+
+
+class BossRuns(Boss):
+    def init(self, contigs=None, engine=None) -> None:
+        """boss/runs/core.py:23-55.  `contigs` optionally replaces the FASTA with an iterable
+        of (name, sequence)."""
+        a = self.args
+        if not a.general.barcodes:
+            self.barcodes_index = {"": 0}
+        else:
+            self.barcodes_index = {int(bc.split('barcode')[1]): i for i, bc in enumerate(a.general.barcodes)}
+        self.nbarcodes = len(self.barcodes_index)
+        self.engine = engine or Engine(nbarcodes=self.nbarcodes, device=a.gpu.device,
+                                       track_entropy=a.gpu.track_entropy)
+        self.ref = Reference(ref=a.general.ref, mmi=a.general.mmi, reject_refs=a.optional.reject_refs,
+                             barcodes=a.general.barcodes, engine=self.engine, contigs=contigs)
+        self.contigs = self.ref.contigs
+        self.contigs_filt = {n: c for n, c in self.contigs.items() if not c.rej}
+        self.contig_names = list(self.contigs.keys())
+        self.mapper = None                     # set by the caller when reads must be mapped
+        self.read_counts = {n: 0 for n in self.contigs}          # AbundanceTracker
+        self.total_reads = 0
+        self.read_starts = ReadStartDist(contigs=self.contigs_filt)
+        # Contig() is always built haploid (reference.py:314-334): haploid initial fill
+        haploid = SiteScoring(ploidy=1)
+        self.scoring = haploid if int(a.optional.ploidy) == 1 else SiteScoring(ploidy=a.optional.ploidy)
+        self.engine.finalize(score0=haploid.score0[0], ent0=haploid.ent0[0])
+        score, entropy = self.scoring.tables()
+        self.engine.set_lut(score, entropy)
+        self.threshold = None
+        self.last_stats = {}
+        self._write_contig_strategies(contig_strats=self.ref.get_strategy_dict())
+
+    def _write_contig_strategies(self, contig_strats) -> None:
+        """boss/runs/core.py:59-69."""
+        cpath_tmp = f'{self.out_dir}/masks/boss_tmp.npz'
+        np.savez(cpath_tmp, **contig_strats)
+        Path(cpath_tmp).rename(f'{self.out_dir}/masks/boss.npz')
+
+    # ---- batch entry points ---------------------------------------------------------------
+    def process_batch_runs(self, new_reads, new_quals) -> None:
+        """boss/runs/core.py:202-224.  `self.mapper` must provide
+        `map_batch_paf(sequences) -> str` (PAF text, mapper.py:68-108)."""
+        if self.mapper is None:
+            raise RuntimeError("no mapper attached: use process_batch_paf(paf_text, new_reads)")
+        paf_text = self.mapper.map_batch_paf(sequences=new_reads)
+        self.process_batch_paf(paf_text, new_reads)
+
+    def process_batch_paf(self, paf_text, new_reads, barcodes=None, min_len=200, starts_filter=None,
+                          n_reads_total=None) -> None:
+        """convert_records + _effect_increments + tracker + count_read_starts + update_wrapper
+        (core.py:214-224).  `barcodes`: {read id: barcode index} as in simulation.py:148."""
+        summ = self.engine.ingest_paf(paf_text, new_reads, barcodes=barcodes, min_len=min_len)
+        self._account_reads(summ, len(new_reads) if n_reads_total is None else n_reads_total, starts_filter)
+        self.update_wrapper()
+
+    def _account_reads(self, summ, n_reads, starts_filter=None):
+        # AbundanceTracker.update (abundance_tracker.py:58-69)
+        self.total_reads += n_reads
+        for ci in summ["contig_idx"]:
+            if ci >= 0:
+                self.read_counts[self.contig_names[ci]] += 1
+        sel = slice(None)
+        if starts_filter is not None:
+            sel = np.array([starts_filter(summ["ids"][i]) for i in summ["read_idx"]], dtype=bool)
+        self.read_starts.count_starts(self.contig_names, summ["contig_idx"][sel], summ["rev"][sel],
+                                      summ["tstart"][sel], summ["tend"][sel])
+
+    # ---- the strategy update --------------------------------------------------------------
+    def _update_scores_contigs(self) -> None:
+        """core.py:90-99 (+ the covsum passes of check_buckets and the bin sums of calc_smu):
+        one fused device sweep."""
+        self.engine.sweep()
+
+    def _check_buckets_contigs(self) -> bool:
+        """core.py:102-111."""
+        thr = self.args.optional.bucket_threshold
+        for cont in self.contigs_filt.values():
+            before = cont.bucket_switches.copy()
+            cont.check_buckets(self.engine.bucket_sums(cont.index), threshold=thr)
+            if not np.array_equal(before, cont.bucket_switches):
+                self.engine.set_bucket_switches(cont.index, cont.bucket_switches)
+        return any(any(c.switched_on) for c in self.contigs.values())
+
+    def update_wrapper(self) -> None:
+        """core.py:160-198."""
+        self._update_scores_contigs()
+        switched_on = self._check_buckets_contigs()
+        if not switched_on:
+            return
+        fhat_c, target_rs = self.read_starts.fhat_compact()
+        windows = np.concatenate(([400 // 100], self.rl_dist.approx_ccl // 100)).astype(np.int32)
+        normaliser = self.engine.benefit(windows, MULT)              # _update_benefits
+        target = self.ref.n_sites // 100
+        counts, fg, ub = self.engine.histogram(normaliser, fhat_c, target_rs, target)
+        fgrid = np.array([fx_to_float(lo, hi) for lo, hi in fg])
+        ubar0 = fx_to_float(ub[0], ub[1])
+        threshold, size, uniq = choose_threshold(normaliser, counts, fgrid, ubar0, self.rl_dist.time_cost)
+        self.threshold = threshold
+        self.last_stats = dict(normaliser=normaliser, exponents=uniq, counts=counts[uniq],
+                               f_grid=fgrid[uniq], ubar0=ubar0, strat_size=size)
+        self.engine.apply_threshold(threshold)                       # find_strat + _distribute_strategy
+        for cname, cont in self.contigs_filt.items():
+            self.engine.get_strat(cont.index, out=cont.strat)
+            f_perc = np.count_nonzero(cont.strat[:, 0]) / cont.strat.shape[0]
+            r_perc = np.count_nonzero(cont.strat[:, 1]) / cont.strat.shape[0]
+            logging.info(f'{cname}: {f_perc}, {r_perc}')
+        self._write_contig_strategies(contig_strats=self.ref.get_strategy_dict())
+
+    update_strategy = update_wrapper      # name used by BASELINE.json's north_star

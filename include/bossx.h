@@ -1,0 +1,200 @@
+/* bossx.h — C-ABI of the MI355X-native BOSS-RUNS decision-update engine.
+ *
+ * The reference (goldman-gp-ebi/BOSS-RUNS v0.4.0) is pure Python and has no FFI for this
+ * path: the path sits behind Python method calls on `BossRuns` (boss/runs/core.py:20-224)
+ * and the `boss.npz` mask file.  This header is therefore the boundary a maintainer would
+ * bind with `ctypes` from those methods (binding stub: INTEGRATION.md).  Every entry point
+ * names the reference call site(s) it replaces.
+ *
+ * Conventions
+ *   - plain C types, caller-allocated output buffers, inputs borrowed for the call only;
+ *   - every function returns 0 on success or a negative BOSSX_E_* code; the message of the
+ *     last failure on a handle is `bossx_last_error(h)`;
+ *   - one caller thread per handle; calls are synchronous unless stated otherwise;
+ *   - there is NO CPU fallback: without a HIP device `bossx_create` fails.
+ */
+#ifndef BOSSX_H
+#define BOSSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BOSSX_OK 0
+#define BOSSX_E_INVALID   (-1)  /* bad argument / call order                                  */
+#define BOSSX_E_HIP       (-2)  /* HIP runtime failure (message carries hipGetErrorString)     */
+#define BOSSX_E_PARSE     (-3)  /* malformed PAF / CIGAR (reference raises ValueError/Assert)  */
+#define BOSSX_E_KEY       (-4)  /* read id in PAF not present in the batch (KeyError)          */
+#define BOSSX_E_RANGE     (-5)  /* mapping outside its contig / non-ACGT read base (IndexError)*/
+#define BOSSX_E_WINDOW    (-6)  /* move_sum window outside [1, n] (Bottleneck ValueError)      */
+#define BOSSX_E_EMPTY     (-7)  /* no non-zero benefit (np.max of empty array: ValueError)     */
+
+#define BOSSX_WINDOW        100     /* strategy / downsampling window, reference.py:109,215   */
+#define BOSSX_BUCKET        20000   /* activation bucket, reference.py:83                      */
+#define BOSSX_MAXCOV        30      /* "maxed" depth, sequences.py:419                         */
+#define BOSSX_NCOMP         278256  /* compositions of 5 counts with sum < 30 = C(34,5)        */
+#define BOSSX_HIST_BINS     1088    /* |frexp exponent| of x/max: 0..1075, rounded up          */
+#define BOSSX_NWIN          11      /* window 4 (S_mu) + 10 read-length pieces                 */
+
+typedef struct bossx_engine bossx_engine;
+
+typedef struct bossx_config {
+    int32_t device;          /* HIP device ordinal                                             */
+    int32_t nbarcodes;       /* >= 1 (reference.py:34: nbarcodes = len(barcodes) or 1)         */
+    int32_t track_entropy;   /* keep the per-site entropy array (sequences.py:450)             */
+    int32_t reserved;
+    void   *stream;          /* hipStream_t to launch on; NULL = engine-owned stream           */
+} bossx_config;
+
+/* ---- lifetime --------------------------------------------------------------------------- */
+int  bossx_create(const bossx_config *cfg, bossx_engine **out);
+void bossx_destroy(bossx_engine *h);
+const char *bossx_last_error(const bossx_engine *h);
+const char *bossx_version(void);
+
+/* ---- reference set-up: Reference._load_contigs / Contig.__init__ (reference.py:18-118,
+ *      305-338).  Contigs are added in FASTA order, rejected ones included (they only
+ *      occupy 4 sites of Reference.n_sites and a bool[1] mask).  `seq` is ASCII, any case;
+ *      non-ACGT letters become code 0 (reference.py:46-68).  Contigs shorter than 100 kb
+ *      must be filtered by the caller (reference.py:330-331).                               */
+int bossx_add_contig(bossx_engine *h, const char *name, const char *seq, int64_t length,
+                     int32_t rejected);
+/* Allocate and initialise device state (coverage 0, scores = haploid score0, strat = 1).
+ * `score0`/`ent0`: initial fill (Contig is always built with ploidy=1, reference.py:314).   */
+int bossx_finalize(bossx_engine *h, double score0, double ent0);
+
+/* Score/entropy tables for every coverage composition with depth < 30, replacing
+ * Scoring.init_score_array + the on-demand fill (sequences.py:347-393, 433-448).
+ * Entry [rank*4 + ref]; rank = sum_k C(c0+..+c(k-1) + k-1, k), k = 1..5.                     */
+int bossx_set_lut(bossx_engine *h, const double *score, const double *entropy, int64_t n);
+
+/* ---- ingestion: Paf.parse_PAF (paf.py:631-672, min_len filter + primary filter),
+ *      Paf.choose_best_mapper (paf.py:709-722), CoverageConverter.convert_records +
+ *      _parse_cigar (sequences.py:678-794) and Contig.increment_coverage
+ *      (reference.py:122-145) for every non-rejected contig.
+ *
+ * The batch: n_reads reads; `names`/`seqs` are concatenated blobs with n_reads+1 offsets;
+ * `barcodes` is NULL (all 0) or one barcode index per read.  `paf` is the PAF text the
+ * mapper produced.  Per chosen mapping (one per mapped read, in first-appearance order) the
+ * summary arrays receive: read index, contig index in add order (-1: target unknown), strand
+ * (0 '+', 1 '-'), tstart, tend, qlen — what ReadStartDist.count_read_starts
+ * (readstartdist.py:43-82) and AbundanceTracker (abundance_tracker.py:24-41) consume.
+ * Capacity of each summary array must be >= n_reads; *n_rec returns the count.
+ *
+ * bossx_stage_batch parses and uploads (H2D) only; bossx_ingest_staged launches the
+ * coverage-scatter kernel on the staged batch (asynchronous on the engine stream);
+ * bossx_ingest_paf = stage + ingest.                                                        */
+typedef struct bossx_batch_summary {
+    int32_t *read_idx;
+    int32_t *contig_idx;
+    uint8_t *rev;
+    int64_t *tstart;
+    int64_t *tend;
+    int64_t *qlen;
+} bossx_batch_summary;
+
+int bossx_stage_batch(bossx_engine *h, const char *paf, size_t paf_len,
+                      const char *names, const int64_t *name_off,
+                      const char *seqs, const int64_t *seq_off,
+                      const int32_t *barcodes, int32_t n_reads, int32_t min_len,
+                      bossx_batch_summary *summary, int32_t *n_rec,
+                      int64_t *aligned_bases);
+int bossx_ingest_staged(bossx_engine *h);
+int bossx_ingest_paf(bossx_engine *h, const char *paf, size_t paf_len,
+                     const char *names, const int64_t *name_off,
+                     const char *seqs, const int64_t *seq_off,
+                     const int32_t *barcodes, int32_t n_reads, int32_t min_len,
+                     bossx_batch_summary *summary, int32_t *n_rec, int64_t *aligned_bases);
+
+/* ---- per-site sweep: Scoring.update_scores (sequences.py:398-455), Contig.modify_scores /
+ *      _find_dropout (reference.py:148-179), the 20-kb sums of Contig.check_buckets
+ *      (reference.py:196-199) and the 100-site in-order bin sums of Contig.calc_smu
+ *      (reference.py:225-231), fused into one pass.  Asynchronous on the engine stream.    */
+int bossx_sweep(bossx_engine *h);
+
+/* Bucket sums of the last sweep: uint64[nbarcodes][n_full_buckets(contig)] (only complete
+ * 20-kb buckets; the reference duplicates the last one into the tail bucket,
+ * utils.py:206-226).  Synchronises.                                                         */
+int bossx_get_bucket_sums(bossx_engine *h, int32_t contig, uint64_t *dst);
+/* Current bucket switches uint8[n_buckets(contig)][nbarcodes] (reference layout), decided by
+ * the caller as Contig.check_buckets does (reference.py:200-208).                           */
+int bossx_set_bucket_switches(bossx_engine *h, int32_t contig, const uint8_t *sw);
+
+/* ---- benefit: Contig.calc_smu + Contig.calc_u (reference.py:215-269) for every
+ *      non-rejected contig and barcode, with the exact Bottleneck running-sum recurrence.
+ *      windows[0] = mu/100 = 4; windows[1..10] = approx_ccl // 100; mult[10] = the
+ *      np.arange(.05,1,.1)[::-1] doubles.  Writes max(additional_benefit) over the merged,
+ *      length-adjusted array (sequences.py:588) to *max_benefit (synchronises).             */
+int bossx_benefit(bossx_engine *h, const int32_t *windows, const double *mult,
+                  double *max_benefit);
+
+/* ---- threshold statistics of Scoring.find_strat_thread (sequences.py:584-629) given the
+ *      (global) normaliser.  fhat is passed compact: `fhat_c` = float64[n_windows][2]
+ *      (already scaled by the normaliser of readstartdist.py:145-151) plus the index
+ *      arithmetic of _expand_fhat / adjust_length.  Outputs (host):
+ *      counts int64[BOSSX_HIST_BINS]; f_grid and ubar0 as exact 128-bit fixed point
+ *      (value * 2^100), little-endian limbs uint64[bins][2] and uint64[2].                  */
+typedef struct bossx_fhat_desc {
+    const double *fhat_c;      /* [n_windows][2]                                              */
+    int64_t n_windows;
+    int64_t rep;               /* 2000 / 100 = 20                                             */
+    int64_t target_rs;         /* ReadStartDist.target_size                                   */
+    int64_t target;            /* Reference.n_sites // 100                                    */
+} bossx_fhat_desc;
+
+int bossx_histogram(bossx_engine *h, double normaliser, const bossx_fhat_desc *fh,
+                    int64_t *counts, uint64_t *fgrid_fx, uint64_t *ubar0_fx);
+
+/* ---- strategy: `benefit >= threshold` (sequences.py:648) written through the bucket gate
+ *      with the reference's row arithmetic (core.py:125-155).  Asynchronous.                */
+int bossx_apply_threshold(bossx_engine *h, double threshold);
+
+/* Contig.strat as bool bytes, reference layout [length//100][2][nbarcodes] (a rejected
+ * contig has the single byte 0, reference.py:116).  Synchronises.                           */
+int bossx_get_strat(bossx_engine *h, int32_t contig, uint8_t *dst);
+
+/* ---- geometry / introspection ----------------------------------------------------------- */
+int32_t bossx_n_contigs(const bossx_engine *h);
+int64_t bossx_contig_length(const bossx_engine *h, int32_t contig);
+int64_t bossx_n_sites(const bossx_engine *h);       /* Reference.n_sites (reference.py:343)   */
+int64_t bossx_merged_bins(const bossx_engine *h);   /* sum over non-rejected of length//100+1 */
+
+/* Parity / checkpoint hooks.  `which`:
+ *   0 coverage   uint16[nb][5][L]        (reference holds [L][5][nb])
+ *   1 scores     float64[nb][L]          (materialised from site state)
+ *   2 entropy    float64[nb][L]
+ *   3 scores_ds  float64[nb][L//100+1]
+ *   4 benefit    float64[nb][2][L//100+1] (additional_benefit, reference.py:266-269)
+ *   5 site state uint8[nb][L] (bit0-1 ref base, bit2 scored, bit3 zeroed by dropout)
+ *   6 touched    uint8[L]     (change_mask rows of the pending batch)
+ * bossx_import accepts 0, 2, 5, 6.                                                            */
+int bossx_export(bossx_engine *h, int32_t contig, int32_t which, void *dst, size_t dst_bytes);
+int bossx_import(bossx_engine *h, int32_t contig, int32_t which, const void *src, size_t src_bytes);
+
+/* Synthetic preload for benchmarks: Poisson(depth) reads' worth of coverage on the reference
+ * base with substitution/deletion noise, generated on the device (no reference analogue).   */
+int bossx_preload_coverage(bossx_engine *h, double depth, uint64_t seed);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+#define BOSSX_K_INGEST   0
+#define BOSSX_K_SWEEP    1
+#define BOSSX_K_BENEFIT  2
+#define BOSSX_K_HIST     3
+#define BOSSX_K_MASK     4
+#define BOSSX_K_COUNT    5
+/* HIP-event time of the last launch of each kernel (ms) and launch counts; enabling timing
+ * brackets each kernel with hipEvents on the engine stream.                                 */
+int bossx_enable_timing(bossx_engine *h, int32_t on);
+int bossx_kernel_ms(bossx_engine *h, float *ms_last /*[BOSSX_K_COUNT]*/,
+                    double *ms_total /*[BOSSX_K_COUNT]*/, int64_t *launches /*[BOSSX_K_COUNT]*/);
+/* Algorithmic bytes of the last launch of each kernel (definition: DESIGN.md).              */
+int bossx_kernel_bytes(bossx_engine *h, double *bytes_last /*[BOSSX_K_COUNT]*/);
+int bossx_synchronize(bossx_engine *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BOSSX_H */

@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _build_oracle():
+    """The oracle's C restatement (move_sum) is compiled on demand; it is test infrastructure."""
+    import subprocess
+    so = os.path.join(REPO, "oracle", "_build", "liboracle_movesum.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", os.path.join(REPO, "oracle")], check=False,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    yield
+
+
+@pytest.fixture
+def in_tmp(tmp_path, monkeypatch):
+    """BossRuns writes ./out_<name>/ relative to the cwd (boss/core.py:44-55)."""
+    monkeypatch.chdir(tmp_path)
+    return tmp_path

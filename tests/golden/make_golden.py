@@ -13,7 +13,6 @@ Fixtures whose values pass through `bottleneck.move_sum` carry `movesum_unpinned
 (the shim restates Bottleneck 1.3.x; the real library is not installed).
 Nothing from /root/reference is copied: fixtures hold inputs (or their seeds) and outputs.
 """
-import hashlib
 import os
 import sys
 import tempfile
@@ -25,37 +24,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 sys.path[:0] = [os.path.join(HERE, "_shims"), "/root/reference", REPO]
 
+sys.path.insert(0, os.path.join(REPO, "tests"))
+from scenarios import (SCENARIOS, E2E_REJECT, E2E_BATCHES, digest, e2e_reference, e2e_batch,  # noqa: E402
+                       batch_digest)
 from boss_runs_amd import synth  # noqa: E402
-
-SCENARIOS = [  # (tag, ploidy, nbarcodes)
-    ("p1_nb1", 1, 1), ("p2_nb1", 2, 1), ("p1_nb2", 1, 2), ("p2_nb2", 2, 2)]
-E2E_LENGTHS = [150_000, 260_000, 120_000, 60_000]
-E2E_NAMES = ["ctgA", "ctgB", "ctgREJ", "ctgSHORT"]
-E2E_REJECT = "ctgREJ"
-E2E_BATCHES = 5
-E2E_READS = 420
-
-
-def digest(*arrs):
-    h = hashlib.sha256()
-    for a in arrs:
-        h.update(a if isinstance(a, (bytes, bytearray)) else np.ascontiguousarray(a).tobytes())
-    return h.hexdigest()
-
-
-def e2e_reference(seed=1):
-    return synth.make_reference(E2E_LENGTHS, seed=seed, names=E2E_NAMES)
-
-
-def e2e_batch(contigs, b, nb):
-    # hot region on ctgB, thin coverage on ctgA; the rejected / short contigs still attract reads
-    return synth.make_batch(contigs, E2E_READS, seed=10 + b, mean_len=3000.0, nbarcodes=nb,
-                            start_weights=[0.6, 1.6, 0.5, 0.5])
-
-
-def carve_hole(batch, contigs):
-    """No-op hook kept for clarity: dropout is exercised by ctgA's thin coverage."""
-    return batch
 
 
 def gen_tables(out):
@@ -147,8 +119,7 @@ def run_scenario(out, tag, ploidy, nb):
              ref_digest=np.array(digest(*[c[1] for c in contigs])))
     for b in range(E2E_BATCHES):
         batch = e2e_batch(contigs, b, nb)
-        d["b%d_input_digest" % b] = np.array(digest(batch["paf"].encode(),
-                                                    "".join(batch["seqs"].values()).encode()))
+        d["b%d_input_digest" % b] = np.array(batch_digest(batch))
         runs.rl_dist.update(read_lengths=batch["read_lengths"])
         paf = Paf.parse_PAF(StringIO(batch["paf"]), min_len=200)
         for recs in paf.values():

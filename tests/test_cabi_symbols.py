@@ -1,0 +1,46 @@
+"""The C-ABI library loads and exports every symbol include/bossx.h declares (no compute
+calls: there is no GPU in the CPU test tier), and the product refuses to run without a GPU."""
+import os
+import re
+
+import pytest
+
+from scenarios import REPO
+
+from boss_runs_amd import _lib
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, "include", "bossx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bossx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported():
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), "libbossx.so does not export %s" % name
+    assert set(declared) == set(_lib.PROTOTYPES), "ctypes prototypes out of sync with bossx.h"
+    assert lib.bossx_version().startswith(b"bossx")
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device the engine must fail loudly rather than compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from boss_runs_amd.engine import Engine
+    with pytest.raises(_lib.BossxError):
+        Engine()
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(REPO, "boss-runs_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".inc")):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "oracle/" not in src or f.endswith(".md"), f

@@ -1,0 +1,161 @@
+"""The oracle against the reference: data-free known answers of the reference's own tests and
+the golden vectors captured by tests/golden/make_golden.py (reference imported in the build
+container).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from scenarios import (GOLDEN, SCENARIOS, E2E_BATCHES, E2E_REJECT, batch_digest, digest, e2e_batch,
+                       e2e_contig_strings, e2e_reference, unpack_strat)
+
+from oracle.model import SiteModel
+from oracle.contig import OContig
+from oracle.dists import OReadlengthDist
+from oracle.pafcigar import parse_paf, convert_records
+from oracle.pipeline import OracleRuns
+from oracle.movesum import move_sum
+
+
+def test_reference_known_answers_scoring():
+    # /root/reference/tests/base/test_runs_sequences.py:113-126
+    m = SiteModel(1)
+    assert np.isclose(m.score0, 0.04969294)
+    assert np.isclose(m.ent0, 0.09302521)
+    pats = np.array([[28, 0, 0, 0, 0], [2, 0, 0, 0, 0]], dtype=np.uint16)
+    ent, sco = m.entropy_and_score(pats)
+    assert np.isclose(sco[3, 0], 3.834200141940696e-44)
+    assert np.isclose(ent[3, 0], 3.834200141940696e-44)
+    assert np.isclose(sco[3, 1], 0.17253973305650225)
+    assert np.isclose(ent[3, 1], 0.22957118271635163)
+
+
+@pytest.mark.parametrize("ploidy,b,g", [(1, 4, 5), (2, 4, 15)])
+def test_reference_known_answers_priors(ploidy, b, g):
+    # /root/reference/tests/base/test_runs_sequences.py:9-19
+    m = SiteModel(ploidy)
+    assert m.len_b == b + 1 and m.len_g == g
+    assert m.phi_pow.shape == (b + 1, g, 1000) and m.priors.shape == (b, g)
+    with pytest.raises(ValueError):
+        SiteModel(3)
+
+
+def test_reference_known_answers_readlengthdist():
+    # /root/reference/tests/base/test_readlengthdist.py:21-32
+    r = OReadlengthDist()
+    r.update({'a': 1, 'b': 2, 'c': 3})
+    assert int(r.lam) == 6000 and not hasattr(r, 'longest_read')
+    assert np.array_equal(r.approx_ccl, [1167, 2729, 3903, 4918, 5866, 6808, 7797, 8912, 10321, 12713])
+
+
+@pytest.mark.parametrize("name,seq,nb", [("ch1", "ACGTACGT", 1), ("ch1", "ACGTACGTNnWwIi", 1),
+                                         ("ch2", "ACgtacGT", 1), ("ch3  r", "ACGTACGT", 1),
+                                         ("ch1_bc", "ACGTACGT", 2)])
+def test_reference_known_answers_contig(name, seq, nb):
+    # /root/reference/tests/base/test_reference.py:10-36
+    c = OContig(name, seq, nbarcodes=nb)
+    assert c.length == len(seq) == len(c.seq_int) and " " not in c.name
+    assert c.coverage.shape == (len(seq), 5, nb) and c.coverage.sum() == 0
+    assert c.bucket_switches.shape == ((len(seq) // 20_000) + 1, nb)
+    assert np.all(c.scores[0] == SiteModel(1).score0)
+
+
+def test_golden_tables():
+    g = np.load(os.path.join(GOLDEN, "g_tables.npz"))
+    for pl in (1, 2):
+        m = SiteModel(pl)
+        assert np.array_equal(g["phi_p%d" % pl], m.phi)
+        assert np.array_equal(g["priors_p%d" % pl], m.priors)
+        assert g["score0_p%d" % pl][0] == m.score0[0] and g["ent0_p%d" % pl][0] == m.ent0[0]
+        ent, sco = m.entropy_and_score(g["patterns"])
+        # same machine family -> bit-equal; across CPUs numpy's SIMD log/pow may differ by ulps
+        assert np.allclose(ent, g["entropy_p%d" % pl], rtol=1e-12, atol=0)
+        assert np.allclose(sco, g["score_p%d" % pl], rtol=1e-9, atol=1e-30)
+
+
+def test_golden_cigar():
+    g = np.load(os.path.join(GOLDEN, "g_cigar.npz"))
+    paf_text = g["paf"].tobytes().decode()
+    seqs = dict(zip(g["read_ids"].tolist(), g["read_seqs"].tolist()))
+    inc = convert_records(parse_paf(paf_text, min_len=200), seqs)
+    flat = [(t, s, e, q) for t, lst in inc.items() for (s, e, q, bc) in lst]
+    assert len(flat) == int(g["n_inc"]) > 20
+    for k, (t, s, e, q) in enumerate(flat):
+        assert t == str(g["inc%03d_tname" % k])
+        assert [s, e] == g["inc%03d_range" % k].tolist()
+        assert np.array_equal(q, g["inc%03d_codes" % k])
+
+
+def test_golden_dists():
+    g = np.load(os.path.join(GOLDEN, "g_dists.npz"))
+    r = OReadlengthDist()
+    assert np.array_equal(r.approx_ccl, g["default_approx_ccl"])
+    for k in range(3):
+        r.update({"x%d" % i: int(v) for i, v in enumerate(g["lens%d" % k])})
+        assert np.array_equal(r.approx_ccl, g["approx_ccl%d" % k])
+        assert r.lam == float(g["lam%d" % k]) and r.time_cost == float(g["time_cost%d" % k])
+
+
+def test_move_sum_semantics():
+    a = np.array([1.0, 2.0, 4.0, 8.0, 16.0, 32.0])
+    assert np.array_equal(move_sum(a, 3), [1, 3, 7, 14, 28, 56])
+    assert np.array_equal(move_sum(a[::-1], 2)[::-1], [3, 6, 12, 24, 48, 32])
+    with pytest.raises(ValueError):
+        move_sum(a, 7)
+    with pytest.raises(ValueError):
+        move_sum(a, 0)
+    # the running recurrence (asum += a[i] - a[i-w]), not a fresh window sum
+    rng = np.random.default_rng(0)
+    x = rng.random(500)
+    y = move_sum(x, 7)
+    asum, ref = 0.0, []
+    for i in range(500):
+        asum = asum + x[i] if i < 7 else asum + (x[i] - x[i - 7])
+        ref.append(asum)
+    assert np.array_equal(y, ref)
+    fresh = np.array([x[max(0, i - 6): i + 1].sum() for i in range(500)])
+    assert np.allclose(y, fresh) and not np.array_equal(y, fresh)
+
+
+@pytest.mark.parametrize("tag,ploidy,nb", SCENARIOS)
+def test_golden_end_to_end(tag, ploidy, nb):
+    """Five batches through the oracle reproduce the reference's masks, thresholds, coverage,
+    scores, entropy, bucket switches, downsampled scores and benefits bit-for-bit."""
+    g = np.load(os.path.join(GOLDEN, "g_e2e_%s.npz" % tag))
+    contigs = e2e_reference()
+    assert str(g["ref_digest"]) == digest(*[c[1] for c in contigs])
+    o = OracleRuns(e2e_contig_strings(contigs), ploidy=ploidy, reject_refs={E2E_REJECT}, nbarcodes=nb)
+    cross_cpu = False
+    for b in range(E2E_BATCHES):
+        batch = e2e_batch(contigs, b, nb)
+        assert str(g["b%d_input_digest" % b]) == batch_digest(batch), "synthetic inputs drifted"
+        o.process_batch(batch["paf"], batch["seqs"], read_lengths=batch["read_lengths"],
+                        barcodes=batch["barcodes"] if nb > 1 else None)
+        updated = bool(int(g["b%d_updated" % b]))
+        assert np.array_equal(o.rl_dist.approx_ccl, g["b%d_approx_ccl" % b])
+        for cname, c in o.contigs.items():
+            key = "b%d_%s_" % (b, cname)
+            if not c.rej:
+                assert str(g[key + "cov_digest"]) == digest(c.coverage)
+                assert int(g[key + "change_count"]) == int(c.change_mask.sum())
+                assert np.array_equal(g[key + "bucket_switches"], c.bucket_switches)
+                assert np.array_equal(g[key + "switched_on"], c.switched_on)
+                assert int(g[key + "n_zero_scores"]) == int((c.scores == 0).sum())
+                assert int(g[key + "n_tiny_scores"]) == int((c.scores == np.finfo(float).tiny).sum())
+                if str(g[key + "scores_digest"]) != digest(c.scores):
+                    cross_cpu = True      # numpy log/pow differ by ulps between CPU generations
+                if updated:
+                    assert np.allclose(g[key + "scores_ds"], c.scores_ds, rtol=1e-9, atol=1e-300)
+                    assert np.allclose(g[key + "additional_benefit"], c.additional_benefit, rtol=1e-6, atol=1e-12)
+                    if not cross_cpu:
+                        assert np.array_equal(g[key + "scores_ds"], c.scores_ds)
+                        assert np.array_equal(g[key + "smu"], c.smu)
+                        assert np.array_equal(g[key + "additional_benefit"], c.additional_benefit)
+            assert np.array_equal(unpack_strat(g, key + "strat", c.strat.shape), c.strat), (b, cname)
+        if updated:
+            assert np.isclose(float(g["b%d_threshold" % b]), o.threshold, rtol=1e-9)
+            if not cross_cpu:
+                assert float(g["b%d_threshold" % b]) == o.threshold
+    assert np.allclose(g["final_ctgA_scores"], o.contigs["ctgA"].scores, rtol=1e-6, atol=1e-300)
+    assert np.array_equal(g["final_ctgA_coverage"], o.contigs["ctgA"].coverage)
+    assert np.array_equal(g["final_read_starts"], o.read_starts.merge())

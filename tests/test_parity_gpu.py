@@ -1,0 +1,138 @@
+"""Parity of the HIP path (through the C-ABI) against the oracle and the golden vectors.
+Bit-exact for coverage, site state, masks, bucket switches and histogram counts; scores and
+benefits are compared bit-for-bit too because the product's table and the oracle's table are
+built by the same numpy on the same host (tolerance 1e-6 relative is the stated bound across
+machines)."""
+import os
+
+import numpy as np
+import pytest
+
+from scenarios import (GOLDEN, SCENARIOS, E2E_BATCHES, E2E_REJECT, batch_digest, e2e_batch,
+                       e2e_contig_strings, e2e_reference, unpack_strat)
+
+pytestmark = pytest.mark.gpu
+
+
+def _product(ploidy, nb, in_tmp):
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.runs import BossRuns
+    args = BossConfig()
+    args.general.name = "parity"
+    args.optional.ploidy = ploidy
+    args.optional.reject_refs = E2E_REJECT
+    if nb > 1:
+        args.general.barcodes = ["barcode%02d" % (i + 1) for i in range(nb)]
+    runs = BossRuns(args)
+    runs.init(contigs=e2e_contig_strings())
+    return runs
+
+
+@pytest.mark.parametrize("tag,ploidy,nb", SCENARIOS)
+def test_end_to_end_vs_oracle_and_golden(tag, ploidy, nb, in_tmp):
+    from oracle.pipeline import OracleRuns
+    g = np.load(os.path.join(GOLDEN, "g_e2e_%s.npz" % tag))
+    contigs = e2e_reference()
+    runs = _product(ploidy, nb, in_tmp)
+    o = OracleRuns(e2e_contig_strings(contigs), ploidy=ploidy, reject_refs={E2E_REJECT}, nbarcodes=nb)
+    assert runs.ref.n_sites == o.n_sites
+    for b in range(E2E_BATCHES):
+        batch = e2e_batch(contigs, b, nb)
+        assert str(g["b%d_input_digest" % b]) == batch_digest(batch)
+        bcs = batch["barcodes"] if nb > 1 else None
+        o.process_batch(batch["paf"], batch["seqs"], read_lengths=batch["read_lengths"], barcodes=bcs)
+        runs.rl_dist.update(batch["read_lengths"])
+        runs.process_batch_paf(batch["paf"], batch["seqs"], barcodes=bcs)
+        assert np.array_equal(runs.rl_dist.approx_ccl, o.rl_dist.approx_ccl)
+        assert np.array_equal(runs.read_starts.merge(), o.read_starts.merge())
+        updated = bool(int(g["b%d_updated" % b]))
+        for cname, oc in o.contigs.items():
+            pc = runs.contigs[cname]
+            key = "b%d_%s_" % (b, cname)
+            # masks: bit-identical to the oracle AND to the reference's golden output
+            assert np.array_equal(pc.strat, oc.strat), (b, cname)
+            assert np.array_equal(pc.strat, unpack_strat(g, key + "strat", oc.strat.shape)), (b, cname)
+            if oc.rej:
+                continue
+            assert np.array_equal(pc.coverage, oc.coverage)
+            assert np.array_equal(pc.bucket_switches, oc.bucket_switches)
+            assert np.array_equal(pc.switched_on, oc.switched_on)
+            ps, os_ = pc.scores, oc.scores
+            assert np.array_equal(ps == 0, os_ == 0)
+            assert np.allclose(ps, os_, rtol=1e-6, atol=0)          # north_star tolerance
+            assert np.array_equal(ps, os_)                           # same-host tables: bit-equal
+            assert np.array_equal(pc.entropy, oc.entropy)
+            if updated:
+                assert np.array_equal(pc.scores_ds, oc.scores_ds)
+                assert np.array_equal(pc.additional_benefit, oc.additional_benefit)
+        if updated:
+            assert runs.threshold == o.threshold
+            d = o.detail
+            assert runs.last_stats["normaliser"] == d["normaliser"]
+            assert np.array_equal(runs.last_stats["exponents"], d["exponents"])
+            assert np.array_equal(runs.last_stats["counts"], d["counts"])
+            assert runs.last_stats["strat_size"] == d["strat_size"]
+            assert np.allclose(runs.last_stats["f_grid"], d["f_grid"], rtol=1e-11)
+            assert np.isclose(runs.last_stats["ubar0"], d["ubar0"], rtol=1e-11)
+    # the file contract: boss.npz as np.load reads it (dynamic_readfish.py:87-110)
+    z = np.load(os.path.join(runs.out_dir, "masks", "boss.npz"))
+    assert set(z.files) == set(o.contigs)
+    for cname, oc in o.contigs.items():
+        assert z[cname].dtype == bool and np.array_equal(z[cname], oc.strat)
+
+
+def test_error_behaviour(in_tmp):
+    """Reference exceptions map to the same Python exception types."""
+    runs = _product(1, 1, in_tmp)
+    contigs = e2e_reference()
+    batch = e2e_batch(contigs, 0, 1)
+    first = batch["paf"].split("\n")[0].split("\t")
+    rid = first[0]
+    # read id missing from the batch -> KeyError (sequences.py:713)
+    seqs = dict(batch["seqs"])
+    with pytest.raises(KeyError):
+        runs.engine.stage_batch(batch["paf"], {k: v for k, v in seqs.items() if k != rid})
+    # CIGAR inconsistent with the PAF coordinates -> ValueError / AssertionError class
+    bad = "\t".join(first[:8] + [str(int(first[8]) + 5)] + first[9:])
+    with pytest.raises(ValueError):
+        runs.engine.stage_batch(bad, seqs)
+    # nothing was ingested by the failed calls
+    runs.engine.sweep()
+    assert runs.contigs["ctgA"].coverage.sum() == 0
+    # window larger than the contig -> Bottleneck's ValueError
+    w = np.array([4] + [5000] * 10, dtype=np.int32)
+    with pytest.raises(ValueError, match="Moving window"):
+        runs.engine.benefit(w, np.ones(10))
+
+
+def test_empty_and_ragged_batches(in_tmp):
+    """An update with no reads still sweeps every contig (core.py:83-86); reads mapped to
+    unknown / rejected / short contigs are ignored."""
+    runs = _product(1, 1, in_tmp)
+    runs.process_batch_paf("", {})
+    assert not any(c.switched_on.any() for c in runs.contigs_filt.values())
+    contigs = e2e_reference()
+    batch = e2e_batch(contigs, 0, 1)
+    only_rej = "\n".join(l for l in batch["paf"].split("\n") if "\tctgREJ\t" in l or "\tctgSHORT\t" in l)
+    runs.process_batch_paf(only_rej, batch["seqs"])
+    for c in runs.contigs_filt.values():
+        assert c.coverage.sum() == 0
+    assert runs.read_counts["ctgREJ"] > 0
+
+
+def test_export_import_roundtrip(in_tmp):
+    runs = _product(1, 2, in_tmp)
+    contigs = e2e_reference()
+    batch = e2e_batch(contigs, 0, 2)
+    runs.rl_dist.update(batch["read_lengths"])
+    runs.process_batch_paf(batch["paf"], batch["seqs"], barcodes=batch["barcodes"])
+    c = runs.contigs["ctgB"]
+    cov, state, ent = c.coverage, runs.engine.export(c.index, "state"), c.entropy
+    scores = c.scores
+    runs2 = _product(1, 2, in_tmp)
+    c2 = runs2.contigs["ctgB"]
+    runs2.engine.import_state(c2.index, "coverage", cov)
+    runs2.engine.import_state(c2.index, "state", state)
+    runs2.engine.import_state(c2.index, "entropy", ent)
+    assert np.array_equal(c2.coverage, cov) and np.array_equal(c2.scores, scores)
+    assert np.array_equal(c2.entropy, ent)
