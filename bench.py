@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Benchmark of the BOSS-RUNS decision update on MI355X (BASELINE.json metric:
+"decision-update wall-clock (ms) + Mbp scored/sec, 4000-read batch").
+
+One step = one decision update on one resident 4000-read batch: coverage-scatter of the
+batch (inputs already parsed and uploaded to HBM), the fused per-site sweep, bucket switches,
+exact move_sum benefit chain, threshold statistics, threshold choice on the host, mask
+kernel and the device-to-host copy of every contig's mask.  `value` = reference positions
+whose score state is brought up to date per second (G * nbarcodes / t_update), summed over
+ranks; `ms_per_step` is the decision-update wall-clock.
+
+    python bench.py                               # N=1, E. coli 4.6 Mb (BASELINE configs[1])
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (contig lengths, names, ploidy, nbarcodes, reject, preload depth)
+    "ecoli": ([4_641_652], ["ecoli_K12"], 1, 1, None, 0.0),
+    "chr20_21": ([64_444_167, 46_709_983], ["chr20", "chr21"], 2, 1, None, 8.0),
+    "shard390": ([248_956_422, 138_394_717], ["chr1", "chr9"], 2, 1, None, 8.0),
+    "barcoded": ([5_000_000] * 10, ["bac%02d" % i for i in range(10)], 1, 8, None, 0.0),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="ecoli", choices=sorted(WORKLOADS))
+    ap.add_argument("--reads", type=int, default=4000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-updates", type=int, default=3)
+    ap.add_argument("--extra-large", action="store_true",
+                    help="also measure the sweep kernel on a 390 Mb shard (HBM-sized working set)")
+    return ap.parse_args()
+
+
+def make_runs(workload, rank, device):
+    from boss_runs_amd import synth
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.runs import BossRuns
+    lens, names, ploidy, nb, reject, preload = WORKLOADS[workload]
+    contigs = synth.make_reference(lens, seed=1 + rank, names=names)
+    args = BossConfig()
+    args.general.name = "bench_r%d" % rank
+    args.optional.ploidy = ploidy
+    args.optional.bucket_threshold = 0        # strategies on from the first update
+    args.gpu.device = device
+    if nb > 1:
+        args.general.barcodes = ["barcode%02d" % (i + 1) for i in range(nb)]
+    runs = BossRuns(args)
+    runs.write_masks = False                  # npz write is reported separately
+    runs.init(contigs=[(n, synth.codes_to_str(c)) for n, c in contigs])
+    if preload > 0:
+        runs.engine.preload_coverage(preload, seed=7 + rank)
+    return runs, contigs, nb
+
+
+def cpu_baseline(contigs, batches, n_updates):
+    """The oracle (structure-faithful numpy port of the reference) on the host cores."""
+    from boss_runs_amd import synth
+    from oracle.pipeline import OracleRuns
+    o = OracleRuns([(n, synth.codes_to_str(c)) for n, c in contigs], bucket_threshold=0)
+    times = []
+    for b in batches[:n_updates]:
+        t0 = time.perf_counter()
+        o.process_batch(b["paf"], b["seqs"], read_lengths=b["read_lengths"])
+        times.append(time.perf_counter() - t0)
+    return o, times
+
+
+def main():
+    a = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the decision-update path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from boss_runs_amd import synth
+
+    os.chdir(tempfile.mkdtemp(prefix="bossx_bench_"))
+    runs, contigs, nb = make_runs(a.workload, rank, local_rank)
+    eng = runs.engine
+    G = sum(c.length for c in runs.contigs_filt.values())
+
+    # ---- inputs: W+K distinct synthetic batches, parsed and resident in HBM before timing ----
+    n_b = a.warmup + a.steps
+    batches, summaries = [], []
+    t_parse = []
+    for i in range(n_b):
+        b = synth.make_batch(contigs, a.reads, seed=1000 * (rank + 1) + i, nbarcodes=nb, extras=False)
+        eng.select_batch(i)
+        t0 = time.perf_counter()
+        s = eng.stage_batch(b["paf"], b["seqs"], barcodes=b["barcodes"] if nb > 1 else None)
+        t_parse.append(time.perf_counter() - t0)
+        batches.append(b)
+        summaries.append(s)
+    aligned = float(np.mean([s["aligned"] for s in summaries]))
+
+    def step(i):
+        runs.rl_dist.update(batches[i]["read_lengths"])
+        eng.ingest_staged(slot=i)
+        runs._account_reads(summaries[i], len(batches[i]["seqs"]))
+        runs.update_wrapper()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    eng.enable_timing(True)
+    base = eng.kernel_stats()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.warmup, n_b):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stats = eng.kernel_stats()
+    eng.enable_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        gt = torch.tensor([float(G * nb)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(gt, op=dist.ReduceOp.SUM)
+        total_sites = float(gt.item())
+    else:
+        total_sites = float(G * nb)
+    ms_per_step = 1e3 * elapsed / a.steps
+    value = total_sites / 1e6 / (elapsed / a.steps)
+
+    if rank == 0:
+        kern = {}
+        for k, v in stats.items():
+            n = v["launches"] - base[k]["launches"]
+            ms = (v["ms_total"] - base[k]["ms_total"]) / max(n, 1)
+            kern[k] = dict(avg_ms=ms, launches=n, bytes=v["bytes_last"],
+                           gbs=(v["bytes_last"] / 1e9) / (ms / 1e3) if ms > 0 else None)
+        dom = max(kern, key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"])
+        roof_k = "site_sweep"    # the HBM-streaming kernel the roofline is quoted on
+        achieved = kern[roof_k]["gbs"] or 0.0
+        out = {
+            "metric": "decision-update Mbp scored/sec (4000-read batch); ms_per_step = decision-update wall-clock",
+            "value": value, "unit": "Mbp/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u16+f64", "data": "synthetic",
+            "config": {"workload": "%s: %s, ploidy %d, nbarcodes %d, %d-read PAF batches (mean 6 kb), per GPU"
+                       % (a.workload, "+".join("%d" % c.length for c in runs.contigs_filt.values()),
+                          WORKLOADS[a.workload][2], nb, a.reads),
+                       "sites_per_gpu": G, "aligned_bases_per_batch": aligned,
+                       "parallelism": "contig-sharded x%d" % world},
+            "roofline": {"kernel": roof_k, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes": kern[roof_k]["bytes"], "avg_launch_ms": kern[roof_k]["avg_ms"]},
+            "kernels": kern, "dominant_kernel_by_time": dom,
+            "host": {"stage_batch_ms_mean": 1e3 * float(np.mean(t_parse))},
+        }
+        if not a.no_cpu_baseline:
+            _, times = cpu_baseline(contigs, batches, a.cpu_updates)
+            t_med = float(np.median(times))
+            out["cpu_baseline"] = {
+                "value": G * nb / 1e6 / t_med, "unit": "Mbp/s", "cores": 1, "kind": "port",
+                "sample": "%d full updates of the same workload through oracle/ (numpy port of the reference; "
+                          "median %.2f s per update, PAF parse included)" % (a.cpu_updates, t_med),
+                "ms_per_update": 1e3 * t_med, "host_cores_available": os.cpu_count()}
+            out["speedup_vs_cpu_port"] = (1e3 * t_med) / ms_per_step
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -45,12 +45,16 @@ struct bossx_engine {
             *d_row_off = nullptr, *d_strat_off = nullptr, *d_bucket_off = nullptr;
     int32_t *d_drop_thr = nullptr;
     uint8_t *d_local = nullptr;
-    // staged batch
-    EmitOp *d_ops = nullptr; size_t ops_cap = 0;
-    uint32_t *d_tiles = nullptr; size_t tiles_cap = 0;
-    uint8_t *d_blob = nullptr; size_t blob_cap = 0;
-    ParsedBatch staged;
-    bool has_staged = false;
+    // staged batches (device-resident inputs); `slot` selects the current one
+    struct Staged {
+        EmitOp *d_ops = nullptr; size_t ops_cap = 0;
+        uint32_t *d_tiles = nullptr; size_t tiles_cap = 0;
+        uint8_t *d_blob = nullptr; size_t blob_cap = 0;
+        ParsedBatch pb;
+        bool valid = false;
+    };
+    std::vector<Staged> slots = std::vector<Staged>(1);
+    int32_t slot = 0;
     // pinned scratch
     void *h_pin = nullptr; size_t pin_cap = 0;
     // timing
@@ -203,8 +207,9 @@ void bossx_destroy(bossx_engine *h) {
     void *ptrs[] = {h->d_cov, h->d_meta, h->d_touched, h->d_strat, h->d_bucket_on, h->d_entropy, h->d_ds,
                     h->d_benefit, h->d_lut_score, h->d_lut_ent, h->d_fhat, h->d_bucket_sums, h->d_drop_count,
                     h->d_stats, h->d_err, h->d_tile_off, h->d_site_off, h->d_length, h->d_bin_off, h->d_row_off,
-                    h->d_strat_off, h->d_bucket_off, h->d_drop_thr, h->d_local, h->d_ops, h->d_tiles, h->d_blob};
+                    h->d_strat_off, h->d_bucket_off, h->d_drop_thr, h->d_local};
     for (void *p : ptrs) if (p) hipFree(p);
+    for (auto &st : h->slots) { if (st.d_ops) hipFree(st.d_ops); if (st.d_tiles) hipFree(st.d_tiles); if (st.d_blob) hipFree(st.d_blob); }
     if (h->h_pin) hipHostFree(h->h_pin);
     for (int k = 0; k < BOSSX_K_COUNT; ++k) { if (h->ev0[k]) hipEventDestroy(h->ev0[k]); if (h->ev1[k]) hipEventDestroy(h->ev1[k]); }
     if (h->own_stream) hipStreamDestroy(h->stream);
@@ -373,42 +378,55 @@ int bossx_stage_batch(bossx_engine *h, const char *paf, size_t paf_len, const ch
     HIPCHK(hipStreamSynchronize(h->stream));
     const size_t blob_bytes = n_reads > 0 ? size_t(seq_off[n_reads]) : 0;
     if (blob_bytes >= (size_t(1) << 32)) return fail(h, BOSSX_E_RANGE, "read blob larger than 4 GiB");
-    if (pb.ops.size() > h->ops_cap) {
-        if (h->d_ops) HIPCHK(hipFree(h->d_ops));
-        h->ops_cap = pb.ops.size() * 5 / 4 + 1024;
-        if ((rc = dev_alloc(h, &h->d_ops, h->ops_cap))) return rc;
+    bossx_engine::Staged &st = h->slots[size_t(h->slot)];
+    st.valid = false;
+    if (pb.ops.size() > st.ops_cap) {
+        if (st.d_ops) HIPCHK(hipFree(st.d_ops));
+        st.d_ops = nullptr;
+        st.ops_cap = pb.ops.size() * 9 / 8 + 1024;
+        if ((rc = dev_alloc(h, &st.d_ops, st.ops_cap))) return rc;
     }
-    if (pb.tile_first_op.size() > h->tiles_cap) {
-        if (h->d_tiles) HIPCHK(hipFree(h->d_tiles));
-        h->tiles_cap = pb.tile_first_op.size() * 5 / 4 + 64;
-        if ((rc = dev_alloc(h, &h->d_tiles, h->tiles_cap))) return rc;
+    if (pb.tile_first_op.size() > st.tiles_cap) {
+        if (st.d_tiles) HIPCHK(hipFree(st.d_tiles));
+        st.d_tiles = nullptr;
+        st.tiles_cap = pb.tile_first_op.size() * 9 / 8 + 64;
+        if ((rc = dev_alloc(h, &st.d_tiles, st.tiles_cap))) return rc;
     }
-    if (blob_bytes + 16 > h->blob_cap) {
-        if (h->d_blob) HIPCHK(hipFree(h->d_blob));
-        h->blob_cap = (blob_bytes + 16) * 5 / 4;
-        if ((rc = dev_alloc(h, &h->d_blob, h->blob_cap))) return rc;
+    if (blob_bytes + 16 > st.blob_cap) {
+        if (st.d_blob) HIPCHK(hipFree(st.d_blob));
+        st.d_blob = nullptr;
+        st.blob_cap = (blob_bytes + 16) * 9 / 8;
+        if ((rc = dev_alloc(h, &st.d_blob, st.blob_cap))) return rc;
     }
     if (!pb.ops.empty()) {
-        HIPCHK(hipMemcpyAsync(h->d_ops, pb.ops.data(), pb.ops.size() * sizeof(EmitOp), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->d_tiles, pb.tile_first_op.data(), pb.tile_first_op.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-        if (blob_bytes) HIPCHK(hipMemcpyAsync(h->d_blob, seqs, blob_bytes, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(st.d_ops, pb.ops.data(), pb.ops.size() * sizeof(EmitOp), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(st.d_tiles, pb.tile_first_op.data(), pb.tile_first_op.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+        if (blob_bytes) HIPCHK(hipMemcpyAsync(st.d_blob, seqs, blob_bytes, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));   // inputs are borrowed for the call only
     }
-    h->staged = std::move(pb);
-    h->has_staged = true;
+    st.pb = std::move(pb);
+    st.valid = true;
+    return BOSSX_OK;
+}
+
+int bossx_select_batch(bossx_engine *h, int32_t slot) {
+    if (!h || slot < 0 || slot >= 256) return fail(h, BOSSX_E_INVALID, "batch slot must be in [0, 256)");
+    if (size_t(slot) >= h->slots.size()) h->slots.resize(size_t(slot) + 1);
+    h->slot = slot;
     return BOSSX_OK;
 }
 
 int bossx_ingest_staged(bossx_engine *h) {
-    if (!h || !h->has_staged) return fail(h, BOSSX_E_INVALID, "no staged batch");
+    if (!h || !h->slots[size_t(h->slot)].valid) return fail(h, BOSSX_E_INVALID, "no staged batch in the selected slot");
     HIPCHK(hipSetDevice(h->cfg.device));
-    const ParsedBatch &pb = h->staged;
+    const bossx_engine::Staged &st = h->slots[size_t(h->slot)];
+    const ParsedBatch &pb = st.pb;
     for (size_t i = 0; i < h->contigs.size(); ++i) h->contigs[i].cov_total += pb.emitted_per_contig[i];
     if (pb.total_emit == 0) return BOSSX_OK;
     const uint32_t n_tiles = uint32_t((pb.total_emit + kEmitTile - 1) / kEmitTile);
     time_begin(h, BOSSX_K_INGEST);
-    hipLaunchKernelGGL(ingest_scatter_kernel, dim3(n_tiles), dim3(256), 0, h->stream, h->d_ops, h->d_tiles,
-                       uint32_t(pb.ops.size()), pb.total_emit, h->d_blob, reinterpret_cast<uint32_t *>(h->d_cov),
+    hipLaunchKernelGGL(ingest_scatter_kernel, dim3(n_tiles), dim3(256), 0, h->stream, st.d_ops, st.d_tiles,
+                       uint32_t(pb.ops.size()), pb.total_emit, st.d_blob, reinterpret_cast<uint32_t *>(h->d_cov),
                        h->d_touched, uint64_t(h->Gp / 2), h->d_err);
     // algorithmic bytes: 1 B read base + 2 B counter read + 2 B counter write + 1 B touched flag
     time_end(h, BOSSX_K_INGEST, 6.0 * double(pb.total_emit) + 16.0 * double(pb.ops.size()));

@@ -104,8 +104,13 @@ class Engine:
     def ingest_paf(self, paf_text, seqs, barcodes=None, min_len=200):
         return self.stage_batch(paf_text, seqs, barcodes, min_len, ingest=True)
 
-    def ingest_staged(self):
+    def ingest_staged(self, slot=None):
+        if slot is not None:
+            self.select_batch(slot)
         self._ck(self.lib.bossx_ingest_staged(self.h))
+
+    def select_batch(self, slot):
+        self._ck(self.lib.bossx_select_batch(self.h, int(slot)))
 
     # ---- update stages -------------------------------------------------------------------
     def sweep(self):

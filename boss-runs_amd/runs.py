@@ -104,6 +104,7 @@ class BossRuns(Boss):
         self.engine.set_lut(score, entropy)
         self.threshold = None
         self.last_stats = {}
+        self.write_masks = True
         self._write_contig_strategies(contig_strats=self.ref.get_strategy_dict())
 
     def _write_contig_strategies(self, contig_strats) -> None:
@@ -180,6 +181,7 @@ class BossRuns(Boss):
             f_perc = np.count_nonzero(cont.strat[:, 0]) / cont.strat.shape[0]
             r_perc = np.count_nonzero(cont.strat[:, 1]) / cont.strat.shape[0]
             logging.info(f'{cname}: {f_perc}, {r_perc}')
-        self._write_contig_strategies(contig_strats=self.ref.get_strategy_dict())
+        if self.write_masks:
+            self._write_contig_strategies(contig_strats=self.ref.get_strategy_dict())
 
     update_strategy = update_wrapper      # name used by BASELINE.json's north_star

@@ -103,6 +103,9 @@ int bossx_stage_batch(bossx_engine *h, const char *paf, size_t paf_len,
                       bossx_batch_summary *summary, int32_t *n_rec,
                       int64_t *aligned_bases);
 int bossx_ingest_staged(bossx_engine *h);
+/* Staged batches live in numbered slots (default 0) so several batches can be resident in HBM
+ * at once; selects the slot the next stage/ingest call uses.                                */
+int bossx_select_batch(bossx_engine *h, int32_t slot);
 int bossx_ingest_paf(bossx_engine *h, const char *paf, size_t paf_len,
                      const char *names, const int64_t *name_off,
                      const char *seqs, const int64_t *seq_off,

@@ -86,7 +86,7 @@ def test_error_behaviour(in_tmp):
     runs = _product(1, 1, in_tmp)
     contigs = e2e_reference()
     batch = e2e_batch(contigs, 0, 1)
-    first = batch["paf"].split("\n")[0].split("\t")
+    first = [l for l in batch["paf"].split("\n") if "\tctgB\t" in l and "tp:A:P" in l][0].split("\t")
     rid = first[0]
     # read id missing from the batch -> KeyError (sequences.py:713)
     seqs = dict(batch["seqs"])
