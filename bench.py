@@ -49,12 +49,17 @@ def parse_args():
     return ap.parse_args()
 
 
-def make_runs(workload, rank, device):
+def make_runs(workload, rank, world, device):
+    """N=1: the fused single-GPU `BossRuns`.  N>1: `DistributedBossRuns`; the global reference is
+    the per-GPU contig set repeated once per rank (weak scaling), contig-partitioned so that
+    every rank owns its own copy, with ONE global threshold per update (the collectives of
+    boss_runs_amd/parallel.py are inside the timed region)."""
     from boss_runs_amd import synth
     from boss_runs_amd.config import BossConfig
     from boss_runs_amd.runs import BossRuns
+    from boss_runs_amd.parallel import DistributedBossRuns
     lens, names, ploidy, nb, reject, preload = WORKLOADS[workload]
-    contigs = synth.make_reference(lens, seed=1 + rank, names=names)
+    mine = synth.make_reference(lens, seed=1 + rank, names=["%s_r%d" % (n, rank) for n in names])
     args = BossConfig()
     args.general.name = "bench_r%d" % rank
     args.optional.ploidy = ploidy
@@ -62,12 +67,23 @@ def make_runs(workload, rank, device):
     args.gpu.device = device
     if nb > 1:
         args.general.barcodes = ["barcode%02d" % (i + 1) for i in range(nb)]
-    runs = BossRuns(args)
+    if world == 1 and not os.environ.get("BOSSX_FORCE_COLLECTIVES"):
+        runs = BossRuns(args)
+        runs.init(contigs=[(n, synth.codes_to_str(c)) for n, c in mine])
+    else:
+        allc = []
+        for r in range(world):
+            for n, L in zip(names, lens):
+                allc.append(("%s_r%d" % (n, r), L))
+        mine_d = {n: synth.codes_to_str(c) for n, c in mine}
+        runs = DistributedBossRuns(args)
+        runs.init(contigs=[(n, mine_d.get(n, L)) for n, L in allc], sharded_reads=True)
+        assert all(not runs.contigs[n].remote for n in mine_d), "partition must give each rank its own contigs"
     runs.write_masks = False                  # npz write is reported separately
-    runs.init(contigs=[(n, synth.codes_to_str(c)) for n, c in contigs])
+    runs.log_fractions = False
     if preload > 0:
         runs.engine.preload_coverage(preload, seed=7 + rank)
-    return runs, contigs, nb
+    return runs, mine, nb
 
 
 def cpu_baseline(contigs, batches, n_updates):
@@ -93,15 +109,16 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the decision-update path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or (os.environ.get("BOSSX_FORCE_COLLECTIVES") and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from boss_runs_amd import synth
 
     os.chdir(tempfile.mkdtemp(prefix="bossx_bench_"))
-    runs, contigs, nb = make_runs(a.workload, rank, local_rank)
+    runs, contigs, nb = make_runs(a.workload, rank, world, local_rank)
+    distributed = hasattr(runs, "account_batch")
     eng = runs.engine
-    G = sum(c.length for c in runs.contigs_filt.values())
+    G = sum(c.length for c in runs.contigs_filt.values() if not getattr(c, "remote", False))
 
     # ---- inputs: W+K distinct synthetic batches, parsed and resident in HBM before timing ----
     n_b = a.warmup + a.steps
@@ -118,9 +135,12 @@ def main():
     aligned = float(np.mean([s["aligned"] for s in summaries]))
 
     def step(i):
-        runs.rl_dist.update(batches[i]["read_lengths"])
         eng.ingest_staged(slot=i)
-        runs._account_reads(summaries[i], len(batches[i]["seqs"]))
+        if distributed:
+            runs.account_batch(summaries[i], batches[i]["read_lengths"], len(batches[i]["seqs"]))
+        else:
+            runs.rl_dist.update(batches[i]["read_lengths"])
+            runs._account_reads(summaries[i], len(batches[i]["seqs"]))
         runs.update_wrapper()
 
     def barrier():
@@ -169,10 +189,11 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u16+f64", "data": "synthetic",
             "config": {"workload": "%s: %s, ploidy %d, nbarcodes %d, %d-read PAF batches (mean 6 kb), per GPU"
-                       % (a.workload, "+".join("%d" % c.length for c in runs.contigs_filt.values()),
+                       % (a.workload, "+".join("%d" % c[1].shape[0] for c in contigs),
                           WORKLOADS[a.workload][2], nb, a.reads),
                        "sites_per_gpu": G, "aligned_bases_per_batch": aligned,
-                       "parallelism": "contig-sharded x%d" % world},
+                       "parallelism": "contig-sharded x%d, one global threshold" % world,
+                       "collectives_per_update": (runs.comm.n_collectives / max(n_b, 1)) if distributed else 0},
             "roofline": {"kernel": roof_k, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes": kern[roof_k]["bytes"], "avg_launch_ms": kern[roof_k]["avg_ms"]},
@@ -189,7 +210,7 @@ def main():
                 "ms_per_update": 1e3 * t_med, "host_cores_available": os.cpu_count()}
             out["speedup_vs_cpu_port"] = (1e3 * t_med) / ms_per_step
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -38,6 +38,18 @@ class FhatDesc(C.Structure):
                 ("target_rs", C.c_int64), ("target", C.c_int64)]
 
 
+class UpdateParams(C.Structure):
+    _fields_ = [("windows", C.c_int32 * NWIN), ("reserved", C.c_int32), ("mult", C.c_double * 10),
+                ("tc", C.c_double), ("bucket_threshold", C.c_double), ("fhat_c", C.c_void_p),
+                ("n_windows", C.c_int64), ("target_rs", C.c_int64)]
+
+
+class UpdateResult(C.Structure):
+    _fields_ = [("updated", C.c_int32), ("any_on", C.c_int32), ("strat_size", C.c_int32),
+                ("n_bins", C.c_int32), ("threshold", C.c_double), ("normaliser", C.c_double),
+                ("ubar0", C.c_double)]
+
+
 # name -> (restype, argtypes); every symbol include/bossx.h declares
 PROTOTYPES = {
     "bossx_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
@@ -64,6 +76,10 @@ PROTOTYPES = {
     "bossx_histogram": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(FhatDesc), C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
     "bossx_apply_threshold": (C.c_int, [C.c_void_p, C.c_double]),
+    "bossx_update": (C.c_int, [C.c_void_p, C.POINTER(UpdateParams), C.c_void_p, C.c_void_p,
+                               C.POINTER(UpdateResult), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bossx_strat_bytes": (C.c_int64, [C.c_void_p]),
+    "bossx_strat_offset": (C.c_int64, [C.c_void_p, C.c_int32]),
     "bossx_get_strat": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "bossx_n_contigs": (C.c_int32, [C.c_void_p]),
     "bossx_contig_length": (C.c_int64, [C.c_void_p, C.c_int32]),

@@ -22,6 +22,7 @@ struct bossx_engine {
     bool own_stream = false;
     bool finalized = false;
     bool lut_set = false;
+    bool all_local = true;
     int32_t nb = 1;
 
     std::vector<ContigInfo> contigs;                    // add order (rejected included)
@@ -37,9 +38,12 @@ struct bossx_engine {
     uint8_t *d_meta = nullptr, *d_touched = nullptr, *d_strat = nullptr, *d_bucket_on = nullptr;
     double *d_entropy = nullptr, *d_ds = nullptr, *d_benefit = nullptr;
     double *d_lut_score = nullptr, *d_lut_ent = nullptr, *d_fhat = nullptr;
-    unsigned long long *d_bucket_sums = nullptr, *d_drop_count = nullptr, *d_stats = nullptr;
+    unsigned long long *d_bucket_sums = nullptr, *d_stats = nullptr;
+    uint32_t *d_drop_count = nullptr;
     int64_t fhat_cap = 0;
     int32_t *d_err = nullptr;
+    Ctrl *d_ctrl = nullptr;
+    uint8_t *d_contig_on = nullptr;
     // contig tables (device)
     int64_t *d_tile_off = nullptr, *d_site_off = nullptr, *d_length = nullptr, *d_bin_off = nullptr,
             *d_row_off = nullptr, *d_strat_off = nullptr, *d_bucket_off = nullptr;
@@ -57,6 +61,7 @@ struct bossx_engine {
     int32_t slot = 0;
     // pinned scratch
     void *h_pin = nullptr; size_t pin_cap = 0;
+    std::vector<int32_t> drop_thr_host;
     // timing
     bool timing = false;
     hipEvent_t ev0[BOSSX_K_COUNT]{}, ev1[BOSSX_K_COUNT]{};
@@ -68,6 +73,8 @@ struct bossx_engine {
 };
 
 namespace {
+
+constexpr size_t kStatWords = size_t(BOSSX_HIST_BINS) * 3 + 2;
 
 int fail(bossx_engine *h, int code, const std::string &msg) {
     if (h) h->err = msg;
@@ -159,6 +166,7 @@ SweepParams sweep_params(bossx_engine *h) {
 int check_contig(bossx_engine *h, int32_t c, bool need_filt) {
     if (!h || c < 0 || c >= int32_t(h->contigs.size())) return fail(h, BOSSX_E_INVALID, "contig index out of range");
     if (need_filt && h->contigs[size_t(c)].rejected) return fail(h, BOSSX_E_INVALID, "contig is rejected");
+    if (need_filt && h->contigs[size_t(c)].remote) return fail(h, BOSSX_E_INVALID, "contig is remote (owned by another device)");
     if (!h->finalized) return fail(h, BOSSX_E_INVALID, "engine not finalized");
     return BOSSX_OK;
 }
@@ -207,7 +215,7 @@ void bossx_destroy(bossx_engine *h) {
     void *ptrs[] = {h->d_cov, h->d_meta, h->d_touched, h->d_strat, h->d_bucket_on, h->d_entropy, h->d_ds,
                     h->d_benefit, h->d_lut_score, h->d_lut_ent, h->d_fhat, h->d_bucket_sums, h->d_drop_count,
                     h->d_stats, h->d_err, h->d_tile_off, h->d_site_off, h->d_length, h->d_bin_off, h->d_row_off,
-                    h->d_strat_off, h->d_bucket_off, h->d_drop_thr, h->d_local};
+                    h->d_strat_off, h->d_bucket_off, h->d_drop_thr, h->d_local, h->d_ctrl, h->d_contig_on};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &st : h->slots) { if (st.d_ops) hipFree(st.d_ops); if (st.d_tiles) hipFree(st.d_tiles); if (st.d_blob) hipFree(st.d_blob); }
     if (h->h_pin) hipHostFree(h->h_pin);
@@ -216,7 +224,9 @@ void bossx_destroy(bossx_engine *h) {
     delete h;
 }
 
-int bossx_add_contig(bossx_engine *h, const char *name, const char *seq, int64_t length, int32_t rejected) {
+int bossx_add_contig(bossx_engine *h, const char *name, const char *seq, int64_t length, int32_t flags) {
+    const int32_t rejected = flags & BOSSX_CONTIG_REJECTED;
+    const bool remote = (flags & BOSSX_CONTIG_REMOTE) != 0;
     if (!h || !name) return BOSSX_E_INVALID;
     if (h->finalized) return fail(h, BOSSX_E_INVALID, "add_contig after finalize");
     ContigInfo c;
@@ -230,6 +240,10 @@ int bossx_add_contig(bossx_engine *h, const char *name, const char *seq, int64_t
     std::vector<uint8_t> codes;
     if (c.rejected) {
         c.length = 4;                           // Contig(seq="ACGT", rej=True), reference.py:337
+    } else if (remote) {
+        if (length < 1) return fail(h, BOSSX_E_INVALID, "remote contig needs its length");
+        c.length = length;
+        c.remote = true;
     } else {
         if (!seq || length < 1) return fail(h, BOSSX_E_INVALID, "contig needs a sequence");
         c.length = length;
@@ -266,7 +280,7 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
         c.filt_index = int32_t(h->filt.size());
         h->filt.push_back(int32_t(i));
         c.site_off = site;
-        c.n_tiles = (c.length + kTileSites - 1) / kTileSites;
+        c.n_tiles = c.remote ? 0 : (c.length + kTileSites - 1) / kTileSites;
         c.tile_off = tile_off.back();
         c.T = c.length / kWindow;
         c.bin_off = bin_off.back();
@@ -275,7 +289,7 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
         c.n_buckets = c.length / kBucket + 1;
         c.bucket_off = bucket_off.back();
         site += c.n_tiles * kTileSites;
-        sbytes += c.T * 2 * nb;
+        sbytes += c.remote ? 0 : c.T * 2 * nb;
         tile_off.push_back(c.tile_off + c.n_tiles);
         site_off.push_back(c.site_off);
         length.push_back(c.length);
@@ -283,9 +297,11 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
         row_off.push_back(c.row_off + c.T);
         strat_off.push_back(c.strat_off);
         bucket_off.push_back(c.bucket_off + c.n_buckets);
-        local.push_back(1);
+        local.push_back(c.remote ? 0 : 1);
+        if (c.remote) h->all_local = false;
     }
     if (h->filt.empty()) return fail(h, BOSSX_E_INVALID, "no non-rejected contig");
+    if (site == 0) site = kTileSites;       // a rank that owns no contig still gets valid buffers
     h->Gp = site; h->n_tiles = tile_off.back(); h->B = bin_off.back(); h->rows = row_off.back();
     h->NBK = bucket_off.back(); h->strat_bytes = sbytes;
     if (uint64_t(h->Gp) >= (1ull << 40)) return fail(h, BOSSX_E_INVALID, "reference too large");
@@ -303,9 +319,11 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
     HIPCHK(hipMemsetAsync(h->d_strat, 1, size_t(h->strat_bytes), h->stream));       // reference.py:118
     if ((rc = dev_alloc(h, &h->d_bucket_on, size_t(nb * h->NBK), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_bucket_sums, size_t(nb * h->NBK), true))) return rc;
-    if ((rc = dev_alloc(h, &h->d_drop_count, h->filt.size(), true))) return rc;
-    if ((rc = dev_alloc(h, &h->d_stats, size_t(BOSSX_HIST_BINS * 3 + 4), true))) return rc;
+    if ((rc = dev_alloc(h, &h->d_drop_count, size_t(h->n_tiles), true))) return rc;
+    if ((rc = dev_alloc(h, &h->d_stats, size_t(BOSSX_HIST_BINS * 3 + 4 + 64), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_err, 1, true))) return rc;
+    if ((rc = dev_alloc(h, &h->d_ctrl, 1, true))) return rc;
+    if ((rc = dev_alloc(h, &h->d_contig_on, h->filt.size(), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_lut_score, size_t(BOSSX_NCOMP) * 4, true))) return rc;
     if ((rc = dev_alloc(h, &h->d_lut_ent, size_t(BOSSX_NCOMP) * 4, true))) return rc;
     if ((rc = upload_vec(h, &h->d_tile_off, tile_off))) return rc;
@@ -321,6 +339,7 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
     // reference base codes into the site-state bytes (bits 0-1), replicated per barcode
     for (int32_t fi : h->filt) {
         const ContigInfo &c = h->contigs[size_t(fi)];
+        if (c.remote) continue;
         const std::vector<uint8_t> &codes = h->host_codes[size_t(fi)];
         for (int64_t b = 0; b < nb; ++b)
             HIPCHK(hipMemcpy(h->d_meta + b * h->Gp + c.site_off, codes.data(), codes.size(), hipMemcpyHostToDevice));
@@ -444,35 +463,39 @@ int bossx_ingest_paf(bossx_engine *h, const char *paf, size_t paf_len, const cha
     return bossx_ingest_staged(h);
 }
 
-int bossx_sweep(bossx_engine *h) {
-    if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "sweep before finalize");
-    if (!h->lut_set) return fail(h, BOSSX_E_INVALID, "sweep before set_lut");
-    HIPCHK(hipSetDevice(h->cfg.device));
+namespace {
+int launch_sweep(bossx_engine *h) {
     // dropout thresholds of this update: mean depth per contig (reference.py:157-158, 174-176)
-    int rc = ensure_pin(h, h->filt.size() * sizeof(int32_t));
-    if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));            // pinned scratch reuse
-    int32_t *thr = static_cast<int32_t *>(h->h_pin);
+    std::vector<int32_t> &thr = h->drop_thr_host;    // member: must outlive the async copy
+    thr.resize(h->filt.size());
     for (size_t k = 0; k < h->filt.size(); ++k) {
         const ContigInfo &c = h->contigs[size_t(h->filt[k])];
         const double mean = double(c.cov_total) / double(c.length * int64_t(h->nb));
-        thr[k] = mean > 5 ? int32_t(mean / 8) : -1;
+        thr[k] = (!c.remote && mean > 5) ? int32_t(mean / 8) : -1;
     }
-    HIPCHK(hipMemcpyAsync(h->d_drop_thr, thr, h->filt.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_drop_thr, thr.data(), thr.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemsetAsync(h->d_bucket_sums, 0, size_t(h->nb * h->NBK) * sizeof(unsigned long long), h->stream));
-    HIPCHK(hipMemsetAsync(h->d_drop_count, 0, h->filt.size() * sizeof(unsigned long long), h->stream));
     HIPCHK(hipMemsetAsync(h->d_ds, 0, size_t(h->nb * h->B) * sizeof(double), h->stream));
     SweepParams P = sweep_params(h);
     time_begin(h, BOSSX_K_SWEEP);
-    hipLaunchKernelGGL(site_sweep_kernel, dim3(uint32_t(h->n_tiles)), dim3(256), 0, h->stream, P);
+    if (h->n_tiles > 0)
+        hipLaunchKernelGGL(site_sweep_kernel, dim3(uint32_t(h->n_tiles)), dim3(256), 0, h->stream, P);
     // algorithmic bytes per site*barcode: 10 B counters + 1 B state read; per site: 1 B touched
     // read; per 100-site bin: 8 B downsampled score write (entropy and state write-backs are
     // data dependent and not counted)
     double sites = 0;
-    for (int32_t fi : h->filt) sites += double(h->contigs[size_t(fi)].length);
+    for (int32_t fi : h->filt) if (!h->contigs[size_t(fi)].remote) sites += double(h->contigs[size_t(fi)].length);
     time_end(h, BOSSX_K_SWEEP, sites * h->nb * 11.0 + sites * 1.0 + double(h->B) * h->nb * 8.0);
     HIPCHK(hipGetLastError());
     return BOSSX_OK;
+}
+}  // namespace
+
+int bossx_sweep(bossx_engine *h) {
+    if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "sweep before finalize");
+    if (!h->lut_set) return fail(h, BOSSX_E_INVALID, "sweep before set_lut");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    return launch_sweep(h);
 }
 
 int bossx_get_bucket_sums(bossx_engine *h, int32_t contig, uint64_t *dst) {
@@ -507,10 +530,11 @@ int bossx_set_bucket_switches(bossx_engine *h, int32_t contig, const uint8_t *sw
     return BOSSX_OK;
 }
 
-int bossx_benefit(bossx_engine *h, const int32_t *windows, const double *mult, double *max_benefit) {
-    if (!h || !h->finalized || !windows || !mult) return fail(h, BOSSX_E_INVALID, "bad benefit call");
-    HIPCHK(hipSetDevice(h->cfg.device));
-    ChainParams P;
+namespace {
+
+int launch_sweep(bossx_engine *h);
+
+int fill_chain_params(bossx_engine *h, const int32_t *windows, const double *mult, ChainParams &P, size_t &lds) {
     int32_t wmax = 0;
     for (int k = 0; k < BOSSX_NWIN; ++k) { P.w[k] = windows[k]; wmax = std::max(wmax, windows[k]); }
     for (int i = 0; i < 10; ++i) P.m[i] = mult[i];
@@ -521,56 +545,85 @@ int bossx_benefit(bossx_engine *h, const int32_t *windows, const double *mult, d
                 return fail(h, BOSSX_E_WINDOW, "Moving window (=" + std::to_string(windows[k]) + ") must between 1 and " +
                                                   std::to_string(c.T + 1) + ", inclusive");
     }
-    int32_t ring = 128;
-    while (ring < wmax + 64) ring <<= 1;
-    if (size_t(ring) * 8 > 150 * 1024) return fail(h, BOSSX_E_WINDOW, "read-length window exceeds the LDS ring");
-    P.ds = h->d_ds; P.benefit = h->d_benefit; P.max_bits = h->d_stats; P.ct = table_of(h);
-    P.B = h->B; P.nb = h->nb; P.ring = ring;
-    const int64_t target = h->n_sites_all / kWindow;
-    P.max_limit = std::min<int64_t>(h->B, target);
-    HIPCHK(hipMemsetAsync(h->d_stats, 0, sizeof(unsigned long long), h->stream));
-    const size_t lds = size_t(ring) * sizeof(double);
-    if (lds > 48 * 1024)
+    int32_t ring = 256;
+    while (ring < wmax + 128) ring <<= 1;
+    if (size_t(ring) * 8 > 128 * 1024) return fail(h, BOSSX_E_WINDOW, "read-length window exceeds the LDS ring");
+    P.ds = h->d_ds; P.benefit = h->d_benefit; P.ctrl = h->d_ctrl; P.ct = table_of(h);
+    P.B = h->B; P.nb = h->nb; P.ring = ring; P.gate = 0;
+    P.probe = getenv("BOSSX_CHAIN_PROBE") ? reinterpret_cast<long long *>(h->d_stats + kStatWords + 8) : nullptr;
+    P.max_limit = std::min<int64_t>(h->B, h->n_sites_all / kWindow);
+    lds = size_t(ring) * sizeof(double);
+    if (lds > 32 * 1024)
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    return BOSSX_OK;
+}
+
+void launch_chain(bossx_engine *h, const ChainParams &P, size_t lds) {
     time_begin(h, BOSSX_K_BENEFIT);
-    hipLaunchKernelGGL(benefit_chain_kernel, dim3(uint32_t(h->filt.size() * size_t(h->nb) * 2)), dim3(64), lds,
-                       h->stream, P);
+    hipLaunchKernelGGL(benefit_chain_kernel, dim3(uint32_t(h->filt.size() * size_t(h->nb) * 2)), dim3(kChainThreads),
+                       lds, h->stream, P);
+    // algorithmic bytes: read the downsampled scores once per direction, write both strands
     time_end(h, BOSSX_K_BENEFIT, double(h->B) * h->nb * (2 * 8.0 + 2 * 8.0));
+}
+
+}  // namespace
+
+int bossx_benefit(bossx_engine *h, const int32_t *windows, const double *mult, double *max_benefit) {
+    if (!h || !h->finalized || !windows || !mult) return fail(h, BOSSX_E_INVALID, "bad benefit call");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    ChainParams P;
+    size_t lds = 0;
+    int rc = fill_chain_params(h, windows, mult, P, lds);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream));
+    launch_chain(h, P, lds);
     HIPCHK(hipGetLastError());
     unsigned long long bits = 0;
-    HIPCHK(hipMemcpyAsync(&bits, h->d_stats, sizeof(bits), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&bits, &h->d_ctrl->max_bits, sizeof(bits), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     double mx;
     memcpy(&mx, &bits, sizeof(mx));
     if (max_benefit) *max_benefit = mx;
+    if (P.probe) {
+        long long pr[40];
+        HIPCHK(hipMemcpy(pr, P.probe, sizeof(pr), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[chain probe] chunks=%lld\n", pr[32]);
+        for (int w = 0; w < 8; ++w)
+            fprintf(stderr, "  wave %d: total %lld  A %lld  B %lld  C %lld (cycles; per chunk %.0f / %.0f / %.0f / %.0f)\n", w, pr[w * 4],
+                    pr[w * 4 + 1], pr[w * 4 + 2], pr[w * 4 + 3], double(pr[w * 4]) / double(pr[32]), double(pr[w * 4 + 1]) / double(pr[32]),
+                    double(pr[w * 4 + 2]) / double(pr[32]), double(pr[w * 4 + 3]) / double(pr[32]));
+    }
     return BOSSX_OK;
 }
 
-int bossx_histogram(bossx_engine *h, double normaliser, const bossx_fhat_desc *fh, int64_t *counts,
-                    uint64_t *fgrid_fx, uint64_t *ubar0_fx) {
-    if (!h || !h->finalized || !fh || !fh->fhat_c || !counts || !fgrid_fx || !ubar0_fx) return fail(h, BOSSX_E_INVALID, "bad histogram call");
-    if (!(normaliser > 0)) return fail(h, BOSSX_E_EMPTY, "no non-zero benefit (np.max of an empty array)");
-    HIPCHK(hipSetDevice(h->cfg.device));
+namespace {
+
+int upload_fhat(bossx_engine *h, const bossx_fhat_desc *fh) {
     const int64_t target = h->n_sites_all / kWindow;
     if (fh->target != target) return fail(h, BOSSX_E_INVALID, "fhat target does not match Reference.n_sites // 100");
     if (fh->rep != 20) return fail(h, BOSSX_E_INVALID, "fhat repeat factor must be 20");
     int rc;
     if (fh->n_windows * 2 > h->fhat_cap) {
+        HIPCHK(hipStreamSynchronize(h->stream));
         if (h->d_fhat) HIPCHK(hipFree(h->d_fhat));
         h->fhat_cap = fh->n_windows * 2 + 64;
         if ((rc = dev_alloc(h, &h->d_fhat, size_t(h->fhat_cap)))) return rc;
     }
     HIPCHK(hipMemcpyAsync(h->d_fhat, fh->fhat_c, size_t(fh->n_windows) * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    const size_t nstat = size_t(BOSSX_HIST_BINS) * 3 + 2;
-    HIPCHK(hipMemsetAsync(h->d_stats, 0, (nstat + 2) * sizeof(unsigned long long), h->stream));
+    return BOSSX_OK;
+}
+
+int launch_hist(bossx_engine *h, const bossx_fhat_desc *fh, int gate) {
+    const int64_t target = h->n_sites_all / kWindow;
+    HIPCHK(hipMemsetAsync(h->d_stats, 0, kStatWords * sizeof(unsigned long long), h->stream));
     HistParams P;
     P.benefit = h->d_benefit; P.fhat_c = h->d_fhat;
-    P.counts = h->d_stats + 2; P.fgrid = h->d_stats + 2 + BOSSX_HIST_BINS; P.ubar = h->d_stats + 2 + BOSSX_HIST_BINS * 3;
+    P.counts = h->d_stats; P.fgrid = h->d_stats + BOSSX_HIST_BINS; P.ubar = h->d_stats + BOSSX_HIST_BINS * 3;
     P.ct = table_of(h); P.B = h->B; P.target = target; P.dpad = target > h->B ? target - h->B : 0;
     P.target_rs = fh->target_rs; P.d2 = target - fh->target_rs;
     P.fexp = fh->n_windows * fh->rep; P.d1 = fh->target_rs - P.fexp;
-    P.nb = h->nb; P.all_local = 1; P.norm = normaliser;
+    P.nb = h->nb; P.all_local = h->all_local ? 1 : 0; P.gate = gate; P.ctrl = h->d_ctrl;
     if (P.d2 < 0) P.d2 = 0;   // trimmed instead of padded: indices unchanged
     if (P.d1 < 0) P.d1 = 0;
     const int64_t blocks = std::min<int64_t>((target + 255) / 256, 2048);
@@ -578,8 +631,37 @@ int bossx_histogram(bossx_engine *h, double normaliser, const bossx_fhat_desc *f
     hipLaunchKernelGGL(threshold_hist_kernel, dim3(uint32_t(std::max<int64_t>(blocks, 1)), uint32_t(h->nb * 2)), dim3(256), 0, h->stream, P);
     time_end(h, BOSSX_K_HIST, double(target) * h->nb * 2 * 8.0);
     HIPCHK(hipGetLastError());
-    std::vector<unsigned long long> host(nstat);
-    HIPCHK(hipMemcpyAsync(host.data(), h->d_stats + 2, nstat * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    return BOSSX_OK;
+}
+
+int launch_mask(bossx_engine *h, int gate) {
+    MaskParams P;
+    P.benefit = h->d_benefit; P.bucket_on = h->d_bucket_on; P.strat = h->d_strat; P.ct = table_of(h);
+    P.B = h->B; P.NBK = h->NBK; P.rows = h->rows; P.nb = h->nb; P.gate = gate; P.ctrl = h->d_ctrl;
+    const int64_t blocks = std::min<int64_t>((h->rows + 255) / 256, 4096);
+    time_begin(h, BOSSX_K_MASK);
+    hipLaunchKernelGGL(strategy_mask_kernel, dim3(uint32_t(std::max<int64_t>(blocks, 1))), dim3(256), 0, h->stream, P);
+    // algorithmic bytes: both strands' benefit read once, one mask byte written per row*strand*barcode
+    time_end(h, BOSSX_K_MASK, double(h->rows) * h->nb * 2 * 9.0);
+    HIPCHK(hipGetLastError());
+    return BOSSX_OK;
+}
+
+}  // namespace
+
+int bossx_histogram(bossx_engine *h, double normaliser, const bossx_fhat_desc *fh, int64_t *counts,
+                    uint64_t *fgrid_fx, uint64_t *ubar0_fx) {
+    if (!h || !h->finalized || !fh || !fh->fhat_c || !counts || !fgrid_fx || !ubar0_fx) return fail(h, BOSSX_E_INVALID, "bad histogram call");
+    if (!(normaliser > 0)) return fail(h, BOSSX_E_EMPTY, "no non-zero benefit (np.max of an empty array)");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int rc = upload_fhat(h, fh);
+    if (rc) return rc;
+    unsigned long long bits;
+    memcpy(&bits, &normaliser, sizeof(bits));
+    HIPCHK(hipMemcpyAsync(&h->d_ctrl->max_bits, &bits, sizeof(bits), hipMemcpyHostToDevice, h->stream));
+    if ((rc = launch_hist(h, fh, 0))) return rc;
+    std::vector<unsigned long long> host(kStatWords);
+    HIPCHK(hipMemcpyAsync(host.data(), h->d_stats, kStatWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     for (int i = 0; i < BOSSX_HIST_BINS; ++i) counts[i] = int64_t(host[size_t(i)]);
     memcpy(fgrid_fx, host.data() + BOSSX_HIST_BINS, size_t(BOSSX_HIST_BINS) * 2 * sizeof(uint64_t));
@@ -590,14 +672,84 @@ int bossx_histogram(bossx_engine *h, double normaliser, const bossx_fhat_desc *f
 int bossx_apply_threshold(bossx_engine *h, double threshold) {
     if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "bad apply_threshold call");
     HIPCHK(hipSetDevice(h->cfg.device));
-    MaskParams P;
-    P.benefit = h->d_benefit; P.bucket_on = h->d_bucket_on; P.strat = h->d_strat; P.ct = table_of(h);
-    P.B = h->B; P.NBK = h->NBK; P.rows = h->rows; P.nb = h->nb; P.threshold = threshold;
-    const int64_t blocks = std::min<int64_t>((h->rows + 255) / 256, 4096);
-    time_begin(h, BOSSX_K_MASK);
-    hipLaunchKernelGGL(strategy_mask_kernel, dim3(uint32_t(std::max<int64_t>(blocks, 1))), dim3(256), 0, h->stream, P);
-    time_end(h, BOSSX_K_MASK, double(h->rows) * h->nb * 2 * 9.0);
+    HIPCHK(hipMemcpyAsync(&h->d_ctrl->threshold, &threshold, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    return launch_mask(h, 0);
+}
+
+// One whole decision update enqueued back to back (no host round trip between kernels):
+// sweep -> bucket switches -> benefit chain -> threshold statistics -> threshold choice ->
+// masks, then one device-to-host copy of all masks and the control block.
+int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all, uint8_t *contig_on,
+                 bossx_update_result *res, int64_t *counts, uint64_t *fgrid_fx, uint64_t *ubar0_fx) {
+    if (!h || !h->finalized || !up || !res) return fail(h, BOSSX_E_INVALID, "bad update call");
+    if (!h->lut_set) return fail(h, BOSSX_E_INVALID, "update before set_lut");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int rc;
+    bossx_fhat_desc fh{up->fhat_c, up->n_windows, 20, up->target_rs, h->n_sites_all / kWindow};
+    ChainParams CP;
+    size_t lds = 0;
+    const bool have_strategy_inputs = up->fhat_c != nullptr;
+    if (have_strategy_inputs) {
+        if ((rc = fill_chain_params(h, up->windows, up->mult, CP, lds))) return rc;
+        if ((rc = upload_fhat(h, &fh))) return rc;
+    }
+    if ((rc = launch_sweep(h))) return rc;
+    {
+        BucketParams P;
+        P.bucket_sums = h->d_bucket_sums; P.bucket_on = h->d_bucket_on; P.contig_on = h->d_contig_on;
+        P.ctrl = h->d_ctrl; P.ct = table_of(h); P.NBK = h->NBK; P.nb = h->nb; P.threshold = up->bucket_threshold;
+        const int64_t blocks = std::min<int64_t>((h->NBK * h->nb + 255) / 256, 1024);
+        hipLaunchKernelGGL(bucket_switch_kernel, dim3(uint32_t(std::max<int64_t>(blocks, 1))), dim3(256), 0, h->stream, P);
+    }
+    if (have_strategy_inputs) {
+        HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream));
+        CP.gate = 1;
+        launch_chain(h, CP, lds);
+        if ((rc = launch_hist(h, &fh, 1))) return rc;
+        PickParams PP;
+        PP.counts = h->d_stats; PP.fgrid = h->d_stats + BOSSX_HIST_BINS; PP.ubar = h->d_stats + BOSSX_HIST_BINS * 3;
+        PP.ctrl = h->d_ctrl; PP.tc = up->tc; PP.gate = 1;
+        hipLaunchKernelGGL(threshold_pick_kernel, dim3(1), dim3(64), 0, h->stream, PP);
+        if ((rc = launch_mask(h, 1))) return rc;
+    }
     HIPCHK(hipGetLastError());
+    // results
+    const size_t need = sizeof(Ctrl) + sizeof(int32_t) + h->filt.size() + (counts ? kStatWords * 8 : 0);
+    if ((rc = ensure_pin(h, need + 64))) return rc;
+    char *pin = static_cast<char *>(h->h_pin);
+    Ctrl *hc = reinterpret_cast<Ctrl *>(pin);
+    int32_t *herr = reinterpret_cast<int32_t *>(pin + sizeof(Ctrl));
+    uint8_t *hon = reinterpret_cast<uint8_t *>(pin + sizeof(Ctrl) + sizeof(int32_t));
+    unsigned long long *hst = reinterpret_cast<unsigned long long *>(pin + ((sizeof(Ctrl) + sizeof(int32_t) + h->filt.size() + 15) & ~size_t(15)));
+    HIPCHK(hipMemcpyAsync(hc, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(herr, h->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(hon, h->d_contig_on, h->filt.size(), hipMemcpyDeviceToHost, h->stream));
+    if (counts) HIPCHK(hipMemcpyAsync(hst, h->d_stats, kStatWords * 8, hipMemcpyDeviceToHost, h->stream));
+    if (strat_all && have_strategy_inputs)
+        HIPCHK(hipMemcpyAsync(strat_all, h->d_strat, size_t(h->strat_bytes), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (*herr) {
+        HIPCHK(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
+        return fail(h, BOSSX_E_RANGE, "a read contains a base other than A/C/G/T inside an aligned segment");
+    }
+    if (contig_on) {
+        for (size_t i = 0; i < h->contigs.size(); ++i) contig_on[i] = 0;
+        for (size_t k = 0; k < h->filt.size(); ++k) contig_on[size_t(h->filt[k])] = hon[k];
+    }
+    res->updated = hc->any_on && have_strategy_inputs;
+    res->any_on = hc->any_on;
+    res->strat_size = hc->strat_size; res->n_bins = hc->n_bins;
+    res->threshold = hc->threshold; res->ubar0 = hc->ubar0;
+    memcpy(&res->normaliser, &hc->max_bits, sizeof(double));
+    if (res->updated && (hc->err & 2)) {
+        HIPCHK(hipMemsetAsync(&h->d_ctrl->err, 0, sizeof(int32_t), h->stream));
+        return fail(h, BOSSX_E_EMPTY, "no non-zero benefit (np.max of an empty array)");
+    }
+    if (counts) {
+        for (int i = 0; i < BOSSX_HIST_BINS; ++i) counts[i] = int64_t(hst[i]);
+        if (fgrid_fx) memcpy(fgrid_fx, hst + BOSSX_HIST_BINS, size_t(BOSSX_HIST_BINS) * 2 * sizeof(uint64_t));
+        if (ubar0_fx) memcpy(ubar0_fx, hst + BOSSX_HIST_BINS * 3, 2 * sizeof(uint64_t));
+    }
     return BOSSX_OK;
 }
 
@@ -606,6 +758,7 @@ int bossx_get_strat(bossx_engine *h, int32_t contig, uint8_t *dst) {
     if (rc) return rc;
     const ContigInfo &c = h->contigs[size_t(contig)];
     if (c.rejected) { dst[0] = 0; return BOSSX_OK; }
+    if (c.remote) return fail(h, BOSSX_E_INVALID, "contig is remote (owned by another device)");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipMemcpyAsync(dst, h->d_strat + c.strat_off, size_t(c.T * 2 * h->nb), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -618,6 +771,11 @@ int64_t bossx_contig_length(const bossx_engine *h, int32_t c) {
 }
 int64_t bossx_n_sites(const bossx_engine *h) { return h ? h->n_sites_all : 0; }
 int64_t bossx_merged_bins(const bossx_engine *h) { return h ? h->B : 0; }
+int64_t bossx_strat_bytes(const bossx_engine *h) { return h ? h->strat_bytes : 0; }
+int64_t bossx_strat_offset(const bossx_engine *h, int32_t c) {
+    if (!h || c < 0 || c >= int32_t(h->contigs.size()) || h->contigs[size_t(c)].rejected || h->contigs[size_t(c)].remote) return -1;
+    return h->contigs[size_t(c)].strat_off;
+}
 
 int bossx_export(bossx_engine *h, int32_t contig, int32_t which, void *dst, size_t dst_bytes) {
     int rc = check_contig(h, contig, true);
@@ -681,6 +839,21 @@ int bossx_export(bossx_engine *h, int32_t contig, int32_t which, void *dst, size
             HIPCHK(hipMemcpyAsync(dst, h->d_touched + c.site_off, size_t(L), hipMemcpyDeviceToHost, h->stream));
             break;
         }
+        case 8: {   // last min(nbin, n_filt) rows of additional_benefit: halo rows other devices need
+            const int64_t K = std::min<int64_t>(nbin, int64_t(h->filt.size()));
+            if (!need(size_t(nb * 2 * K) * 8)) return fail(h, BOSSX_E_INVALID, "export buffer too small");
+            for (int64_t pl = 0; pl < nb * 2; ++pl)
+                HIPCHK(hipMemcpyAsync(static_cast<double *>(dst) + pl * K, h->d_benefit + pl * h->B + c.bin_off + nbin - K,
+                                      size_t(K) * 8, hipMemcpyDeviceToHost, h->stream));
+            break;
+        }
+        case 7: {
+            if (!need(size_t(nb * c.n_buckets))) return fail(h, BOSSX_E_INVALID, "export buffer too small");
+            for (int64_t b = 0; b < nb; ++b)
+                HIPCHK(hipMemcpyAsync(static_cast<uint8_t *>(dst) + b * c.n_buckets, h->d_bucket_on + b * h->NBK + c.bucket_off,
+                                      size_t(c.n_buckets), hipMemcpyDeviceToHost, h->stream));
+            break;
+        }
         default:
             return fail(h, BOSSX_E_INVALID, "unknown export selector");
     }
@@ -742,6 +915,7 @@ int bossx_preload_coverage(bossx_engine *h, double depth, uint64_t seed) {
     HIPCHK(hipSetDevice(h->cfg.device));
     for (int32_t fi : h->filt) {
         ContigInfo &c = h->contigs[size_t(fi)];
+        if (c.remote) continue;
         const int64_t blocks = std::min<int64_t>((c.length + 255) / 256, 8192);
         hipLaunchKernelGGL(preload_kernel, dim3(uint32_t(blocks)), dim3(256), 0, h->stream, h->d_cov, h->d_meta,
                            h->d_touched, h->Gp, h->nb, c.site_off, c.length, depth, seed);

@@ -36,6 +36,7 @@ struct ContigInfo {
     std::string name;
     int64_t length = 0;       // Contig.length (4 for a rejected dummy)
     bool rejected = false;
+    bool remote = false;      // non-rejected, but its sites live on another device (multi-GPU)
     int32_t filt_index = -1;  // index among non-rejected contigs (merge order), -1 if rejected
     // geometry of non-rejected contigs
     int64_t site_off = 0;     // first padded global site (multiple of kTileSites)

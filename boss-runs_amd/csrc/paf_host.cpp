@@ -182,7 +182,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             err = "read '" + r.qname + "': mapping without cg tag";   // assert rec.cigar is not None
             return BOSSX_E_PARSE;
         }
-        if (cidx < 0 || contigs[size_t(cidx)].rejected) continue;   // core.py:83-86: only contigs_filt
+        if (cidx < 0 || contigs[size_t(cidx)].rejected || contigs[size_t(cidx)].remote) continue;   // core.py:83-86: only (local) contigs_filt
         const ContigInfo &c = contigs[size_t(cidx)];
         const int64_t seq_b = in.seq_off[read], seq_len = in.seq_off[read + 1] - seq_b;
         const int64_t tlo = r.tstart < r.tend ? r.tstart : r.tend;

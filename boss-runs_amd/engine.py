@@ -5,7 +5,8 @@ import numpy as np
 
 from . import _lib
 
-EXPORT = dict(coverage=0, scores=1, entropy=2, scores_ds=3, benefit=4, state=5, touched=6)
+EXPORT = dict(coverage=0, scores=1, entropy=2, scores_ds=3, benefit=4, state=5, touched=6,
+              bucket_switches=7, benefit_tail=8)
 
 
 class Engine:
@@ -24,6 +25,7 @@ class Engine:
         self.names = []
         self.lengths = []
         self.rejected = []
+        self.remote = []
 
     def close(self):
         if getattr(self, "h", None):
@@ -40,17 +42,22 @@ class Engine:
         _lib.check(self.lib, self.h, rc)
 
     # ---- set-up --------------------------------------------------------------------------
-    def add_contig(self, name, seq, rejected=False):
-        """seq: str/bytes (ASCII) or None for a rejected contig."""
+    def add_contig(self, name, seq, rejected=False, remote_length=None):
+        """seq: str/bytes (ASCII); None for a rejected contig; `remote_length` registers a
+        contig whose sites live on another GPU (geometry only)."""
         if rejected:
             self._ck(self.lib.bossx_add_contig(self.h, name.encode(), None, 0, 1))
             self.lengths.append(4)
+        elif remote_length is not None:
+            self._ck(self.lib.bossx_add_contig(self.h, name.encode(), None, int(remote_length), 2))
+            self.lengths.append(int(remote_length))
         else:
             raw = seq.encode("ascii") if isinstance(seq, str) else bytes(seq)
             self._ck(self.lib.bossx_add_contig(self.h, name.encode(), raw, len(raw), 0))
             self.lengths.append(len(raw))
         self.names.append(name.strip().split(" ")[0])
         self.rejected.append(bool(rejected))
+        self.remote.append(remote_length is not None and not rejected)
         return len(self.names) - 1
 
     def finalize(self, score0, ent0):
@@ -145,6 +152,54 @@ class Engine:
                                           fg.ctypes.data, ub.ctypes.data))
         return counts, fg, ub
 
+    def update(self, bucket_threshold, windows=None, mult=None, tc=0.0, fhat_c=None, target_rs=0,
+               want_stats=False):
+        """bossx_update: one fused decision update.  Without `fhat_c` only the sweep and the
+        bucket switches run.  Returns dict(updated, any_on, threshold, normaliser, ubar0,
+        strat_size, n_bins, contig_on[, counts, fgrid_fx, ubar_fx]); masks land in
+        `self.strat_all` (bytes of every non-rejected contig, add order)."""
+        up = _lib.UpdateParams()
+        f = None
+        if fhat_c is not None:
+            w = np.ascontiguousarray(windows, dtype=np.int32)
+            m = np.ascontiguousarray(mult, dtype=np.float64)
+            assert w.shape == (_lib.NWIN,) and m.shape == (10,)
+            for i in range(_lib.NWIN):
+                up.windows[i] = int(w[i])
+            for i in range(10):
+                up.mult[i] = float(m[i])
+            f = np.ascontiguousarray(fhat_c, dtype=np.float64)
+            up.fhat_c = f.ctypes.data
+            up.n_windows = f.shape[0]
+            up.target_rs = int(target_rs)
+        up.tc = float(tc)
+        up.bucket_threshold = float(bucket_threshold)
+        if getattr(self, "strat_all", None) is None:
+            self.strat_all = np.ones(max(int(self.lib.bossx_strat_bytes(self.h)), 1), dtype=np.uint8)
+        on = np.zeros(len(self.names), dtype=np.uint8)
+        res = _lib.UpdateResult()
+        counts = fg = ub = None
+        if want_stats:
+            counts = np.zeros(_lib.HIST_BINS, dtype=np.int64)
+            fg = np.zeros((_lib.HIST_BINS, 2), dtype=np.uint64)
+            ub = np.zeros(2, dtype=np.uint64)
+        self._ck(self.lib.bossx_update(self.h, C.byref(up), self.strat_all.ctypes.data, on.ctypes.data,
+                                       C.byref(res), None if counts is None else counts.ctypes.data,
+                                       None if fg is None else fg.ctypes.data,
+                                       None if ub is None else ub.ctypes.data))
+        out = dict(updated=bool(res.updated), any_on=bool(res.any_on), threshold=res.threshold,
+                   normaliser=res.normaliser, ubar0=res.ubar0, strat_size=res.strat_size,
+                   n_bins=res.n_bins, contig_on=on.astype(bool))
+        if want_stats:
+            out.update(counts=counts, fgrid_fx=fg, ubar_fx=ub)
+        return out
+
+    def strat_view(self, contig):
+        """Zero-copy bool view [T,2,nb] of one contig's mask inside `strat_all`."""
+        off = int(self.lib.bossx_strat_offset(self.h, contig))
+        T = self.lengths[contig] // 100
+        return self.strat_all[off: off + T * 2 * self.nb].view(np.bool_).reshape(T, 2, self.nb)
+
     def apply_threshold(self, threshold):
         self._ck(self.lib.bossx_apply_threshold(self.h, float(threshold)))
 
@@ -181,6 +236,11 @@ class Engine:
             raw = np.empty((nb, 2, L // 100 + 1), dtype=np.float64)
         elif which == "state":
             raw = np.empty((nb, L), dtype=np.uint8)
+        elif which == "bucket_switches":
+            raw = np.empty((nb, L // 20000 + 1), dtype=np.uint8)
+        elif which == "benefit_tail":
+            k = min(L // 100 + 1, sum(1 for r in self.rejected if not r))
+            raw = np.empty((nb, 2, k), dtype=np.float64)
         else:
             raw = np.empty(L, dtype=np.uint8)
         self._ck(self.lib.bossx_export(self.h, contig, code, raw.ctypes.data, raw.nbytes))
@@ -188,8 +248,10 @@ class Engine:
             return np.ascontiguousarray(raw.transpose(2, 1, 0))          # [L,5,nb]
         if which in ("scores", "entropy", "scores_ds", "state"):
             return np.ascontiguousarray(raw.T)                           # [L,nb]
-        if which == "benefit":
-            return np.ascontiguousarray(raw.transpose(2, 1, 0))          # [T+1,2,nb]
+        if which == "bucket_switches":
+            return np.ascontiguousarray(raw.T).astype(bool)              # [n_buckets,nb]
+        if which in ("benefit", "benefit_tail"):
+            return np.ascontiguousarray(raw.transpose(2, 1, 0))          # [T+1 (or tail),2,nb]
         return raw
 
     def import_state(self, contig, which, arr):

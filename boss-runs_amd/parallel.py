@@ -1,0 +1,280 @@
+"""Multi-GPU decision update: one process per GPU, contigs partitioned across ranks.
+
+The reference is a single process.  Every per-site and per-bin stage of the
+update is contig-local (boss/runs/core.py:83-121 loops over contigs), so ranks own whole
+contigs — contiguous runs in FASTA order, which keeps the row-drift halo of
+`_distribute_strategy` (core.py:125-155) between neighbouring ranks only.  What is global:
+
+  * the read-length distribution and the read-start counts (host, 4000 values per batch):
+    one all-gather of the per-rank batch summaries when reads are sharded over ranks;
+  * "is any strategy switched on" (core.py:111): one MAX all-reduce until it is;
+  * normaliser = max(benefit) (sequences.py:588): MAX all-reduce of one double;
+  * the exponent histogram, its f-hat sums and ubar0 (sequences.py:593-629): SUM all-reduce of
+    ~26 KB of exact integer limbs (order-free, so the result is bit-identical for any rank
+    count);
+  * the <= n_contigs halo rows per contig and the finished masks (gathered for boss.npz).
+
+All of it is latency-bound; with the "nccl" backend (= RCCL over xGMI) the tensors live on
+the GPU, with "gloo" (CPU tests) on the host.  There is no collective on the per-site path.
+"""
+import logging
+
+import numpy as np
+
+from . import _lib
+from .runs import BossRuns, MULT, FX_SHIFT, choose_threshold
+
+
+def partition_contigs(weights, world):
+    """Contiguous partition of `weights` (FASTA order) into `world` groups minimising the
+    heaviest group (classic linear partition, O(n^2 * world)).  Returns owner rank per item;
+    with fewer items than ranks the trailing ranks own nothing."""
+    w = [float(x) for x in weights]
+    n = len(w)
+    world = max(1, int(world))
+    if n == 0:
+        return []
+    k = min(world, n)
+    pre = np.concatenate(([0.0], np.cumsum(w)))
+    cost = np.full((k + 1, n + 1), np.inf)
+    cut = np.zeros((k + 1, n + 1), dtype=np.int64)
+    cost[0, 0] = 0.0
+    for g in range(1, k + 1):
+        for i in range(g, n + 1):
+            best, arg = np.inf, g - 1
+            for j in range(g - 1, i):
+                c = max(cost[g - 1, j], pre[i] - pre[j])
+                if c < best:
+                    best, arg = c, j
+            cost[g, i], cut[g, i] = best, arg
+    owner = [0] * n
+    i = n
+    for g in range(k, 0, -1):
+        j = int(cut[g, i])
+        for t in range(j, i):
+            owner[t] = g - 1
+        i = j
+    return owner
+
+
+class Comm:
+    """Thin wrapper over torch.distributed for small numpy payloads."""
+
+    def __init__(self):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.on = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank() if self.on else 0
+        self.world = dist.get_world_size() if self.on else 1
+        self.device = "cpu"
+        if self.on and dist.get_backend() == "nccl":
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.n_collectives = 0
+        # exercise the collectives even with a single rank (validation of the nccl path)
+        import os
+        self.force = self.on and bool(os.environ.get("BOSSX_FORCE_COLLECTIVES"))
+
+    def _t(self, arr):
+        return self.torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
+
+    def allreduce(self, arr, op="sum"):
+        arr = np.ascontiguousarray(arr)
+        if self.world == 1 and not self.force:
+            return arr.copy()
+        t = self._t(arr)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX)
+        self.n_collectives += 1
+        return t.cpu().numpy()
+
+    def allgather(self, arr):
+        """Same-shape arrays from every rank, stacked on a new leading axis."""
+        arr = np.ascontiguousarray(arr)
+        if self.world == 1 and not self.force:
+            return arr[np.newaxis].copy()
+        t = self._t(arr)
+        out = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        self.n_collectives += 1
+        return np.stack([o.cpu().numpy() for o in out])
+
+
+def fx_to_limbs(fx):
+    """uint64[..., 2] (lo, hi) -> int64[..., 4] 32-bit limbs (sums of <= 2^31 ranks cannot overflow)."""
+    fx = np.asarray(fx, dtype=np.uint64)
+    lo, hi = fx[..., 0], fx[..., 1]
+    m = np.uint64(0xffffffff)
+    return np.stack([lo & m, lo >> np.uint64(32), hi & m, hi >> np.uint64(32)], axis=-1).astype(np.int64)
+
+
+def limbs_to_float(limbs):
+    """int64[..., 4] limbs (possibly carrying) -> correctly rounded float64 of value / 2^100."""
+    limbs = np.asarray(limbs, dtype=np.int64)
+    flat = limbs.reshape(-1, 4)
+    out = np.empty(flat.shape[0], dtype=np.float64)
+    for i, (a, b, c, d) in enumerate(flat.tolist()):
+        out[i] = (a + (b << 32) + (c << 64) + (d << 96)) / (1 << FX_SHIFT)
+    return out.reshape(limbs.shape[:-1])
+
+
+class DistributedBossRuns(BossRuns):
+    """`BossRuns` over several GPUs.  Construct on every rank with the same arguments, after
+    `torch.distributed.init_process_group`; with world size 1 it degenerates to the stage-wise
+    single-GPU update."""
+
+    READ_CAP = 8192      # max reads per rank and batch in the sharded-reads exchange
+
+    def init(self, contigs, engine=None, sharded_reads=True, gather_masks=True) -> None:
+        """`contigs`: list of (name, sequence) — every rank may pass the full list, or a bare
+        length in place of the sequence for contigs it does not own."""
+        self.comm = Comm()
+        self.sharded_reads = sharded_reads
+        self.gather_masks = gather_masks
+        contigs = list(contigs)
+        rej = set(self.args.optional.reject_refs.split(',')) if self.args.optional.reject_refs else set()
+        keep = [(n, s) for n, s in contigs
+                if (int(s) if isinstance(s, (int, np.integer)) else len(s)) >= int(1e5) and n not in rej]
+        nb = len(self.args.general.barcodes) if self.args.general.barcodes else 1
+        lens = [int(s) if isinstance(s, (int, np.integer)) else len(s) for _, s in keep]
+        self.owner = partition_contigs([l * nb for l in lens], self.comm.world)
+        self.owner_of = {n: o for (n, _), o in zip(keep, self.owner)}
+        rank = self.comm.rank
+        super().init(contigs=contigs, engine=engine, is_local=lambda name, k: self.owner[k] == rank)
+        self.local_filt = {n: c for n, c in self.contigs_filt.items() if not c.remote}
+        self.armed = False
+        self.filt_names = list(self.contigs_filt.keys())
+
+    # ---- batch -----------------------------------------------------------------------------
+    def process_batch_paf(self, paf_text, new_reads, barcodes=None, min_len=200, read_lengths=None,
+                          **kw) -> None:
+        """Sharded reads: this rank's reads (they must map to its own contigs); the read-length
+        and read-start summaries are all-gathered so every rank holds the global
+        distributions.  Replicated reads (`sharded_reads=False`): every rank passes the whole
+        batch and no exchange is needed."""
+        summ = self.engine.ingest_paf(paf_text, new_reads, barcodes=barcodes, min_len=min_len)
+        if read_lengths is None:
+            read_lengths = np.array([len(s) for s in new_reads.values()], dtype=np.int64)
+        self.account_batch(summ, read_lengths, len(new_reads))
+        self.update_wrapper()
+
+    def account_batch(self, summ, read_lengths, n_reads):
+        """Make the read-length distribution, read-start counts and abundance counts global:
+        with sharded reads, one all-gather of this rank's per-mapping summary."""
+        read_lengths = np.asarray(list(read_lengths.values()) if isinstance(read_lengths, dict)
+                                  else read_lengths, dtype=np.int64)
+        if self.sharded_reads and (self.comm.world > 1 or self.comm.force):
+            cap = self.READ_CAP
+            k, m = len(summ["contig_idx"]), len(read_lengths)
+            if k > cap or m > cap:
+                raise ValueError("batch larger than READ_CAP")
+            buf = np.zeros((2 * cap + 1, 4), dtype=np.int64)
+            buf[0, :3] = (k, m, n_reads)
+            buf[1:1 + k, 0] = summ["contig_idx"]
+            buf[1:1 + k, 1] = summ["rev"]
+            buf[1:1 + k, 2] = summ["tstart"]
+            buf[1:1 + k, 3] = summ["tend"]
+            buf[1 + cap:1 + cap + m, 0] = read_lengths
+            allb = self.comm.allgather(buf)
+            rec = np.concatenate([b[1:1 + int(b[0, 0])] for b in allb])
+            read_lengths = np.concatenate([b[1 + cap:1 + cap + int(b[0, 1]), 0] for b in allb])
+            n_reads = int(sum(int(b[0, 2]) for b in allb))
+            summ = dict(contig_idx=rec[:, 0], rev=rec[:, 1], tstart=rec[:, 2], tend=rec[:, 3])
+        self.rl_dist.update(read_lengths)
+        self.total_reads += n_reads
+        ci = np.asarray(summ["contig_idx"])
+        for i, n in enumerate(np.bincount(ci[ci >= 0], minlength=len(self.contig_names))):
+            if n:
+                self.read_counts[self.contig_names[i]] += int(n)
+        self.read_starts.count_starts(self.contig_names, ci, summ["rev"], summ["tstart"], summ["tend"])
+
+    # ---- update ----------------------------------------------------------------------------
+    def update_wrapper(self) -> None:
+        eng, comm = self.engine, self.comm
+        eng.sweep()
+        thr_b = self.args.optional.bucket_threshold
+        for cont in self.local_filt.values():
+            cont.check_buckets(eng.bucket_sums(cont.index), threshold=thr_b)
+        if not self.armed:
+            local_on = any(any(c.switched_on) for c in self.local_filt.values())
+            self.armed = bool(comm.allreduce(np.array([int(local_on)], dtype=np.int64), "max")[0])
+            if not self.armed:
+                return
+        fhat_c, target_rs = self.read_starts.fhat_compact()
+        windows = np.concatenate(([400 // 100], self.rl_dist.approx_ccl // 100)).astype(np.int32)
+        local_max = eng.benefit(windows, MULT)
+        normaliser = float(comm.allreduce(np.array([local_max], dtype=np.float64), "max")[0])
+        target = self.ref.n_sites // 100
+        counts, fg, ub = eng.histogram(normaliser, fhat_c, target_rs, target)
+        packed = np.concatenate((counts.reshape(-1, 1), fx_to_limbs(fg)), axis=1)           # [bins, 5]
+        packed = np.concatenate((packed, np.concatenate(([0], fx_to_limbs(ub)))[np.newaxis]))
+        packed = comm.allreduce(packed, "sum")
+        counts = packed[:-1, 0]
+        fgrid = limbs_to_float(packed[:-1, 1:])
+        ubar0 = float(limbs_to_float(packed[-1, 1:]))
+        threshold, size, uniq = choose_threshold(normaliser, counts, fgrid, ubar0, self.rl_dist.time_cost)
+        self.threshold = threshold
+        self.last_stats = dict(normaliser=normaliser, exponents=uniq, counts=counts[uniq],
+                               f_grid=fgrid[uniq], ubar0=ubar0, strat_size=size)
+        eng.apply_threshold(threshold)
+        for cont in self.local_filt.values():
+            cont.strat = eng.get_strat(cont.index)
+        if comm.world > 1 or comm.force:
+            self._patch_halo(threshold)
+            if self.gather_masks:
+                self._gather_masks()
+        if self.write_masks and comm.rank == 0:
+            self._write_contig_strategies(contig_strats=self.ref.get_strategy_dict())
+
+    def _patch_halo(self, threshold):
+        """Contig k takes merged rows [row_off_k, row_off_k + T_k) although its block starts k
+        rows later (core.py:141-155): its first <= k rows come from the tails of the preceding
+        blocks, which may live on another rank.  Owners publish `benefit >= threshold` for the
+        last n_filt rows of their blocks; everyone patches."""
+        nf = len(self.filt_names)
+        nb = self.nbarcodes
+        tails = np.zeros((nf, nf, 2, nb), dtype=np.int64)
+        for j, name in enumerate(self.filt_names):
+            c = self.contigs_filt[name]
+            if c.remote:
+                continue
+            t = self.engine.export(c.index, "benefit_tail") >= threshold          # [K,2,nb]
+            tails[j, nf - t.shape[0]:] = t
+        tails = self.comm.allreduce(tails, "sum")
+        T = [self.contigs_filt[n].length // 100 for n in self.filt_names]
+        row_off = np.concatenate(([0], np.cumsum(T)))
+        bin_off = row_off[:-1] + np.arange(nf)
+        bin_end = bin_off + np.array(T) + 1
+        for k, name in enumerate(self.filt_names):
+            c = self.contigs_filt[name]
+            if c.remote:
+                continue
+            sw = c.bucket_switches
+            for r in range(min(k, T[k])):
+                g = row_off[k] + r
+                j = int(np.searchsorted(bin_off, g, side="right") - 1)
+                if not self.contigs_filt[self.filt_names[j]].remote:
+                    continue                                   # the mask kernel already wrote it
+                row = tails[j, nf - (bin_end[j] - g)]
+                on = sw[r // 200]
+                c.strat[r][:, on] = row[:, on].astype(bool)
+
+    def _gather_masks(self):
+        """Every rank ends up with every contig's mask (rank 0 writes boss.npz)."""
+        sizes = [self.contigs_filt[n].length // 100 * 2 * self.nbarcodes for n in self.filt_names]
+        total = int(sum(sizes))
+        buf = np.zeros(total, dtype=np.uint8)
+        off = 0
+        for n, sz in zip(self.filt_names, sizes):
+            c = self.contigs_filt[n]
+            if not c.remote:
+                buf[off:off + sz] = c.strat.reshape(-1)
+            off += sz
+        allb = self.comm.allgather(buf)
+        off = 0
+        for n, sz in zip(self.filt_names, sizes):
+            c = self.contigs_filt[n]
+            if c.remote:
+                c.strat = allb[self.owner_of[n], off:off + sz].view(np.bool_).reshape(-1, 2, self.nbarcodes).copy()
+            off += sz
+
+    update_strategy = update_wrapper

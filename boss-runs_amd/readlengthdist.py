@@ -30,9 +30,12 @@ class ReadlengthDist:
         lens = lens[lens > self.mu * 2]
         if lens.size:
             lens = np.minimum(lens, int(1e6) - 1)
-            # uint16 counters wrap exactly like repeated `+= 1` (readlengthdist.py:23,48)
-            self.read_lengths += np.bincount(lens, minlength=int(1e6)).astype('uint16')
-        observed = np.nonzero(self.read_lengths)[0]
+            self._hi = max(getattr(self, "_hi", 0), int(lens.max()))
+            # unbuffered in-place add: uint16 counters wrap exactly like the reference's
+            # repeated `+= 1` (readlengthdist.py:23,48)
+            np.add.at(self.read_lengths, lens, np.uint16(1))
+        # only lengths up to the longest one seen so far can be non-zero
+        observed = np.nonzero(self.read_lengths[:getattr(self, "_hi", 0) + 1])[0]
         if observed.size == 0:
             logging.info('Attempted update of read lengths before observing any reads')
             return

@@ -2,8 +2,8 @@
 
 A `Contig` here is a thin view: the per-site arrays live in HBM inside the engine; the
 attributes the reference exposes (`coverage`, `scores`, `entropy`, `scores_ds`,
-`additional_benefit`) are materialised on access in the reference's layout.  `strat`,
-`bucket_switches` and `switched_on` are real numpy arrays kept current by `BossRuns`.
+`additional_benefit`) are materialised on access in the reference's layout.  `strat`
+and `switched_on` are real numpy arrays kept current by `BossRuns`.
 """
 import gzip
 import logging
@@ -32,7 +32,7 @@ def read_fasta(path):
 
 
 class Contig:
-    def __init__(self, name, length, rej=False, barcodes=None, engine=None, index=-1):
+    def __init__(self, name, length, rej=False, barcodes=None, engine=None, index=-1, remote=False):
         self.name = name.strip().split(" ")[0]
         self.length = int(length)
         self.rej = rej
@@ -41,8 +41,8 @@ class Contig:
         self.bucket_size = 20_000
         self._engine = engine
         self.index = index
+        self.remote = remote          # multi-GPU: per-site state lives on another rank
         nb = self.nbarcodes
-        self.bucket_switches = np.zeros((self.length // self.bucket_size + 1, nb), dtype="bool")
         self.switched_on = np.zeros(nb, dtype="bool")
         if rej:
             self.strat = np.zeros(1, dtype="bool")                       # reference.py:116
@@ -53,7 +53,17 @@ class Contig:
     def _export(self, which):
         if self.rej:
             raise AttributeError("rejected contigs hold no per-site state")
+        if self.remote:
+            raise AttributeError("contig %s is owned by another rank" % self.name)
         return self._engine.export(self.index, which)
+
+    @property
+    def bucket_switches(self):
+        """bool[length // 20000 + 1, nb]; the switches live on the device (they gate the mask
+        kernel), this reads them back."""
+        if self.rej or self.remote or self._engine is None:
+            return np.zeros((self.length // self.bucket_size + 1, self.nbarcodes), dtype="bool")
+        return self._engine.export(self.index, "bucket_switches")
 
     @property
     def coverage(self):
@@ -76,23 +86,31 @@ class Contig:
         return self._export("benefit")
 
     def check_buckets(self, bucket_sums, threshold=5.0):
-        """Contig.check_buckets (reference.py:183-211) from the engine's 20-kb covsum totals
-        (`bucket_sums` uint64[nb, length // 20000])."""
+        """Contig.check_buckets (reference.py:183-211) on the host, from the engine's 20-kb
+        covsum totals (`bucket_sums` uint64[nb, length // 20000]); used by the stage-wise
+        update.  The fused update takes the same decision on the device."""
+        old = self.bucket_switches
+        new = old.copy()
         for b in range(self.nbarcodes):
             means = np.divide(bucket_sums[b], self.bucket_size)
-            d = self.bucket_switches.shape[0] - means.shape[0]      # utils.adjust_length
+            d = new.shape[0] - means.shape[0]                       # utils.adjust_length
             if d > 0:
                 means = np.append(means, means[-d:], axis=0)
-            self.bucket_switches[np.where(means >= threshold)[0], b] = True
-            if self.bucket_switches[:, b].any() and not all(self.switched_on):
+            new[np.where(means >= threshold)[0], b] = True
+            if new[:, b].any() and not all(self.switched_on):
                 self.switched_on[np.logical_not(self.switched_on)] = True
                 logging.info(f"Activated strategy for: {self.name}")
+        if not np.array_equal(old, new):
+            self._engine.set_bucket_switches(self.index, new)
 
 
 class Reference:
-    def __init__(self, ref, mmi=None, reject_refs=None, barcodes=None, engine=None, contigs=None):
-        """Loads the FASTA (or takes `contigs`: iterable of (name, sequence)), registers every
-        contig >= 100 kb with the engine in file order (reference.py:305-338)."""
+    def __init__(self, ref, mmi=None, reject_refs=None, barcodes=None, engine=None, contigs=None,
+                 is_local=None):
+        """Loads the FASTA (or takes `contigs`: iterable of (name, sequence-or-length)),
+        registers every contig >= 100 kb with the engine in file order (reference.py:305-338).
+        `is_local(name, index_among_non_rejected) -> bool` marks contigs owned by another rank
+        (multi-GPU); those may be given as a bare length."""
         self.ref, self.mmi, self.barcodes = ref, mmi, barcodes
         if contigs is None:
             if not Path(ref).is_file():
@@ -106,12 +124,21 @@ class Reference:
         logging.info("Reading reference file")
         self.contigs = {}
         min_len = int(1e5)
+        k = 0
         for cname, cseq in contigs:
-            if len(cseq) < min_len:
+            clen = int(cseq) if isinstance(cseq, (int, np.integer)) else len(cseq)
+            if clen < min_len:
                 continue                                            # reference.py:330-331
             if cname not in self.reject_refs:
-                idx = engine.add_contig(cname, cseq, rejected=False)
-                self.contigs[cname] = Contig(cname, len(cseq), barcodes=barcodes, engine=engine, index=idx)
+                if is_local is not None and not is_local(cname, k):
+                    idx = engine.add_contig(cname, None, remote_length=clen)
+                    self.contigs[cname] = Contig(cname, clen, barcodes=barcodes, engine=engine, index=idx, remote=True)
+                else:
+                    if isinstance(cseq, (int, np.integer)):
+                        raise ValueError("local contig %s needs its sequence" % cname)
+                    idx = engine.add_contig(cname, cseq, rejected=False)
+                    self.contigs[cname] = Contig(cname, clen, barcodes=barcodes, engine=engine, index=idx)
+                k += 1
             else:
                 idx = engine.add_contig(cname, None, rejected=True)
                 self.contigs[cname] = Contig(cname, 4, rej=True, engine=engine, index=idx)

@@ -76,7 +76,7 @@ class Boss:
 
 
 class BossRuns(Boss):
-    def init(self, contigs=None, engine=None) -> None:
+    def init(self, contigs=None, engine=None, is_local=None) -> None:
         """boss/runs/core.py:23-55.  `contigs` optionally replaces the FASTA with an iterable
         of (name, sequence)."""
         a = self.args
@@ -88,7 +88,8 @@ class BossRuns(Boss):
         self.engine = engine or Engine(nbarcodes=self.nbarcodes, device=a.gpu.device,
                                        track_entropy=a.gpu.track_entropy)
         self.ref = Reference(ref=a.general.ref, mmi=a.general.mmi, reject_refs=a.optional.reject_refs,
-                             barcodes=a.general.barcodes, engine=self.engine, contigs=contigs)
+                             barcodes=a.general.barcodes, engine=self.engine, contigs=contigs,
+                             is_local=is_local)
         self.contigs = self.ref.contigs
         self.contigs_filt = {n: c for n, c in self.contigs.items() if not c.rej}
         self.contig_names = list(self.contigs.keys())
@@ -105,6 +106,8 @@ class BossRuns(Boss):
         self.threshold = None
         self.last_stats = {}
         self.write_masks = True
+        self.keep_stats = False        # also fetch the threshold statistics (tests)
+        self.log_fractions = True
         self._write_contig_strategies(contig_strats=self.ref.get_strategy_dict())
 
     def _write_contig_strategies(self, contig_strats) -> None:
@@ -133,9 +136,10 @@ class BossRuns(Boss):
     def _account_reads(self, summ, n_reads, starts_filter=None):
         # AbundanceTracker.update (abundance_tracker.py:58-69)
         self.total_reads += n_reads
-        for ci in summ["contig_idx"]:
-            if ci >= 0:
-                self.read_counts[self.contig_names[ci]] += 1
+        ci = summ["contig_idx"]
+        for i, n in enumerate(np.bincount(ci[ci >= 0], minlength=len(self.contig_names))):
+            if n:
+                self.read_counts[self.contig_names[i]] += int(n)
         sel = slice(None)
         if starts_filter is not None:
             sel = np.array([starts_filter(summ["ids"][i]) for i in summ["read_idx"]], dtype=bool)
@@ -152,14 +156,58 @@ class BossRuns(Boss):
         """core.py:102-111."""
         thr = self.args.optional.bucket_threshold
         for cont in self.contigs_filt.values():
-            before = cont.bucket_switches.copy()
             cont.check_buckets(self.engine.bucket_sums(cont.index), threshold=thr)
-            if not np.array_equal(before, cont.bucket_switches):
-                self.engine.set_bucket_switches(cont.index, cont.bucket_switches)
         return any(any(c.switched_on) for c in self.contigs.values())
 
     def update_wrapper(self) -> None:
-        """core.py:160-198."""
+        """core.py:160-198, enqueued as one fused device update (bossx_update): scores +
+        dropout + bucket sums + bin sums, bucket switches, and — once any strategy is switched
+        on — benefits, threshold search, masks."""
+        eng = self.engine
+        thr = self.args.optional.bucket_threshold
+        armed = any(any(c.switched_on) for c in self.contigs.values())
+        # Before anything is switched on the strategy stages are skipped on the device as well;
+        # they are still enqueued (gated) so that the update in which the first bucket flips
+        # produces masks, as in the reference.
+        fhat_c, target_rs = self.read_starts.fhat_compact()
+        have_rl = hasattr(self.rl_dist, "time_cost")
+        if have_rl:
+            windows = np.concatenate(([400 // 100], self.rl_dist.approx_ccl // 100)).astype(np.int32)
+            res = eng.update(thr, windows, MULT, tc=self.rl_dist.time_cost // 100, fhat_c=fhat_c,
+                             target_rs=target_rs, want_stats=self.keep_stats)
+        else:
+            res = eng.update(thr)
+        for cname, cont in self.contigs_filt.items():
+            if res["contig_on"][cont.index] and not all(cont.switched_on):
+                cont.switched_on[:] = True
+                logging.info(f"Activated strategy for: {cname}")
+        switched_on = armed or res["any_on"]
+        if not switched_on:
+            return
+        if not have_rl:
+            # the reference raises AttributeError here (readlengthdist.py:68)
+            raise AttributeError("'ReadlengthDist' object has no attribute 'time_cost'")
+        self.threshold = res["threshold"]
+        self.last_stats = dict(normaliser=res["normaliser"], ubar0=res["ubar0"],
+                               strat_size=res["strat_size"], n_bins=res["n_bins"])
+        if self.keep_stats:
+            counts = res["counts"]
+            uniq = np.nonzero(counts)[0]
+            self.last_stats.update(exponents=uniq, counts=counts[uniq],
+                                   f_grid=np.array([fx_to_float(*res["fgrid_fx"][e]) for e in uniq]))
+        for cname, cont in self.contigs_filt.items():
+            cont.strat = eng.strat_view(cont.index)
+            if self.log_fractions:
+                f_perc = np.count_nonzero(cont.strat[:, 0]) / cont.strat.shape[0]
+                r_perc = np.count_nonzero(cont.strat[:, 1]) / cont.strat.shape[0]
+                logging.info(f'{cname}: {f_perc}, {r_perc}')
+        if self.write_masks:
+            self._write_contig_strategies(contig_strats=self.ref.get_strategy_dict())
+
+    def update_wrapper_staged(self) -> None:
+        """The same update through the stage-wise C-ABI (sweep / bucket sums / benefit /
+        histogram / apply_threshold) with the bucket and threshold decisions on the host —
+        the form the multi-GPU protocol interleaves with collectives."""
         self._update_scores_contigs()
         switched_on = self._check_buckets_contigs()
         if not switched_on:
@@ -177,10 +225,7 @@ class BossRuns(Boss):
                                f_grid=fgrid[uniq], ubar0=ubar0, strat_size=size)
         self.engine.apply_threshold(threshold)                       # find_strat + _distribute_strategy
         for cname, cont in self.contigs_filt.items():
-            self.engine.get_strat(cont.index, out=cont.strat)
-            f_perc = np.count_nonzero(cont.strat[:, 0]) / cont.strat.shape[0]
-            r_perc = np.count_nonzero(cont.strat[:, 1]) / cont.strat.shape[0]
-            logging.info(f'{cname}: {f_perc}, {r_perc}')
+            cont.strat = self.engine.get_strat(cont.index)
         if self.write_masks:
             self._write_contig_strategies(contig_strats=self.ref.get_strategy_dict())
 

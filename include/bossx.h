@@ -60,8 +60,12 @@ const char *bossx_version(void);
  *      occupy 4 sites of Reference.n_sites and a bool[1] mask).  `seq` is ASCII, any case;
  *      non-ACGT letters become code 0 (reference.py:46-68).  Contigs shorter than 100 kb
  *      must be filtered by the caller (reference.py:330-331).                               */
+#define BOSSX_CONTIG_REJECTED 1   /* reject_refs entry: "ACGT" dummy, bool[1] mask                */
+#define BOSSX_CONTIG_REMOTE   2   /* multi-GPU: sites live on another device; `seq` may be NULL,
+                                     `length` is required.  The contig keeps its place in the
+                                     merged bin / row geometry (core.py:125-155).               */
 int bossx_add_contig(bossx_engine *h, const char *name, const char *seq, int64_t length,
-                     int32_t rejected);
+                     int32_t flags);
 /* Allocate and initialise device state (coverage 0, scores = haploid score0, strat = 1).
  * `score0`/`ent0`: initial fill (Contig is always built with ploidy=1, reference.py:314).   */
 int bossx_finalize(bossx_engine *h, double score0, double ent0);
@@ -155,6 +159,41 @@ int bossx_histogram(bossx_engine *h, double normaliser, const bossx_fhat_desc *f
  *      with the reference's row arithmetic (core.py:125-155).  Asynchronous.                */
 int bossx_apply_threshold(bossx_engine *h, double threshold);
 
+/* ---- the whole of BossRuns.update_wrapper (core.py:160-198) in one call: sweep, bucket
+ *      switches (decided on the device with `bucket_threshold`, reference.py:200-208), and —
+ *      once any bucket of any contig is on — benefit, threshold search and masks, enqueued
+ *      back to back with a single synchronisation at the end.  `fhat_c == NULL` runs only the
+ *      sweep and the bucket switches.  `strat_all` (may be NULL) receives every non-rejected
+ *      contig's mask back to back in add order (bossx_strat_bytes bytes); `contig_on`
+ *      (may be NULL) one byte per contig in add order = any(Contig.switched_on).  The optional
+ *      statistics arrays are those of bossx_histogram.                                       */
+typedef struct bossx_update_params {
+    int32_t windows[BOSSX_NWIN];
+    int32_t reserved;
+    double  mult[10];
+    double  tc;                 /* ReadlengthDist.time_cost // 100 (sequences.py:581)           */
+    double  bucket_threshold;   /* OptionalConfig.bucket_threshold (config.py:51)               */
+    const double *fhat_c;       /* as bossx_fhat_desc                                           */
+    int64_t n_windows;
+    int64_t target_rs;
+} bossx_update_params;
+
+typedef struct bossx_update_result {
+    int32_t updated;            /* 1 if the strategy was recomputed (switched_on)               */
+    int32_t any_on;
+    int32_t strat_size;         /* argmax + 1 of sequences.py:636                               */
+    int32_t n_bins;             /* occupied exponent bins                                       */
+    double  threshold;
+    double  normaliser;
+    double  ubar0;
+} bossx_update_result;
+
+int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all,
+                 uint8_t *contig_on, bossx_update_result *res, int64_t *counts,
+                 uint64_t *fgrid_fx, uint64_t *ubar0_fx);
+int64_t bossx_strat_bytes(const bossx_engine *h);
+int64_t bossx_strat_offset(const bossx_engine *h, int32_t contig);
+
 /* Contig.strat as bool bytes, reference layout [length//100][2][nbarcodes] (a rejected
  * contig has the single byte 0, reference.py:116).  Synchronises.                           */
 int bossx_get_strat(bossx_engine *h, int32_t contig, uint8_t *dst);
@@ -173,6 +212,8 @@ int64_t bossx_merged_bins(const bossx_engine *h);   /* sum over non-rejected of 
  *   4 benefit    float64[nb][2][L//100+1] (additional_benefit, reference.py:266-269)
  *   5 site state uint8[nb][L] (bit0-1 ref base, bit2 scored, bit3 zeroed by dropout)
  *   6 touched    uint8[L]     (change_mask rows of the pending batch)
+ *   7 bucket switches uint8[nb][L//20000+1] (export only)
+ *   8 benefit tail float64[nb][2][min(L//100+1, n_filt)] (export only; multi-GPU halo rows)
  * bossx_import accepts 0, 2, 5, 6.                                                            */
 int bossx_export(bossx_engine *h, int32_t contig, int32_t which, void *dst, size_t dst_bytes);
 int bossx_import(bossx_engine *h, int32_t contig, int32_t which, const void *src, size_t src_bytes);

@@ -28,12 +28,16 @@ def _product(ploidy, nb, in_tmp):
     return runs
 
 
+@pytest.mark.parametrize("mode", ["fused", "staged"])
 @pytest.mark.parametrize("tag,ploidy,nb", SCENARIOS)
-def test_end_to_end_vs_oracle_and_golden(tag, ploidy, nb, in_tmp):
+def test_end_to_end_vs_oracle_and_golden(tag, ploidy, nb, mode, in_tmp):
     from oracle.pipeline import OracleRuns
     g = np.load(os.path.join(GOLDEN, "g_e2e_%s.npz" % tag))
     contigs = e2e_reference()
     runs = _product(ploidy, nb, in_tmp)
+    runs.keep_stats = True
+    if mode == "staged":
+        runs.update_wrapper = runs.update_wrapper_staged
     o = OracleRuns(e2e_contig_strings(contigs), ploidy=ploidy, reject_refs={E2E_REJECT}, nbarcodes=nb)
     assert runs.ref.n_sites == o.n_sites
     for b in range(E2E_BATCHES):
@@ -136,3 +140,36 @@ def test_export_import_roundtrip(in_tmp):
     runs2.engine.import_state(c2.index, "entropy", ent)
     assert np.array_equal(c2.coverage, cov) and np.array_equal(c2.scores, scores)
     assert np.array_equal(c2.entropy, ent)
+
+
+def test_distributed_protocol_single_rank_nccl(in_tmp, monkeypatch):
+    """The multi-GPU protocol on one GPU with the collectives forced on (nccl = RCCL): device
+    tensors, dtypes and the stage-wise engine calls; result must equal the fused update."""
+    import torch
+    import torch.distributed as dist
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.parallel import DistributedBossRuns
+    monkeypatch.setenv("BOSSX_FORCE_COLLECTIVES", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29631")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        contigs = e2e_reference()
+        args = BossConfig()
+        args.general.name = "dist"
+        args.optional.reject_refs = E2E_REJECT
+        d = DistributedBossRuns(args)
+        d.init(contigs=e2e_contig_strings(contigs))
+        f = _product(1, 1, in_tmp)
+        for b in range(3):
+            batch = e2e_batch(contigs, b, 1)
+            d.process_batch_paf(batch["paf"], batch["seqs"], read_lengths=batch["read_lengths"])
+            f.rl_dist.update(batch["read_lengths"])
+            f.process_batch_paf(batch["paf"], batch["seqs"])
+            assert d.threshold == f.threshold
+            for n in f.contigs:
+                assert np.array_equal(d.contigs[n].strat, f.contigs[n].strat), (b, n)
+        assert d.comm.n_collectives >= 6
+    finally:
+        dist.destroy_process_group()
