@@ -199,6 +199,7 @@ def main():
                          "algorithmic_bytes": kern[roof_k]["bytes"], "avg_launch_ms": kern[roof_k]["avg_ms"]},
             "kernels": kern, "dominant_kernel_by_time": dom,
             "host": {"stage_batch_ms_mean": 1e3 * float(np.mean(t_parse))},
+            "move_sum_on_fp64_matrix_core": eng.matrix_chain,
         }
         if not a.no_cpu_baseline:
             _, times = cpu_baseline(contigs, batches, a.cpu_updates)

@@ -85,6 +85,7 @@ PROTOTYPES = {
     "bossx_contig_length": (C.c_int64, [C.c_void_p, C.c_int32]),
     "bossx_n_sites": (C.c_int64, [C.c_void_p]),
     "bossx_merged_bins": (C.c_int64, [C.c_void_p]),
+    "bossx_matrix_chain": (C.c_int32, [C.c_void_p]),
     "bossx_export": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]),
     "bossx_import": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]),
     "bossx_preload_coverage": (C.c_int, [C.c_void_p, C.c_double, C.c_uint64]),

@@ -23,6 +23,7 @@ struct bossx_engine {
     bool finalized = false;
     bool lut_set = false;
     bool all_local = true;
+    bool matrix_chain = false;      // FP64 matrix-core recurrence passed its start-up self-test
     int32_t nb = 1;
 
     std::vector<ContigInfo> contigs;                    // add order (rejected included)
@@ -54,11 +55,17 @@ struct bossx_engine {
         EmitOp *d_ops = nullptr; size_t ops_cap = 0;
         uint32_t *d_tiles = nullptr; size_t tiles_cap = 0;
         uint8_t *d_blob = nullptr; size_t blob_cap = 0;
+        TileSeg *d_segs = nullptr; size_t segs_cap = 0;
+        TileRef *d_tilerefs = nullptr; size_t tilerefs_cap = 0;
         ParsedBatch pb;
         bool valid = false;
     };
     std::vector<Staged> slots = std::vector<Staged>(1);
     int32_t slot = 0;
+    int32_t pending_slot = -1;      // staged batch whose increments the next sweep applies
+    double pending_emit = 0, pending_ops = 0;
+    bool touched_dirty = false;     // the `touched` byte array holds flags the next sweep must read
+    uint32_t *d_tile_ref = nullptr;
     // pinned scratch
     void *h_pin = nullptr; size_t pin_cap = 0;
     std::vector<int32_t> drop_thr_host;
@@ -156,11 +163,38 @@ void time_collect(bossx_engine *h) {
 SweepParams sweep_params(bossx_engine *h) {
     SweepParams P;
     P.cov = h->d_cov; P.meta = h->d_meta; P.touched = h->d_touched; P.entropy = h->d_entropy;
+    P.tile_ref = h->d_tile_ref; P.tiles = nullptr; P.segs = nullptr; P.ops = nullptr; P.blob = nullptr;
+    P.err_flag = h->d_err; P.use_touched = h->touched_dirty ? 1 : 0;
+    if (h->pending_slot >= 0) {
+        const bossx_engine::Staged &st = h->slots[size_t(h->pending_slot)];
+        P.tiles = st.d_tilerefs; P.segs = st.d_segs; P.ops = st.d_ops; P.blob = st.d_blob;
+    }
     P.ds = h->d_ds; P.bucket_sums = h->d_bucket_sums; P.drop_count = h->d_drop_count;
     P.lut_score = h->d_lut_score; P.lut_ent = h->d_lut_ent; P.ct = table_of(h);
     P.Gp = h->Gp; P.B = h->B; P.NBK = h->NBK; P.nb = h->nb;
     P.score0 = h->score0; P.tiny = std::numeric_limits<double>::min();
     return P;
+}
+
+// Rare path: a second batch arrives (or a slot is re-staged) before the sweep that would have
+// applied the pending one.  Apply the pending batch with the global-atomic scatter kernel; it
+// marks `touched`, which the next sweep then reads.
+int flush_pending(bossx_engine *h) {
+    if (h->pending_slot < 0) return BOSSX_OK;
+    const bossx_engine::Staged &st = h->slots[size_t(h->pending_slot)];
+    const ParsedBatch &pb = st.pb;
+    const uint32_t n = uint32_t(pb.tiles.size());
+    hipLaunchKernelGGL(tile_ref_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, st.d_tilerefs, n, h->d_tile_ref, 0);
+    const uint32_t n_tiles = uint32_t((pb.total_emit + kEmitTile - 1) / kEmitTile);
+    time_begin(h, BOSSX_K_INGEST);
+    hipLaunchKernelGGL(ingest_scatter_kernel, dim3(n_tiles), dim3(256), 0, h->stream, st.d_ops, st.d_tiles,
+                       uint32_t(pb.ops.size()), pb.total_emit, st.d_blob, reinterpret_cast<uint32_t *>(h->d_cov),
+                       h->d_touched, uint64_t(h->Gp / 2), h->d_err);
+    time_end(h, BOSSX_K_INGEST, 6.0 * double(pb.total_emit) + 16.0 * double(pb.ops.size()));
+    HIPCHK(hipGetLastError());
+    h->pending_slot = -1;
+    h->touched_dirty = true;
+    return BOSSX_OK;
 }
 
 int check_contig(bossx_engine *h, int32_t c, bool need_filt) {
@@ -217,7 +251,8 @@ void bossx_destroy(bossx_engine *h) {
                     h->d_stats, h->d_err, h->d_tile_off, h->d_site_off, h->d_length, h->d_bin_off, h->d_row_off,
                     h->d_strat_off, h->d_bucket_off, h->d_drop_thr, h->d_local, h->d_ctrl, h->d_contig_on};
     for (void *p : ptrs) if (p) hipFree(p);
-    for (auto &st : h->slots) { if (st.d_ops) hipFree(st.d_ops); if (st.d_tiles) hipFree(st.d_tiles); if (st.d_blob) hipFree(st.d_blob); }
+    for (auto &st : h->slots) { if (st.d_ops) hipFree(st.d_ops); if (st.d_tiles) hipFree(st.d_tiles); if (st.d_blob) hipFree(st.d_blob); if (st.d_segs) hipFree(st.d_segs); if (st.d_tilerefs) hipFree(st.d_tilerefs); }
+    if (h->d_tile_ref) hipFree(h->d_tile_ref);
     if (h->h_pin) hipHostFree(h->h_pin);
     for (int k = 0; k < BOSSX_K_COUNT; ++k) { if (h->ev0[k]) hipEventDestroy(h->ev0[k]); if (h->ev1[k]) hipEventDestroy(h->ev1[k]); }
     if (h->own_stream) hipStreamDestroy(h->stream);
@@ -320,7 +355,8 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
     if ((rc = dev_alloc(h, &h->d_bucket_on, size_t(nb * h->NBK), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_bucket_sums, size_t(nb * h->NBK), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_drop_count, size_t(h->n_tiles), true))) return rc;
-    if ((rc = dev_alloc(h, &h->d_stats, size_t(BOSSX_HIST_BINS * 3 + 4 + 64), true))) return rc;
+    if ((rc = dev_alloc(h, &h->d_tile_ref, size_t(h->n_tiles), true))) return rc;
+    if ((rc = dev_alloc(h, &h->d_stats, size_t(BOSSX_HIST_BINS * 3 + 4 + 128), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_err, 1, true))) return rc;
     if ((rc = dev_alloc(h, &h->d_ctrl, 1, true))) return rc;
     if ((rc = dev_alloc(h, &h->d_contig_on, h->filt.size(), true))) return rc;
@@ -365,6 +401,17 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
         }
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_binom), bn, sizeof(bn)));
     HIPCHK(hipStreamSynchronize(h->stream));
+    // matrix-core recurrence: use it only if it reproduces sequential v_add_f64 bit for bit
+    if (!getenv("BOSSX_NO_MATRIX_CHAIN")) {
+        HIPCHK(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
+        hipLaunchKernelGGL(mfma_selftest_kernel, dim3(64), dim3(64), 0, h->stream, 0x5eedULL, h->d_err);
+        int32_t bad = 1;
+        HIPCHK(hipMemcpyAsync(&bad, h->d_err, sizeof(bad), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->matrix_chain = (bad == 0);
+        HIPCHK(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
+        if (!h->matrix_chain) fprintf(stderr, "bossx: FP64 matrix-core recurrence self-test failed (%d); using the vector-ALU chain\n", bad);
+    }
     h->finalized = true;
     return BOSSX_OK;
 }
@@ -397,6 +444,10 @@ int bossx_stage_batch(bossx_engine *h, const char *paf, size_t paf_len, const ch
     HIPCHK(hipStreamSynchronize(h->stream));
     const size_t blob_bytes = n_reads > 0 ? size_t(seq_off[n_reads]) : 0;
     if (blob_bytes >= (size_t(1) << 32)) return fail(h, BOSSX_E_RANGE, "read blob larger than 4 GiB");
+    if (h->pending_slot == h->slot) {     // the slot still feeds the next sweep: apply it now
+        if ((rc = flush_pending(h))) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
     bossx_engine::Staged &st = h->slots[size_t(h->slot)];
     st.valid = false;
     if (pb.ops.size() > st.ops_cap) {
@@ -417,7 +468,21 @@ int bossx_stage_batch(bossx_engine *h, const char *paf, size_t paf_len, const ch
         st.blob_cap = (blob_bytes + 16) * 9 / 8;
         if ((rc = dev_alloc(h, &st.d_blob, st.blob_cap))) return rc;
     }
+    if (pb.segs.size() > st.segs_cap) {
+        if (st.d_segs) HIPCHK(hipFree(st.d_segs));
+        st.d_segs = nullptr;
+        st.segs_cap = pb.segs.size() * 9 / 8 + 64;
+        if ((rc = dev_alloc(h, &st.d_segs, st.segs_cap))) return rc;
+    }
+    if (pb.tiles.size() > st.tilerefs_cap) {
+        if (st.d_tilerefs) HIPCHK(hipFree(st.d_tilerefs));
+        st.d_tilerefs = nullptr;
+        st.tilerefs_cap = pb.tiles.size() * 9 / 8 + 64;
+        if ((rc = dev_alloc(h, &st.d_tilerefs, st.tilerefs_cap))) return rc;
+    }
     if (!pb.ops.empty()) {
+        HIPCHK(hipMemcpyAsync(st.d_segs, pb.segs.data(), pb.segs.size() * sizeof(TileSeg), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(st.d_tilerefs, pb.tiles.data(), pb.tiles.size() * sizeof(TileRef), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(st.d_ops, pb.ops.data(), pb.ops.size() * sizeof(EmitOp), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(st.d_tiles, pb.tile_first_op.data(), pb.tile_first_op.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
         if (blob_bytes) HIPCHK(hipMemcpyAsync(st.d_blob, seqs, blob_bytes, hipMemcpyHostToDevice, h->stream));
@@ -438,18 +503,19 @@ int bossx_select_batch(bossx_engine *h, int32_t slot) {
 int bossx_ingest_staged(bossx_engine *h) {
     if (!h || !h->slots[size_t(h->slot)].valid) return fail(h, BOSSX_E_INVALID, "no staged batch in the selected slot");
     HIPCHK(hipSetDevice(h->cfg.device));
+    int rc;
+    if (h->pending_slot >= 0 && (rc = flush_pending(h))) return rc;   // two batches before one sweep
     const bossx_engine::Staged &st = h->slots[size_t(h->slot)];
     const ParsedBatch &pb = st.pb;
     for (size_t i = 0; i < h->contigs.size(); ++i) h->contigs[i].cov_total += pb.emitted_per_contig[i];
     if (pb.total_emit == 0) return BOSSX_OK;
-    const uint32_t n_tiles = uint32_t((pb.total_emit + kEmitTile - 1) / kEmitTile);
-    time_begin(h, BOSSX_K_INGEST);
-    hipLaunchKernelGGL(ingest_scatter_kernel, dim3(n_tiles), dim3(256), 0, h->stream, st.d_ops, st.d_tiles,
-                       uint32_t(pb.ops.size()), pb.total_emit, st.d_blob, reinterpret_cast<uint32_t *>(h->d_cov),
-                       h->d_touched, uint64_t(h->Gp / 2), h->d_err);
-    // algorithmic bytes: 1 B read base + 2 B counter read + 2 B counter write + 1 B touched flag
-    time_end(h, BOSSX_K_INGEST, 6.0 * double(pb.total_emit) + 16.0 * double(pb.ops.size()));
+    // the increments are applied by the next sweep, tile by tile (site_sweep_kernel prologue)
+    const uint32_t n = uint32_t(pb.tiles.size());
+    hipLaunchKernelGGL(tile_ref_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, st.d_tilerefs, n, h->d_tile_ref, 1);
     HIPCHK(hipGetLastError());
+    h->pending_slot = h->slot;
+    h->pending_emit = double(pb.total_emit);
+    h->pending_ops = double(pb.ops.size());
     return BOSSX_OK;
 }
 
@@ -479,14 +545,23 @@ int launch_sweep(bossx_engine *h) {
     SweepParams P = sweep_params(h);
     time_begin(h, BOSSX_K_SWEEP);
     if (h->n_tiles > 0)
-        hipLaunchKernelGGL(site_sweep_kernel, dim3(uint32_t(h->n_tiles)), dim3(256), 0, h->stream, P);
-    // algorithmic bytes per site*barcode: 10 B counters + 1 B state read; per site: 1 B touched
-    // read; per 100-site bin: 8 B downsampled score write (entropy and state write-backs are
-    // data dependent and not counted)
+        hipLaunchKernelGGL(site_sweep_kernel<false>, dim3(uint32_t(h->n_tiles)), dim3(256), 0, h->stream, P);
+    if (h->pending_slot >= 0 && !h->slots[size_t(h->pending_slot)].pb.tiles.empty())
+        hipLaunchKernelGGL(site_sweep_kernel<true>, dim3(uint32_t(h->slots[size_t(h->pending_slot)].pb.tiles.size())),
+                           dim3(256), 0, h->stream, P);
+    // algorithmic bytes: per site*barcode 10 B counters + 1 B state read; per 100-site bin 8 B
+    // downsampled score write; per ingested base 1 B read base + 2 B counter write-back, per
+    // emit run 16 B (entropy / state write-backs of changed sites are data dependent and not
+    // counted; the counter READ of an ingested base is already in the 10 B/site)
     double sites = 0;
     for (int32_t fi : h->filt) if (!h->contigs[size_t(fi)].remote) sites += double(h->contigs[size_t(fi)].length);
-    time_end(h, BOSSX_K_SWEEP, sites * h->nb * 11.0 + sites * 1.0 + double(h->B) * h->nb * 8.0);
+    double bytes = sites * h->nb * 11.0 + double(h->B) * h->nb * 8.0;
+    if (h->touched_dirty) bytes += sites;
+    if (h->pending_slot >= 0) bytes += 3.0 * h->pending_emit + 16.0 * h->pending_ops;
+    time_end(h, BOSSX_K_SWEEP, bytes);
     HIPCHK(hipGetLastError());
+    h->pending_slot = -1;
+    h->touched_dirty = false;
     return BOSSX_OK;
 }
 }  // namespace
@@ -553,16 +628,23 @@ int fill_chain_params(bossx_engine *h, const int32_t *windows, const double *mul
     P.probe = getenv("BOSSX_CHAIN_PROBE") ? reinterpret_cast<long long *>(h->d_stats + kStatWords + 8) : nullptr;
     P.max_limit = std::min<int64_t>(h->B, h->n_sites_all / kWindow);
     lds = size_t(ring) * sizeof(double);
-    if (lds > 32 * 1024)
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_kernel),
+    if (lds > 32 * 1024) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_kernel<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_kernel<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    }
     return BOSSX_OK;
 }
 
 void launch_chain(bossx_engine *h, const ChainParams &P, size_t lds) {
     time_begin(h, BOSSX_K_BENEFIT);
-    hipLaunchKernelGGL(benefit_chain_kernel, dim3(uint32_t(h->filt.size() * size_t(h->nb) * 2)), dim3(kChainThreads),
-                       lds, h->stream, P);
+    if (h->matrix_chain)
+        hipLaunchKernelGGL(benefit_chain_kernel<true>, dim3(uint32_t(h->filt.size() * size_t(h->nb) * 2)), dim3(kChainThreads),
+                           lds, h->stream, P);
+    else
+        hipLaunchKernelGGL(benefit_chain_kernel<false>, dim3(uint32_t(h->filt.size() * size_t(h->nb) * 2)), dim3(kChainThreads),
+                           lds, h->stream, P);
     // algorithmic bytes: read the downsampled scores once per direction, write both strands
     time_end(h, BOSSX_K_BENEFIT, double(h->B) * h->nb * (2 * 8.0 + 2 * 8.0));
 }
@@ -586,13 +668,13 @@ int bossx_benefit(bossx_engine *h, const int32_t *windows, const double *mult, d
     memcpy(&mx, &bits, sizeof(mx));
     if (max_benefit) *max_benefit = mx;
     if (P.probe) {
-        long long pr[40];
+        long long pr[72];
         HIPCHK(hipMemcpy(pr, P.probe, sizeof(pr), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[chain probe] chunks=%lld\n", pr[32]);
-        for (int w = 0; w < 8; ++w)
+        fprintf(stderr, "[chain probe] chunks=%lld\n", pr[64]);
+        for (int w = 0; w < 16; ++w)
             fprintf(stderr, "  wave %d: total %lld  A %lld  B %lld  C %lld (cycles; per chunk %.0f / %.0f / %.0f / %.0f)\n", w, pr[w * 4],
-                    pr[w * 4 + 1], pr[w * 4 + 2], pr[w * 4 + 3], double(pr[w * 4]) / double(pr[32]), double(pr[w * 4 + 1]) / double(pr[32]),
-                    double(pr[w * 4 + 2]) / double(pr[32]), double(pr[w * 4 + 3]) / double(pr[32]));
+                    pr[w * 4 + 1], pr[w * 4 + 2], pr[w * 4 + 3], double(pr[w * 4]) / double(pr[64]), double(pr[w * 4 + 1]) / double(pr[64]),
+                    double(pr[w * 4 + 2]) / double(pr[64]), double(pr[w * 4 + 3]) / double(pr[64]));
     }
     return BOSSX_OK;
 }
@@ -771,6 +853,7 @@ int64_t bossx_contig_length(const bossx_engine *h, int32_t c) {
 }
 int64_t bossx_n_sites(const bossx_engine *h) { return h ? h->n_sites_all : 0; }
 int64_t bossx_merged_bins(const bossx_engine *h) { return h ? h->B : 0; }
+int32_t bossx_matrix_chain(const bossx_engine *h) { return (h && h->matrix_chain) ? 1 : 0; }
 int64_t bossx_strat_bytes(const bossx_engine *h) { return h ? h->strat_bytes : 0; }
 int64_t bossx_strat_offset(const bossx_engine *h, int32_t c) {
     if (!h || c < 0 || c >= int32_t(h->contigs.size()) || h->contigs[size_t(c)].rejected || h->contigs[size_t(c)].remote) return -1;
@@ -781,6 +864,7 @@ int bossx_export(bossx_engine *h, int32_t contig, int32_t which, void *dst, size
     int rc = check_contig(h, contig, true);
     if (rc) return rc;
     HIPCHK(hipSetDevice(h->cfg.device));
+    if (h->pending_slot >= 0 && (rc = flush_pending(h))) return rc;   // make staged increments visible
     const ContigInfo &c = h->contigs[size_t(contig)];
     const int64_t L = c.length, nb = h->nb, nbin = c.T + 1;
     auto need = [&](size_t n) { return dst_bytes >= n; };
@@ -865,6 +949,7 @@ int bossx_import(bossx_engine *h, int32_t contig, int32_t which, const void *src
     int rc = check_contig(h, contig, true);
     if (rc) return rc;
     HIPCHK(hipSetDevice(h->cfg.device));
+    if (h->pending_slot >= 0 && (rc = flush_pending(h))) return rc;
     ContigInfo &c = h->contigs[size_t(contig)];
     const int64_t L = c.length, nb = h->nb;
     switch (which) {
@@ -901,6 +986,7 @@ int bossx_import(bossx_engine *h, int32_t contig, int32_t which, const void *src
         case 6: {
             if (src_bytes != size_t(L)) return fail(h, BOSSX_E_INVALID, "import size mismatch");
             HIPCHK(hipMemcpy(h->d_touched + c.site_off, src, size_t(L), hipMemcpyHostToDevice));
+            h->touched_dirty = true;
             break;
         }
         default:
@@ -929,6 +1015,7 @@ int bossx_preload_coverage(bossx_engine *h, double depth, uint64_t seed) {
         c.cov_total = tot;
     }
     HIPCHK(hipGetLastError());
+    h->touched_dirty = true;
     return BOSSX_OK;
 }
 

@@ -15,7 +15,8 @@ constexpr int kWindow = BOSSX_WINDOW;      // 100-bp strategy window
 constexpr int kBucket = BOSSX_BUCKET;      // 20-kb activation bucket
 constexpr int kTileSites = 2000;           // sites per sweep tile: 20 bins, 1/10 bucket
 constexpr int kTileBins = kTileSites / kWindow;
-constexpr int kEmitTile = 2048;            // emitted reference bases per ingest tile
+constexpr int kEmitTile = 2048;            // emitted reference bases per ingest tile (fallback scatter)
+constexpr int kSegMax = 1024;              // emitted bases per tile segment (one LDS staging round)
 
 // One emitting CIGAR run (M-like or D) of a chosen mapping, 16 bytes, loaded as one uint4.
 //   emit_start : index of its first emitted base in the batch-wide emit order
@@ -51,8 +52,22 @@ struct ContigInfo {
     uint64_t cov_total = 0;   // sum of all counters of this contig (all barcodes)
 };
 
+// A read's stretch of at most kSegMax emitted bases that falls into one sweep tile.
+struct TileSeg {
+    uint32_t e_lo, e_hi;      // emit-index range [e_lo, e_hi)
+    uint32_t op_lo, op_hi;    // first and last (inclusive) emit run overlapping the range
+};
+// A sweep tile that receives bases from the batch, with its slice of the segment list.
+struct TileRef {
+    uint32_t tile;            // global sweep tile index
+    uint32_t seg_lo, seg_hi;  // segments [seg_lo, seg_hi)
+    uint32_t pad;
+};
+
 struct ParsedBatch {
     std::vector<EmitOp> ops;
+    std::vector<TileSeg> segs;             // grouped by tile (counting sort)
+    std::vector<TileRef> tiles;            // touched tiles, ascending
     std::vector<uint32_t> tile_first_op;   // n_tiles + 1 entries
     uint64_t total_emit = 0;
     std::vector<uint64_t> emitted_per_contig;   // indexed by contig add order

@@ -11,6 +11,7 @@
 // BOSSX_E_RANGE); on error nothing is ingested.
 #include "engine.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <string_view>
@@ -157,6 +158,8 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
     // ---- pass 2: chosen mappings -> emit runs ------------------------------------------------
     uint64_t cur_emit = 0;
     out.tile_first_op.clear();
+    std::vector<TileSeg> raw_segs;
+    std::vector<uint32_t> raw_tile;
     int32_t n_rec = 0;
     for (const Group &g : groups) {
         const Rec &r = g.best;
@@ -261,6 +264,45 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             return BOSSX_E_PARSE;
         }
         out.emitted_per_contig[size_t(cidx)] += uint64_t(thi - tlo);
+        // split the read's emitted stretch at sweep-tile boundaries (padded site space)
+        if (out.ops.size() > first_op) {
+            const uint64_t site0 = uint64_t(c.site_off + tlo);
+            const uint64_t site1 = uint64_t(c.site_off + thi);
+            const uint64_t e0 = out.ops[first_op].emit_start;
+            size_t op = first_op;
+            for (uint64_t t = site0 / kTileSites; t * kTileSites < site1; ++t) {
+                const uint64_t s_lo = std::max<uint64_t>(t * kTileSites, site0);
+                const uint64_t s_hi = std::min<uint64_t>((t + 1) * kTileSites, site1);
+                // pieces of at most kSegMax emitted bases, each with its exact emit-run range
+                for (uint64_t p_lo = s_lo; p_lo < s_hi; p_lo += kSegMax) {
+                    const uint64_t p_hi = std::min<uint64_t>(p_lo + kSegMax, s_hi);
+                    TileSeg sg;
+                    sg.e_lo = uint32_t(e0 + (p_lo - site0));
+                    sg.e_hi = uint32_t(e0 + (p_hi - site0));
+                    while (op + 1 < out.ops.size() && out.ops[op + 1].emit_start <= sg.e_lo) ++op;
+                    sg.op_lo = uint32_t(op);
+                    size_t oh = op;
+                    while (oh + 1 < out.ops.size() && out.ops[oh + 1].emit_start < sg.e_hi) ++oh;
+                    sg.op_hi = uint32_t(oh);
+                    raw_segs.push_back(sg);
+                    raw_tile.push_back(uint32_t(t));
+                }
+            }
+        }
+    }
+    // group segments by tile (stable sort of the small tile-id list)
+    {
+        std::vector<uint32_t> order(raw_segs.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = uint32_t(i);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return raw_tile[a] < raw_tile[b]; });
+        out.segs.reserve(order.size());
+        for (uint32_t idx : order) {
+            const uint32_t t = raw_tile[idx];
+            if (out.tiles.empty() || out.tiles.back().tile != t)
+                out.tiles.push_back(TileRef{t, uint32_t(out.segs.size()), uint32_t(out.segs.size()), 0});
+            out.segs.push_back(raw_segs[idx]);
+            out.tiles.back().seg_hi = uint32_t(out.segs.size());
+        }
     }
     if (cur_emit >= (1ull << 32) - kEmitTile) {
         err = "batch too large: more than 2^32 aligned bases";

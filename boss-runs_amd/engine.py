@@ -219,6 +219,10 @@ class Engine:
         return self.lib.bossx_n_sites(self.h)
 
     @property
+    def matrix_chain(self):
+        return bool(self.lib.bossx_matrix_chain(self.h))
+
+    @property
     def merged_bins(self):
         return self.lib.bossx_merged_bins(self.h)
 

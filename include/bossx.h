@@ -203,6 +203,9 @@ int32_t bossx_n_contigs(const bossx_engine *h);
 int64_t bossx_contig_length(const bossx_engine *h, int32_t contig);
 int64_t bossx_n_sites(const bossx_engine *h);       /* Reference.n_sites (reference.py:343)   */
 int64_t bossx_merged_bins(const bossx_engine *h);   /* sum over non-rejected of length//100+1 */
+/* 1 if the move_sum recurrence runs on the FP64 matrix core (it passed the bit-exactness
+ * self-test at finalize), 0 if on the vector ALU.  Results are identical either way.         */
+int32_t bossx_matrix_chain(const bossx_engine *h);
 
 /* Parity / checkpoint hooks.  `which`:
  *   0 coverage   uint16[nb][5][L]        (reference holds [L][5][nb])

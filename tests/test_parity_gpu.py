@@ -173,3 +173,29 @@ def test_distributed_protocol_single_rank_nccl(in_tmp, monkeypatch):
         assert d.comm.n_collectives >= 6
     finally:
         dist.destroy_process_group()
+
+
+def test_two_batches_before_one_sweep(in_tmp):
+    """A second batch ingested before the sweep takes the global-atomic fallback path; the
+    result must equal two separate oracle increments followed by one update."""
+    from oracle.pipeline import OracleRuns
+    from oracle.pafcigar import parse_paf, convert_records
+    runs = _product(1, 1, in_tmp)
+    contigs = e2e_reference()
+    o = OracleRuns(e2e_contig_strings(contigs), reject_refs={E2E_REJECT})
+    incs = {n: [] for n in o.contigs_filt}
+    for b in range(2):
+        batch = e2e_batch(contigs, b, 1)
+        runs.engine.ingest_paf(batch["paf"], batch["seqs"])
+        for n, lst in convert_records(parse_paf(batch["paf"], min_len=200), batch["seqs"]).items():
+            if n in incs:
+                incs[n].extend(lst)
+    for n, c in o.contigs_filt.items():
+        c.increment_coverage(incs[n])
+    runs.engine.sweep()
+    for n, c in o.contigs_filt.items():
+        c.update_scores(o.cache)
+        c.modify_scores()
+        assert np.array_equal(runs.contigs[n].coverage, c.coverage)
+        assert np.array_equal(runs.contigs[n].scores, c.scores)
+        assert np.array_equal(runs.contigs[n].entropy, c.entropy)
