@@ -165,6 +165,7 @@ SweepParams sweep_params(bossx_engine *h) {
     P.cov = h->d_cov; P.meta = h->d_meta; P.touched = h->d_touched; P.entropy = h->d_entropy;
     P.tile_ref = h->d_tile_ref; P.tiles = nullptr; P.segs = nullptr; P.ops = nullptr; P.blob = nullptr;
     P.err_flag = h->d_err; P.use_touched = h->touched_dirty ? 1 : 0;
+    P.probe = getenv("BOSSX_SWEEP_PROBE") ? h->d_stats + kStatWords + 80 : nullptr;
     if (h->pending_slot >= 0) {
         const bossx_engine::Staged &st = h->slots[size_t(h->pending_slot)];
         P.tiles = st.d_tilerefs; P.segs = st.d_segs; P.ops = st.d_ops; P.blob = st.d_blob;
@@ -560,6 +561,16 @@ int launch_sweep(bossx_engine *h) {
     if (h->pending_slot >= 0) bytes += 3.0 * h->pending_emit + 16.0 * h->pending_ops;
     time_end(h, BOSSX_K_SWEEP, bytes);
     HIPCHK(hipGetLastError());
+    if (P.probe) {
+        unsigned long long pr[24];
+        HIPCHK(hipMemcpy(pr, P.probe, sizeof(pr), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemset(P.probe, 0, sizeof(pr)));
+        fprintf(stderr, "[sweep probe] plain: %llu blocks, %.0f cycles each | ingest: %llu blocks, %.0f cycles each (expand %.0f, apply %.0f), %.1f segs/tile\n",
+                pr[0], pr[0] ? double(pr[1]) / pr[0] : 0.0, pr[8], pr[8] ? double(pr[9]) / pr[8] : 0.0,
+                pr[8] ? double(pr[10]) / pr[8] : 0.0, pr[8] ? double(pr[11]) / pr[8] : 0.0, pr[8] ? double(pr[12]) / pr[8] : 0.0);
+        if (pr[16]) fprintf(stderr, "[sweep probe] per wave-round (%llu rounds): stage %.0f, search+issue %.0f, prefetch %.0f, accumulate %.0f cycles\n",
+                            pr[16], double(pr[17]) / pr[16], double(pr[18]) / pr[16], double(pr[19]) / pr[16], double(pr[20]) / pr[16]);
+    }
     h->pending_slot = -1;
     h->touched_dirty = false;
     return BOSSX_OK;

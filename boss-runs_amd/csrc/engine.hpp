@@ -16,7 +16,7 @@ constexpr int kBucket = BOSSX_BUCKET;      // 20-kb activation bucket
 constexpr int kTileSites = 2000;           // sites per sweep tile: 20 bins, 1/10 bucket
 constexpr int kTileBins = kTileSites / kWindow;
 constexpr int kEmitTile = 2048;            // emitted reference bases per ingest tile (fallback scatter)
-constexpr int kSegMax = 1024;              // emitted bases per tile segment (one LDS staging round)
+constexpr int kSegMax = 256;               // emitted bases per tile segment (one wave's staging round)
 
 // One emitting CIGAR run (M-like or D) of a chosen mapping, 16 bytes, loaded as one uint4.
 //   emit_start : index of its first emitted base in the batch-wide emit order
