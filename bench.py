@@ -136,10 +136,13 @@ def main():
 
     def step(i):
         eng.ingest_staged(slot=i)
+        if not distributed:      # sweep starts now; the host bookkeeping below overlaps with it
+            eng.update_begin(runs.args.optional.bucket_threshold)
         if distributed:
             runs.account_batch(summaries[i], batches[i]["read_lengths"], len(batches[i]["seqs"]))
         else:
             runs.rl_dist.update(batches[i]["read_lengths"])
+            runs.launch_benefit()    # the chain needs only the read-length windows
             runs._account_reads(summaries[i], len(batches[i]["seqs"]))
         runs.update_wrapper()
 

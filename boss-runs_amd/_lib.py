@@ -39,7 +39,7 @@ class FhatDesc(C.Structure):
 
 
 class UpdateParams(C.Structure):
-    _fields_ = [("windows", C.c_int32 * NWIN), ("reserved", C.c_int32), ("mult", C.c_double * 10),
+    _fields_ = [("windows", C.c_int32 * NWIN), ("flags", C.c_int32), ("mult", C.c_double * 10),
                 ("tc", C.c_double), ("bucket_threshold", C.c_double), ("fhat_c", C.c_void_p),
                 ("n_windows", C.c_int64), ("target_rs", C.c_int64)]
 
@@ -76,6 +76,8 @@ PROTOTYPES = {
     "bossx_histogram": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(FhatDesc), C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
     "bossx_apply_threshold": (C.c_int, [C.c_void_p, C.c_double]),
+    "bossx_update_begin": (C.c_int, [C.c_void_p, C.c_double]),
+    "bossx_update_benefit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "bossx_update": (C.c_int, [C.c_void_p, C.POINTER(UpdateParams), C.c_void_p, C.c_void_p,
                                C.POINTER(UpdateResult), C.c_void_p, C.c_void_p, C.c_void_p]),
     "bossx_strat_bytes": (C.c_int64, [C.c_void_p]),

@@ -769,6 +769,41 @@ int bossx_apply_threshold(bossx_engine *h, double threshold) {
     return launch_mask(h, 0);
 }
 
+namespace {
+void launch_buckets(bossx_engine *h, double threshold) {
+    BucketParams P;
+    P.bucket_sums = h->d_bucket_sums; P.bucket_on = h->d_bucket_on; P.contig_on = h->d_contig_on;
+    P.ctrl = h->d_ctrl; P.ct = table_of(h); P.NBK = h->NBK; P.nb = h->nb; P.threshold = threshold;
+    const int64_t blocks = std::min<int64_t>((h->NBK * h->nb + 255) / 256, 1024);
+    hipLaunchKernelGGL(bucket_switch_kernel, dim3(uint32_t(std::max<int64_t>(blocks, 1))), dim3(256), 0, h->stream, P);
+}
+}  // namespace
+
+int bossx_update_begin(bossx_engine *h, double bucket_threshold) {
+    if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "bad update_begin call");
+    if (!h->lut_set) return fail(h, BOSSX_E_INVALID, "update before set_lut");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int rc = launch_sweep(h);
+    if (rc) return rc;
+    launch_buckets(h, bucket_threshold);
+    HIPCHK(hipGetLastError());
+    return BOSSX_OK;
+}
+
+int bossx_update_benefit(bossx_engine *h, const int32_t *windows, const double *mult) {
+    if (!h || !h->finalized || !windows || !mult) return fail(h, BOSSX_E_INVALID, "bad update_benefit call");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    ChainParams CP;
+    size_t lds = 0;
+    int rc = fill_chain_params(h, windows, mult, CP, lds);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream));
+    CP.gate = 1;
+    launch_chain(h, CP, lds);
+    HIPCHK(hipGetLastError());
+    return BOSSX_OK;
+}
+
 // One whole decision update enqueued back to back (no host round trip between kernels):
 // sweep -> bucket switches -> benefit chain -> threshold statistics -> threshold choice ->
 // masks, then one device-to-host copy of all masks and the control block.
@@ -786,18 +821,16 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
         if ((rc = fill_chain_params(h, up->windows, up->mult, CP, lds))) return rc;
         if ((rc = upload_fhat(h, &fh))) return rc;
     }
-    if ((rc = launch_sweep(h))) return rc;
-    {
-        BucketParams P;
-        P.bucket_sums = h->d_bucket_sums; P.bucket_on = h->d_bucket_on; P.contig_on = h->d_contig_on;
-        P.ctrl = h->d_ctrl; P.ct = table_of(h); P.NBK = h->NBK; P.nb = h->nb; P.threshold = up->bucket_threshold;
-        const int64_t blocks = std::min<int64_t>((h->NBK * h->nb + 255) / 256, 1024);
-        hipLaunchKernelGGL(bucket_switch_kernel, dim3(uint32_t(std::max<int64_t>(blocks, 1))), dim3(256), 0, h->stream, P);
+    if (!(up->flags & BOSSX_UPDATE_SWEEP_DONE)) {
+        if ((rc = launch_sweep(h))) return rc;
+        launch_buckets(h, up->bucket_threshold);
     }
     if (have_strategy_inputs) {
-        HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream));
-        CP.gate = 1;
-        launch_chain(h, CP, lds);
+        if (!(up->flags & BOSSX_UPDATE_BENEFIT_DONE)) {
+            HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream));
+            CP.gate = 1;
+            launch_chain(h, CP, lds);
+        }
         if ((rc = launch_hist(h, &fh, 1))) return rc;
         PickParams PP;
         PP.counts = h->d_stats; PP.fgrid = h->d_stats + BOSSX_HIST_BINS; PP.ubar = h->d_stats + BOSSX_HIST_BINS * 3;

@@ -152,6 +152,20 @@ class Engine:
                                           fg.ctypes.data, ub.ctypes.data))
         return counts, fg, ub
 
+    def update_begin(self, bucket_threshold):
+        """Enqueue sweep + bucket switches now (asynchronous); the following `update` call only
+        adds the strategy stages.  Lets host bookkeeping overlap with the sweep."""
+        self._ck(self.lib.bossx_update_begin(self.h, float(bucket_threshold)))
+        self._sweep_done = True
+
+    def update_benefit(self, windows, mult):
+        """Enqueue the move_sum chain now (asynchronous, gated on the device-side armed flag)."""
+        w = np.ascontiguousarray(windows, dtype=np.int32)
+        m = np.ascontiguousarray(mult, dtype=np.float64)
+        assert w.shape == (_lib.NWIN,) and m.shape == (10,)
+        self._ck(self.lib.bossx_update_benefit(self.h, w.ctypes.data, m.ctypes.data))
+        self._benefit_done = tuple(w.tolist())
+
     def update(self, bucket_threshold, windows=None, mult=None, tc=0.0, fhat_c=None, target_rs=0,
                want_stats=False):
         """bossx_update: one fused decision update.  Without `fhat_c` only the sweep and the
@@ -174,6 +188,12 @@ class Engine:
             up.target_rs = int(target_rs)
         up.tc = float(tc)
         up.bucket_threshold = float(bucket_threshold)
+        up.flags = 1 if getattr(self, "_sweep_done", False) else 0
+        done = getattr(self, "_benefit_done", None)
+        if done is not None and fhat_c is not None and done == tuple(int(x) for x in windows):
+            up.flags |= 2
+        self._sweep_done = False
+        self._benefit_done = None
         if getattr(self, "strat_all", None) is None:
             self.strat_all = np.ones(max(int(self.lib.bossx_strat_bytes(self.h)), 1), dtype=np.uint8)
         on = np.zeros(len(self.names), dtype=np.uint8)

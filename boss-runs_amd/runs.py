@@ -106,6 +106,7 @@ class BossRuns(Boss):
         self.threshold = None
         self.last_stats = {}
         self.write_masks = True
+        self._fused = True             # False when update_wrapper is replaced by the staged form
         self.keep_stats = False        # also fetch the threshold statistics (tests)
         self.log_fractions = True
         self._write_contig_strategies(contig_strats=self.ref.get_strategy_dict())
@@ -130,6 +131,9 @@ class BossRuns(Boss):
         """convert_records + _effect_increments + tracker + count_read_starts + update_wrapper
         (core.py:214-224).  `barcodes`: {read id: barcode index} as in simulation.py:148."""
         summ = self.engine.ingest_paf(paf_text, new_reads, barcodes=barcodes, min_len=min_len)
+        if self._fused:       # the GPU sweeps / runs the chain while the host does its bookkeeping
+            self.engine.update_begin(self.args.optional.bucket_threshold)
+            self.launch_benefit()
         self._account_reads(summ, len(new_reads) if n_reads_total is None else n_reads_total, starts_filter)
         self.update_wrapper()
 
@@ -145,6 +149,13 @@ class BossRuns(Boss):
             sel = np.array([starts_filter(summ["ids"][i]) for i in summ["read_idx"]], dtype=bool)
         self.read_starts.count_starts(self.contig_names, summ["contig_idx"][sel], summ["rev"][sel],
                                       summ["tstart"][sel], summ["tend"][sel])
+
+    def launch_benefit(self):
+        """Enqueue calc_smu/calc_u as soon as the read-length windows are known (the caller has
+        already updated `rl_dist`, as boss/core.py:106 does before process_batch_runs)."""
+        if hasattr(self.rl_dist, "time_cost"):
+            windows = np.concatenate(([400 // 100], self.rl_dist.approx_ccl // 100)).astype(np.int32)
+            self.engine.update_benefit(windows, MULT)
 
     # ---- the strategy update --------------------------------------------------------------
     def _update_scores_contigs(self) -> None:

@@ -167,9 +167,11 @@ int bossx_apply_threshold(bossx_engine *h, double threshold);
  *      contig's mask back to back in add order (bossx_strat_bytes bytes); `contig_on`
  *      (may be NULL) one byte per contig in add order = any(Contig.switched_on).  The optional
  *      statistics arrays are those of bossx_histogram.                                       */
+#define BOSSX_UPDATE_SWEEP_DONE   1  /* bossx_update_begin already enqueued sweep + bucket switches */
+#define BOSSX_UPDATE_BENEFIT_DONE 2  /* bossx_update_benefit already enqueued the move_sum chain     */
 typedef struct bossx_update_params {
     int32_t windows[BOSSX_NWIN];
-    int32_t reserved;
+    int32_t flags;
     double  mult[10];
     double  tc;                 /* ReadlengthDist.time_cost // 100 (sequences.py:581)           */
     double  bucket_threshold;   /* OptionalConfig.bucket_threshold (config.py:51)               */
@@ -188,6 +190,14 @@ typedef struct bossx_update_result {
     double  ubar0;
 } bossx_update_result;
 
+/* Optional first half of bossx_update: enqueue the sweep (with the pending batch's increments)
+ * and the bucket switches and return immediately, so the caller's host-side bookkeeping
+ * (read-length distribution, read starts, f-hat) overlaps with it; then call bossx_update with
+ * BOSSX_UPDATE_SWEEP_DONE in `flags`.                                                         */
+int bossx_update_begin(bossx_engine *h, double bucket_threshold);
+/* Optional second part: enqueue calc_smu/calc_u (gated on the device-side "armed" flag) as soon
+ * as the read-length windows are known; asynchronous.                                          */
+int bossx_update_benefit(bossx_engine *h, const int32_t *windows, const double *mult);
 int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all,
                  uint8_t *contig_on, bossx_update_result *res, int64_t *counts,
                  uint64_t *fgrid_fx, uint64_t *ubar0_fx);

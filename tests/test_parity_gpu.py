@@ -38,6 +38,7 @@ def test_end_to_end_vs_oracle_and_golden(tag, ploidy, nb, mode, in_tmp):
     runs.keep_stats = True
     if mode == "staged":
         runs.update_wrapper = runs.update_wrapper_staged
+        runs._fused = False
     o = OracleRuns(e2e_contig_strings(contigs), ploidy=ploidy, reject_refs={E2E_REJECT}, nbarcodes=nb)
     assert runs.ref.n_sites == o.n_sites
     for b in range(E2E_BATCHES):
