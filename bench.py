@@ -44,8 +44,8 @@ def parse_args():
     ap.add_argument("--reads", type=int, default=4000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-updates", type=int, default=3)
-    ap.add_argument("--extra-large", action="store_true",
-                    help="also measure the sweep kernel on a 390 Mb shard (HBM-sized working set)")
+    ap.add_argument("--no-large", action="store_true",
+                    help="skip the extra sweep-kernel measurement on a 200 Mb contig (HBM-sized working set)")
     return ap.parse_args()
 
 
@@ -84,6 +84,54 @@ def make_runs(workload, rank, world, device):
     if preload > 0:
         runs.engine.preload_coverage(preload, seed=7 + rank)
     return runs, mine, nb
+
+
+def pmc_traffic(workload, kernel_substr):
+    """HBM bytes per launch of `kernel_substr` from the newest committed rocprofv3 PMC summary
+    of this workload (profiles/rNN_<workload>_rocprof_summary.json: FETCH_SIZE and WRITE_SIZE
+    from separate --pmc passes, in KB; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_%s_rocprof_summary.json" % workload)))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    tot, found = 0.0, False
+    for name, v in d.get("kernels", {}).items():
+        if kernel_substr in name and "FETCH_SIZE_avg_per_launch" in v and "WRITE_SIZE_avg_per_launch" in v:
+            tot += (2.0 * v["FETCH_SIZE_avg_per_launch"] + v["WRITE_SIZE_avg_per_launch"]) * 1024.0
+            found = True
+    return (tot if found else None), os.path.basename(files[-1])
+
+
+def large_sweep(device, L=200_000_000, reps=5, depth=8.0):
+    """The sweep kernel alone on one 200 Mb contig (working set 2.4 GB >> Infinity Cache):
+    `stream` = fresh state (no LUT gathers), `gather` = every site scored (depth-8 preload)."""
+    from boss_runs_amd.engine import Engine
+    from boss_runs_amd.scoring import SiteScoring
+    rng = np.random.default_rng(1)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=L, dtype=np.uint8)].tobytes()
+    e = Engine(nbarcodes=1, device=device, track_entropy=True)
+    e.add_contig("big", seq)
+    del seq
+    hap = SiteScoring(1)
+    e.finalize(hap.score0[0], hap.ent0[0])
+    e.set_lut(*hap.tables())
+    e.enable_timing(True)
+    out = {"sites": L}
+    for tag in ("stream", "gather"):
+        if tag == "gather":
+            e.preload_coverage(depth, seed=3)
+            e.sweep(); e.synchronize()          # first sweep after the preload touches every site
+        ms = []
+        for _ in range(reps):
+            e.sweep(); e.synchronize()
+            st = e.kernel_stats()["site_sweep"]
+            ms.append(st["ms_last"])
+        m = float(np.median(ms))
+        out[tag] = {"ms": m, "algorithmic_bytes": st["bytes_last"], "achieved": st["bytes_last"] / 1e6 / m,
+                    "frac": st["bytes_last"] / 1e6 / m / HBM_PEAK_GBS, "unit": "GB/s"}
+    e.close()
+    return out
 
 
 def cpu_baseline(contigs, batches, n_updates):
@@ -186,6 +234,7 @@ def main():
         dom = max(kern, key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"])
         roof_k = "site_sweep"    # the HBM-streaming kernel the roofline is quoted on
         achieved = kern[roof_k]["gbs"] or 0.0
+        traffic, traffic_src = pmc_traffic(a.workload, "site_sweep_kernel")
         out = {
             "metric": "decision-update Mbp scored/sec (4000-read batch); ms_per_step = decision-update wall-clock",
             "value": value, "unit": "Mbp/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -198,12 +247,19 @@ def main():
                        "parallelism": "contig-sharded x%d, one global threshold" % world,
                        "collectives_per_update": (runs.comm.n_collectives / max(n_b, 1)) if distributed else 0},
             "roofline": {"kernel": roof_k, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes": kern[roof_k]["bytes"], "avg_launch_ms": kern[roof_k]["avg_ms"]},
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src,
+                         "algorithmic_bytes": kern[roof_k]["bytes"], "avg_launch_ms": kern[roof_k]["avg_ms"],
+                         "note": "site_sweep = sweep<false> + sweep<true> launches (fused CIGAR expansion + "
+                                 "coverage increment + scoring + bin sums); at this size the working set is "
+                                 "cache resident and the kernel is latency bound; see roofline_large"},
             "kernels": kern, "dominant_kernel_by_time": dom,
             "host": {"stage_batch_ms_mean": 1e3 * float(np.mean(t_parse))},
             "move_sum_on_fp64_matrix_core": eng.matrix_chain,
         }
+        if not a.no_large and world == 1:
+            del runs, eng
+            out["roofline_large"] = large_sweep(local_rank)
         if not a.no_cpu_baseline:
             _, times = cpu_baseline(contigs, batches, a.cpu_updates)
             t_med = float(np.median(times))

@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT="$ROOT/gpurun_out/prof_$W"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--workload $W --no-cpu-baseline ${BENCH_ARGS}"
+ARGS="--workload $W --no-cpu-baseline --no-large ${BENCH_ARGS}"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o "$W" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_trace.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o "$W" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o "$W" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_write.log" 2>&1
