@@ -200,3 +200,84 @@ def test_two_batches_before_one_sweep(in_tmp):
         assert np.array_equal(runs.contigs[n].coverage, c.coverage)
         assert np.array_equal(runs.contigs[n].scores, c.scores)
         assert np.array_equal(runs.contigs[n].entropy, c.entropy)
+
+
+def test_deep_coverage_and_long_reads_vs_oracle(in_tmp):
+    """Stress of the tile-binned ingest: ~100x coverage on a 130 kb contig (hundreds of segments
+    per tile, several descriptor stages), 20-kb reads crossing many tiles, 8 barcodes, zero-length
+    CIGAR runs.  Coverage, scores and masks must equal the oracle bit for bit."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.runs import BossRuns
+    from oracle.pipeline import OracleRuns
+    nb = 8
+    contigs = synth.make_reference([130_000, 101_000], seed=11, names=["deepA", "deepB"])
+    strs = [(n, synth.codes_to_str(c)) for n, c in contigs]
+    args = BossConfig()
+    args.general.name = "deep"
+    args.general.barcodes = ["barcode%02d" % (i + 1) for i in range(nb)]
+    runs = BossRuns(args)
+    runs.init(contigs=strs)
+    o = OracleRuns(strs, nbarcodes=nb)
+    for b in range(2):
+        batch = synth.make_batch(contigs, 1500, seed=300 + b, mean_len=9000.0, max_len=40000, nbarcodes=nb)
+        # sprinkle zero-length runs into some CIGARs: "0M", "0I", "0D" are legal no-ops
+        lines = batch["paf"].split("\n")
+        for i in range(0, len(lines), 7):
+            lines[i] = lines[i].replace("cg:Z:", "cg:Z:0M0D0I")
+        batch["paf"] = "\n".join(lines)
+        o.process_batch(batch["paf"], batch["seqs"], read_lengths=batch["read_lengths"], barcodes=batch["barcodes"])
+        runs.rl_dist.update(batch["read_lengths"])
+        runs.process_batch_paf(batch["paf"], batch["seqs"], barcodes=batch["barcodes"])
+        for n, oc in o.contigs.items():
+            pc = runs.contigs[n]
+            assert np.array_equal(pc.coverage, oc.coverage), (b, n)
+            assert np.array_equal(pc.scores, oc.scores), (b, n)
+            assert np.array_equal(pc.strat, oc.strat), (b, n)
+        assert runs.threshold == o.threshold
+    assert int(o.contigs["deepA"].coverage.sum(axis=(1, 2)).max()) >= 100    # ~100x over the 8 barcodes
+
+
+def test_full_size_ecoli_properties(in_tmp):
+    """BASELINE configs[1] at full size (4.64 Mb, 4000-read batches) through size-independent
+    properties: conservation of ingested bases, bucket sums = coverage sums, idempotence of an
+    update without new reads, masks only change inside switched-on buckets, state export /
+    import round trip."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.runs import BossRuns
+    contigs = synth.make_reference([synth.ECOLI_LEN], seed=1, names=["ecoli"])
+    args = BossConfig()
+    args.general.name = "full"
+    runs = BossRuns(args)
+    runs.write_masks = False
+    runs.init(contigs=[(n, synth.codes_to_str(c)) for n, c in contigs])
+    c = runs.contigs["ecoli"]
+    total = 0
+    for b in range(2):
+        batch = synth.make_batch(contigs, 4000, seed=900 + b, extras=True)
+        summ = runs.engine.stage_batch(batch["paf"], batch["seqs"])
+        total += summ["aligned"]
+        runs.engine.ingest_staged()
+        runs.rl_dist.update(batch["read_lengths"])
+        runs._account_reads(summ, len(batch["seqs"]))
+        runs.update_wrapper()
+    cov = c.coverage
+    assert int(cov.sum(dtype=np.uint64)) == total                         # every aligned base counted once
+    depth = cov.sum(axis=1, dtype=np.uint64)[:, 0]
+    bs = runs.engine.bucket_sums(c.index)[0]
+    assert np.array_equal(bs, depth[: (synth.ECOLI_LEN // 20000) * 20000].reshape(-1, 20000).sum(axis=1))
+    assert c.switched_on.all() and runs.threshold is not None            # mean depth ~10 > 5
+    sw = c.bucket_switches[:, 0]
+    strat1 = c.strat.copy()
+    off_rows = ~np.repeat(sw, 200)[: strat1.shape[0]]
+    assert strat1[off_rows].all()                                         # untouched rows keep the initial 1
+    assert 0 < strat1.mean() < 1
+    # an update without new reads leaves every mask and score unchanged (idempotence)
+    scores1 = c.scores
+    thr1 = runs.threshold
+    runs.update_wrapper()
+    assert runs.threshold == thr1 and np.array_equal(c.strat, strat1) and np.array_equal(c.scores, scores1)
+    # score values are the table's: zero-depth sites never looked up keep score0
+    never = (depth == 0) & (runs.engine.export(c.index, "state")[:, 0] & 4 == 0)
+    assert np.all(scores1[never, 0] == runs.scoring.score0[0])
