@@ -68,6 +68,7 @@ struct bossx_engine {
     uint32_t *d_tile_ref = nullptr;
     // pinned scratch
     void *h_pin = nullptr; size_t pin_cap = 0;
+    void *h_blob_pin = nullptr; size_t blob_pin_cap = 0;
     std::vector<int32_t> drop_thr_host;
     // timing
     bool timing = false;
@@ -182,10 +183,21 @@ SweepParams sweep_params(bossx_engine *h) {
 // marks `touched`, which the next sweep then reads.
 int flush_pending(bossx_engine *h) {
     if (h->pending_slot < 0) return BOSSX_OK;
-    const bossx_engine::Staged &st = h->slots[size_t(h->pending_slot)];
-    const ParsedBatch &pb = st.pb;
+    bossx_engine::Staged &st = h->slots[size_t(h->pending_slot)];
+    ParsedBatch &pb = st.pb;
     const uint32_t n = uint32_t(pb.tiles.size());
     hipLaunchKernelGGL(tile_ref_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, st.d_tilerefs, n, h->d_tile_ref, 0);
+    if (pb.tile_first_op.empty()) {            // emit-order tiling is only needed on this path
+        build_emit_tiles(pb);
+        if (pb.tile_first_op.size() > st.tiles_cap) {
+            if (st.d_tiles) HIPCHK(hipFree(st.d_tiles));
+            st.d_tiles = nullptr;
+            st.tiles_cap = pb.tile_first_op.size() * 9 / 8 + 64;
+            int rc = dev_alloc(h, &st.d_tiles, st.tiles_cap);
+            if (rc) return rc;
+        }
+        HIPCHK(hipMemcpy(st.d_tiles, pb.tile_first_op.data(), pb.tile_first_op.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     const uint32_t n_tiles = uint32_t((pb.total_emit + kEmitTile - 1) / kEmitTile);
     time_begin(h, BOSSX_K_INGEST);
     hipLaunchKernelGGL(ingest_scatter_kernel, dim3(n_tiles), dim3(256), 0, h->stream, st.d_ops, st.d_tiles,
@@ -255,6 +267,7 @@ void bossx_destroy(bossx_engine *h) {
     for (auto &st : h->slots) { if (st.d_ops) hipFree(st.d_ops); if (st.d_tiles) hipFree(st.d_tiles); if (st.d_blob) hipFree(st.d_blob); if (st.d_segs) hipFree(st.d_segs); if (st.d_tilerefs) hipFree(st.d_tilerefs); }
     if (h->d_tile_ref) hipFree(h->d_tile_ref);
     if (h->h_pin) hipHostFree(h->h_pin);
+    if (h->h_blob_pin) hipHostFree(h->h_blob_pin);
     for (int k = 0; k < BOSSX_K_COUNT; ++k) { if (h->ev0[k]) hipEventDestroy(h->ev0[k]); if (h->ev1[k]) hipEventDestroy(h->ev1[k]); }
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
@@ -457,12 +470,6 @@ int bossx_stage_batch(bossx_engine *h, const char *paf, size_t paf_len, const ch
         st.ops_cap = pb.ops.size() * 9 / 8 + 1024;
         if ((rc = dev_alloc(h, &st.d_ops, st.ops_cap))) return rc;
     }
-    if (pb.tile_first_op.size() > st.tiles_cap) {
-        if (st.d_tiles) HIPCHK(hipFree(st.d_tiles));
-        st.d_tiles = nullptr;
-        st.tiles_cap = pb.tile_first_op.size() * 9 / 8 + 64;
-        if ((rc = dev_alloc(h, &st.d_tiles, st.tiles_cap))) return rc;
-    }
     if (blob_bytes + 16 > st.blob_cap) {
         if (st.d_blob) HIPCHK(hipFree(st.d_blob));
         st.d_blob = nullptr;
@@ -485,13 +492,42 @@ int bossx_stage_batch(bossx_engine *h, const char *paf, size_t paf_len, const ch
         HIPCHK(hipMemcpyAsync(st.d_segs, pb.segs.data(), pb.segs.size() * sizeof(TileSeg), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(st.d_tilerefs, pb.tiles.data(), pb.tiles.size() * sizeof(TileRef), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(st.d_ops, pb.ops.data(), pb.ops.size() * sizeof(EmitOp), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(st.d_tiles, pb.tile_first_op.data(), pb.tile_first_op.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
         if (blob_bytes) HIPCHK(hipMemcpyAsync(st.d_blob, seqs, blob_bytes, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));   // inputs are borrowed for the call only
     }
     st.pb = std::move(pb);
     st.valid = true;
     return BOSSX_OK;
+}
+
+int bossx_stage_batch_ptrs(bossx_engine *h, const char *paf, size_t paf_len, const char *const *name_ptrs,
+                           const int64_t *name_lens, const char *const *seq_ptrs, const int64_t *seq_lens,
+                           const int32_t *barcodes, int32_t n_reads, int32_t min_len,
+                           bossx_batch_summary *summary, int32_t *n_rec, int64_t *aligned_bases) {
+    if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "stage_batch before finalize");
+    if (n_reads < 0 || (n_reads > 0 && (!name_ptrs || !name_lens || !seq_ptrs || !seq_lens))) return fail(h, BOSSX_E_INVALID, "bad batch arrays");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    std::vector<int64_t> name_off(size_t(n_reads) + 1, 0), seq_off(size_t(n_reads) + 1, 0);
+    for (int32_t i = 0; i < n_reads; ++i) {
+        name_off[size_t(i) + 1] = name_off[size_t(i)] + name_lens[i];
+        seq_off[size_t(i) + 1] = seq_off[size_t(i)] + seq_lens[i];
+    }
+    std::string names(size_t(name_off[size_t(n_reads)]), '\0');
+    for (int32_t i = 0; i < n_reads; ++i) memcpy(&names[size_t(name_off[size_t(i)])], name_ptrs[i], size_t(name_lens[i]));
+    // gather the sequences into pinned memory: one pass, and the H2D copy runs at full PCIe rate
+    const size_t blob_bytes = size_t(seq_off[size_t(n_reads)]);
+    HIPCHK(hipStreamSynchronize(h->stream));           // the pinned buffer may still feed a copy
+    if (blob_bytes + 64 > h->blob_pin_cap) {
+        if (h->h_blob_pin) HIPCHK(hipHostFree(h->h_blob_pin));
+        h->h_blob_pin = nullptr; h->blob_pin_cap = 0;
+        const size_t cap = (blob_bytes + 64) * 5 / 4;
+        HIPCHK(hipHostMalloc(&h->h_blob_pin, cap, hipHostMallocDefault));
+        h->blob_pin_cap = cap;
+    }
+    char *blob = static_cast<char *>(h->h_blob_pin);
+    for (int32_t i = 0; i < n_reads; ++i) memcpy(blob + seq_off[size_t(i)], seq_ptrs[i], size_t(seq_lens[i]));
+    return bossx_stage_batch(h, paf, paf_len, names.data(), name_off.data(), blob, seq_off.data(), barcodes, n_reads,
+                             min_len, summary, n_rec, aligned_bases);
 }
 
 int bossx_select_batch(bossx_engine *h, int32_t slot) {

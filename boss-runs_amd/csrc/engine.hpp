@@ -68,7 +68,7 @@ struct ParsedBatch {
     std::vector<EmitOp> ops;
     std::vector<TileSeg> segs;             // grouped by tile (counting sort)
     std::vector<TileRef> tiles;            // touched tiles, ascending
-    std::vector<uint32_t> tile_first_op;   // n_tiles + 1 entries
+    std::vector<uint32_t> tile_first_op;   // emit-order tiles (fallback scatter only; build_emit_tiles)
     uint64_t total_emit = 0;
     std::vector<uint64_t> emitted_per_contig;   // indexed by contig add order
     int32_t n_rec = 0;
@@ -83,6 +83,8 @@ struct ParseInput {
     int32_t min_len;
     int32_t nbarcodes;
 };
+
+void build_emit_tiles(ParsedBatch &pb);
 
 // Parses the PAF text, picks the best mapping per read and expands CIGARs into emit runs.
 // Returns BOSSX_OK or an error code with `err` filled.  Nothing is produced on error.

@@ -64,6 +64,13 @@ struct Group {
     int64_t key_q, key_dp;
 };
 
+struct CigarTable {
+    bool ok[256];
+    constexpr CigarTable() : ok() { for (const char *p = "MIDNSHP=XB"; *p; ++p) ok[static_cast<unsigned char>(*p)] = true; }
+    constexpr bool operator[](unsigned char c) const { return ok[c]; }
+};
+constexpr CigarTable kCigarOp{};
+
 }  // namespace
 
 int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs,
@@ -157,7 +164,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
 
     // ---- pass 2: chosen mappings -> emit runs ------------------------------------------------
     uint64_t cur_emit = 0;
-    out.tile_first_op.clear();
+    out.ops.reserve(in.paf_len / 3 + 16);
     std::vector<TileSeg> raw_segs;
     std::vector<uint32_t> raw_tile;
     int32_t n_rec = 0;
@@ -212,7 +219,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
                 return BOSSX_E_PARSE;
             }
             const char op = *cp++;
-            if (!strchr("MIDNSHP=XB", op)) {
+            if (!kCigarOp[static_cast<unsigned char>(op)]) {
                 err = "read '" + r.qname + "': unknown CIGAR op";
                 return BOSSX_E_PARSE;
             }
@@ -240,14 +247,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             e.qpos = del ? 0u : uint32_t(seq_b + q);
             e.meta = uint32_t((site >> 32) & 0xffu) | (uint32_t(bc) << 8) | (r.rev ? kOpRev : 0u) |
                      (del ? kOpDel : 0u);
-            const uint32_t op_idx = uint32_t(out.ops.size());
             out.ops.push_back(e);
-            // tiles whose first element falls inside this run
-            uint64_t t = (cur_emit + kEmitTile - 1) / kEmitTile;
-            for (; t * kEmitTile < cur_emit + uint64_t(len); ++t) {
-                if (out.tile_first_op.size() <= t) out.tile_first_op.resize(t + 1);
-                out.tile_first_op[t] = op_idx;
-            }
             cur_emit += uint64_t(len);
             ref_pos += len;
             if (!del) { consumed += len; q += qstep * len; }
@@ -310,10 +310,21 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
     }
     out.total_emit = cur_emit;
     out.n_rec = n_rec;
-    const size_t n_tiles = size_t((cur_emit + kEmitTile - 1) / kEmitTile);
-    out.tile_first_op.resize(n_tiles + 1);
-    out.tile_first_op[n_tiles] = out.ops.empty() ? 0u : uint32_t(out.ops.size() - 1);
     return BOSSX_OK;
+}
+
+// Emit-order tiling for the fallback scatter kernel: tile t -> the run that holds element
+// t * kEmitTile (built on demand; the normal path bins by sweep tile instead).
+void build_emit_tiles(ParsedBatch &pb) {
+    const size_t n_tiles = size_t((pb.total_emit + kEmitTile - 1) / kEmitTile);
+    pb.tile_first_op.assign(n_tiles + 1, 0);
+    size_t op = 0;
+    for (size_t t = 0; t < n_tiles; ++t) {
+        const uint64_t e = uint64_t(t) * kEmitTile;
+        while (op + 1 < pb.ops.size() && pb.ops[op + 1].emit_start <= e) ++op;
+        pb.tile_first_op[t] = uint32_t(op);
+    }
+    pb.tile_first_op[n_tiles] = pb.ops.empty() ? 0u : uint32_t(pb.ops.size() - 1);
 }
 
 }  // namespace bossx

@@ -83,9 +83,37 @@ class Engine:
         blob = "".join(seqs.values()).encode("ascii")
         return names, name_off, blob, seq_off, ids
 
+    _as_utf8 = None
+
+    @classmethod
+    def _str_pointers(cls, strings):
+        """Pointers/lengths of the (ASCII) buffers inside Python str objects — no copies; the
+        caller keeps the strings alive for the duration of the C call."""
+        if cls._as_utf8 is None:
+            api = C.pythonapi.PyUnicode_AsUTF8AndSize
+            api.restype = C.c_void_p
+            api.argtypes = [C.py_object, C.POINTER(C.c_ssize_t)]
+            cls._as_utf8 = api
+        api = cls._as_utf8
+        n = len(strings)
+        ptrs = np.empty(max(n, 1), dtype=np.uint64)
+        lens = np.empty(max(n, 1), dtype=np.int64)
+        sz = C.c_ssize_t()
+        ref = C.byref(sz)
+        for i, s in enumerate(strings):
+            ptrs[i] = api(s, ref)
+            lens[i] = sz.value
+        return ptrs, lens
+
     def stage_batch(self, paf_text, seqs, barcodes=None, min_len=200, ingest=False, packed=None):
         """Parse + upload one batch.  Returns dict of per-mapping summary arrays."""
-        names, name_off, blob, seq_off, ids = packed if packed is not None else self.pack_reads(seqs)
+        if packed is None and not ingest:
+            return self._stage_batch_ptrs(paf_text, seqs, barcodes, min_len)
+        if packed is None and ingest:
+            out = self._stage_batch_ptrs(paf_text, seqs, barcodes, min_len)
+            self.ingest_staged()
+            return out
+        names, name_off, blob, seq_off, ids = packed
         n = len(ids)
         paf = paf_text.encode() if isinstance(paf_text, str) else bytes(paf_text)
         bc = None
@@ -102,6 +130,33 @@ class Engine:
         self._ck(fn(self.h, paf, len(paf), names, name_off.ctypes.data, blob, seq_off.ctypes.data,
                     None if bc is None else bc.ctypes.data, n, int(min_len), C.byref(summ),
                     C.byref(n_rec), C.byref(aligned)))
+        k = n_rec.value
+        out = {key: v[:k] for key, v in s.items()}
+        out["aligned"] = aligned.value
+        out["ids"] = ids
+        return out
+
+    def _stage_batch_ptrs(self, paf_text, seqs, barcodes, min_len):
+        ids = list(seqs.keys())
+        vals = list(seqs.values())
+        n = len(ids)
+        nptr, nlen = self._str_pointers(ids)
+        sptr, slen = self._str_pointers(vals)
+        paf = paf_text.encode() if isinstance(paf_text, str) else bytes(paf_text)
+        bc = None
+        if barcodes is not None:
+            bc = np.ascontiguousarray([barcodes[i] for i in ids] if isinstance(barcodes, dict) else barcodes,
+                                      dtype=np.int32)
+        s = dict(read_idx=np.zeros(max(n, 1), np.int32), contig_idx=np.zeros(max(n, 1), np.int32),
+                 rev=np.zeros(max(n, 1), np.uint8), tstart=np.zeros(max(n, 1), np.int64),
+                 tend=np.zeros(max(n, 1), np.int64), qlen=np.zeros(max(n, 1), np.int64))
+        summ = _lib.BatchSummary(*[s[k].ctypes.data for k in ("read_idx", "contig_idx", "rev", "tstart", "tend", "qlen")])
+        n_rec = C.c_int32(0)
+        aligned = C.c_int64(0)
+        self._ck(self.lib.bossx_stage_batch_ptrs(self.h, paf, len(paf), nptr.ctypes.data, nlen.ctypes.data,
+                                                 sptr.ctypes.data, slen.ctypes.data,
+                                                 None if bc is None else bc.ctypes.data, n, int(min_len),
+                                                 C.byref(summ), C.byref(n_rec), C.byref(aligned)))
         k = n_rec.value
         out = {key: v[:k] for key, v in s.items()}
         out["aligned"] = aligned.value

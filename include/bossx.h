@@ -106,6 +106,14 @@ int bossx_stage_batch(bossx_engine *h, const char *paf, size_t paf_len,
                       const int32_t *barcodes, int32_t n_reads, int32_t min_len,
                       bossx_batch_summary *summary, int32_t *n_rec,
                       int64_t *aligned_bases);
+/* Same as bossx_stage_batch for callers that hold the reads as separate strings (a Python
+ * dict of str): one pointer + length per read name and per read sequence; the library gathers
+ * the sequences into its own pinned staging buffer (no concatenation on the caller's side).    */
+int bossx_stage_batch_ptrs(bossx_engine *h, const char *paf, size_t paf_len,
+                           const char *const *name_ptrs, const int64_t *name_lens,
+                           const char *const *seq_ptrs, const int64_t *seq_lens,
+                           const int32_t *barcodes, int32_t n_reads, int32_t min_len,
+                           bossx_batch_summary *summary, int32_t *n_rec, int64_t *aligned_bases);
 int bossx_ingest_staged(bossx_engine *h);
 /* Staged batches live in numbered slots (default 0) so several batches can be resident in HBM
  * at once; selects the slot the next stage/ingest call uses.                                */
