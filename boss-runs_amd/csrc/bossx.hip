@@ -668,8 +668,10 @@ int fill_chain_params(bossx_engine *h, const int32_t *windows, const double *mul
                                                   std::to_string(c.T + 1) + ", inclusive");
     }
     int32_t ring = 256;
-    while (ring < wmax + 128) ring <<= 1;
-    if (size_t(ring) * 8 > 128 * 1024) return fail(h, BOSSX_E_WINDOW, "read-length window exceeds the LDS ring");
+    while (ring < wmax + 2 * kChainChunk) ring <<= 1;
+    // static LDS of the chain kernel (difference / sum tiles) + the ring must fit 160 KiB
+    if (size_t(ring) * 8 + 2 * 2 * 16 * size_t(kChainPad) * 8 + 1024 > 160 * 1024)
+        return fail(h, BOSSX_E_WINDOW, "read-length window exceeds the LDS ring (reads longer than ~790 kb in the 95th percentile)");
     P.ds = h->d_ds; P.benefit = h->d_benefit; P.ctrl = h->d_ctrl; P.ct = table_of(h);
     P.B = h->B; P.nb = h->nb; P.ring = ring; P.gate = 0;
     P.probe = getenv("BOSSX_CHAIN_PROBE") ? reinterpret_cast<long long *>(h->d_stats + kStatWords + 8) : nullptr;
