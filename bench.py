@@ -77,7 +77,9 @@ def make_runs(workload, rank, world, device):
                 allc.append(("%s_r%d" % (n, r), L))
         mine_d = {n: synth.codes_to_str(c) for n, c in mine}
         runs = DistributedBossRuns(args)
-        runs.init(contigs=[(n, mine_d.get(n, L)) for n, L in allc], sharded_reads=True)
+        # masks stay on their owner rank in the timed loop (the all-gather to rank 0 is only
+        # needed when boss.npz is written; halo rows are still exchanged every update)
+        runs.init(contigs=[(n, mine_d.get(n, L)) for n, L in allc], sharded_reads=True, gather_masks=False)
         assert all(not runs.contigs[n].remote for n in mine_d), "partition must give each rank its own contigs"
     runs.write_masks = False                  # npz write is reported separately
     runs.log_fractions = False
@@ -184,7 +186,9 @@ def main():
 
     def step(i):
         eng.ingest_staged(slot=i)
-        if not distributed:      # sweep starts now; the host bookkeeping below overlaps with it
+        if distributed:          # sweep starts now; the exchange / host bookkeeping overlap with it
+            runs.begin_update()
+        else:
             eng.update_begin(runs.args.optional.bucket_threshold)
         if distributed:
             runs.account_batch(summaries[i], batches[i]["read_lengths"], len(batches[i]["seqs"]))

@@ -82,6 +82,8 @@ PROTOTYPES = {
     "bossx_apply_threshold": (C.c_int, [C.c_void_p, C.c_double]),
     "bossx_update_begin": (C.c_int, [C.c_void_p, C.c_double]),
     "bossx_update_benefit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bossx_arm": (C.c_int, [C.c_void_p]),
+    "bossx_get_max": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "bossx_update": (C.c_int, [C.c_void_p, C.POINTER(UpdateParams), C.c_void_p, C.c_void_p,
                                C.POINTER(UpdateResult), C.c_void_p, C.c_void_p, C.c_void_p]),
     "bossx_strat_bytes": (C.c_int64, [C.c_void_p]),

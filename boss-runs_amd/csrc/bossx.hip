@@ -828,6 +828,25 @@ int bossx_update_begin(bossx_engine *h, double bucket_threshold) {
     return BOSSX_OK;
 }
 
+int bossx_arm(bossx_engine *h) {
+    if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "bad arm call");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int32_t one = 1;
+    HIPCHK(hipMemcpyAsync(&h->d_ctrl->any_on, &one, sizeof(one), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return BOSSX_OK;
+}
+
+int bossx_get_max(bossx_engine *h, double *max_benefit) {
+    if (!h || !h->finalized || !max_benefit) return fail(h, BOSSX_E_INVALID, "bad get_max call");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    unsigned long long bits = 0;
+    HIPCHK(hipMemcpyAsync(&bits, &h->d_ctrl->max_bits, sizeof(bits), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    memcpy(max_benefit, &bits, sizeof(double));
+    return BOSSX_OK;
+}
+
 int bossx_update_benefit(bossx_engine *h, const int32_t *windows, const double *mult) {
     if (!h || !h->finalized || !windows || !mult) return fail(h, BOSSX_E_INVALID, "bad update_benefit call");
     HIPCHK(hipSetDevice(h->cfg.device));

@@ -221,6 +221,14 @@ class Engine:
         self._ck(self.lib.bossx_update_benefit(self.h, w.ctypes.data, m.ctypes.data))
         self._benefit_done = tuple(w.tolist())
 
+    def arm(self):
+        self._ck(self.lib.bossx_arm(self.h))
+
+    def get_max(self):
+        mx = C.c_double(0.0)
+        self._ck(self.lib.bossx_get_max(self.h, C.byref(mx)))
+        return mx.value
+
     def update(self, bucket_threshold, windows=None, mult=None, tc=0.0, fhat_c=None, target_rs=0,
                want_stats=False):
         """bossx_update: one fused decision update.  Without `fhat_c` only the sweep and the

@@ -142,6 +142,7 @@ class DistributedBossRuns(BossRuns):
         super().init(contigs=contigs, engine=engine, is_local=lambda name, k: self.owner[k] == rank)
         self.local_filt = {n: c for n, c in self.contigs_filt.items() if not c.remote}
         self.armed = False
+        self._begun = False
         self.filt_names = list(self.contigs_filt.keys())
 
     # ---- batch -----------------------------------------------------------------------------
@@ -154,6 +155,7 @@ class DistributedBossRuns(BossRuns):
         summ = self.engine.ingest_paf(paf_text, new_reads, barcodes=barcodes, min_len=min_len)
         if read_lengths is None:
             read_lengths = np.array([len(s) for s in new_reads.values()], dtype=np.int64)
+        self.begin_update()
         self.account_batch(summ, read_lengths, len(new_reads))
         self.update_wrapper()
 
@@ -188,20 +190,51 @@ class DistributedBossRuns(BossRuns):
         self.read_starts.count_starts(self.contig_names, ci, summ["rev"], summ["tstart"], summ["tend"])
 
     # ---- update ----------------------------------------------------------------------------
+    def begin_update(self):
+        """Start the sweep (with the pending batch's increments) and the device-side bucket
+        switches now, so that `account_batch`'s exchange and the host bookkeeping overlap with
+        them.  Optional: `update_wrapper` does it if it was not called."""
+        if hasattr(self.engine, "update_begin") and not self._begun:
+            self.engine.update_begin(self.args.optional.bucket_threshold)
+            self._begun = True
+
     def update_wrapper(self) -> None:
         eng, comm = self.engine, self.comm
-        eng.sweep()
+        device_side = hasattr(eng, "update_begin")        # the HIP engine; test doubles lack it
         thr_b = self.args.optional.bucket_threshold
-        for cont in self.local_filt.values():
-            cont.check_buckets(eng.bucket_sums(cont.index), threshold=thr_b)
-        if not self.armed:
-            local_on = any(any(c.switched_on) for c in self.local_filt.values())
-            self.armed = bool(comm.allreduce(np.array([int(local_on)], dtype=np.int64), "max")[0])
+        if device_side:
+            self.begin_update()
+            self._begun = False
+            windows = None
+            if self.armed and hasattr(self.rl_dist, "time_cost"):
+                windows = np.concatenate(([400 // 100], self.rl_dist.approx_ccl // 100)).astype(np.int32)
+                eng.update_benefit(windows, MULT)          # chain runs while f-hat is built
             if not self.armed:
-                return
-        fhat_c, target_rs = self.read_starts.fhat_compact()
-        windows = np.concatenate(([400 // 100], self.rl_dist.approx_ccl // 100)).astype(np.int32)
-        local_max = eng.benefit(windows, MULT)
+                res = eng.update(thr_b)                    # waits for sweep + buckets: local flags
+                for cont in self.local_filt.values():
+                    if res["contig_on"][cont.index]:
+                        cont.switched_on[:] = True
+                self.armed = bool(comm.allreduce(np.array([int(res["any_on"])], dtype=np.int64), "max")[0])
+                if not self.armed:
+                    return
+                eng.arm()                                  # the decision is global (core.py:111)
+            fhat_c, target_rs = self.read_starts.fhat_compact()
+            if windows is None:
+                windows = np.concatenate(([400 // 100], self.rl_dist.approx_ccl // 100)).astype(np.int32)
+                eng.update_benefit(windows, MULT)
+            local_max = eng.get_max()
+        else:
+            eng.sweep()
+            for cont in self.local_filt.values():
+                cont.check_buckets(eng.bucket_sums(cont.index), threshold=thr_b)
+            if not self.armed:
+                local_on = any(any(c.switched_on) for c in self.local_filt.values())
+                self.armed = bool(comm.allreduce(np.array([int(local_on)], dtype=np.int64), "max")[0])
+                if not self.armed:
+                    return
+            fhat_c, target_rs = self.read_starts.fhat_compact()
+            windows = np.concatenate(([400 // 100], self.rl_dist.approx_ccl // 100)).astype(np.int32)
+            local_max = eng.benefit(windows, MULT)
         normaliser = float(comm.allreduce(np.array([local_max], dtype=np.float64), "max")[0])
         target = self.ref.n_sites // 100
         counts, fg, ub = eng.histogram(normaliser, fhat_c, target_rs, target)
@@ -209,7 +242,9 @@ class DistributedBossRuns(BossRuns):
         packed = np.concatenate((packed, np.concatenate(([0], fx_to_limbs(ub)))[np.newaxis]))
         packed = comm.allreduce(packed, "sum")
         counts = packed[:-1, 0]
-        fgrid = limbs_to_float(packed[:-1, 1:])
+        fgrid = np.zeros(counts.shape[0], dtype=np.float64)
+        occ = np.nonzero(counts)[0]                      # only occupied bins need the big-int conversion
+        fgrid[occ] = limbs_to_float(packed[occ, 1:])
         ubar0 = float(limbs_to_float(packed[-1, 1:]))
         threshold, size, uniq = choose_threshold(normaliser, counts, fgrid, ubar0, self.rl_dist.time_cost)
         self.threshold = threshold

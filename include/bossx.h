@@ -206,6 +206,12 @@ int bossx_update_begin(bossx_engine *h, double bucket_threshold);
 /* Optional second part: enqueue calc_smu/calc_u (gated on the device-side "armed" flag) as soon
  * as the read-length windows are known; asynchronous.                                          */
 int bossx_update_benefit(bossx_engine *h, const int32_t *windows, const double *mult);
+/* Multi-GPU helpers.  bossx_arm sets the device-side "some strategy is switched on" flag (the
+ * decision is global: any contig on any rank, core.py:111), so gated stages run on ranks whose
+ * own contigs are still below the bucket threshold.  bossx_get_max waits for the chain and
+ * returns this device's max(additional_benefit) (0 if the gated chain did not run).           */
+int bossx_arm(bossx_engine *h);
+int bossx_get_max(bossx_engine *h, double *max_benefit);
 int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all,
                  uint8_t *contig_on, bossx_update_result *res, int64_t *counts,
                  uint64_t *fgrid_fx, uint64_t *ubar0_fx);
