@@ -530,6 +530,25 @@ int bossx_stage_batch_ptrs(bossx_engine *h, const char *paf, size_t paf_len, con
                              min_len, summary, n_rec, aligned_bases);
 }
 
+int bossx_paf_summary(bossx_engine *h, const char *paf, size_t paf_len, const char *const *name_ptrs,
+                      const int64_t *name_lens, int32_t n_reads, int32_t min_len,
+                      bossx_batch_summary *summary, int32_t *n_rec) {
+    if (!h || !h->finalized || !summary) return fail(h, BOSSX_E_INVALID, "bad paf_summary call");
+    if (n_reads < 0 || (n_reads > 0 && (!name_ptrs || !name_lens))) return fail(h, BOSSX_E_INVALID, "bad batch arrays");
+    std::vector<int64_t> name_off(size_t(n_reads) + 1, 0), seq_off(size_t(n_reads) + 1, 0);
+    for (int32_t i = 0; i < n_reads; ++i) name_off[size_t(i) + 1] = name_off[size_t(i)] + name_lens[i];
+    std::string names(size_t(name_off[size_t(n_reads)]), '\0');
+    for (int32_t i = 0; i < n_reads; ++i) memcpy(&names[size_t(name_off[size_t(i)])], name_ptrs[i], size_t(name_lens[i]));
+    ParseInput in{paf ? paf : "", paf ? paf_len : 0, names.data(), name_off.data(), seq_off.data(), nullptr, n_reads, min_len, h->nb};
+    in.summary_only = true;
+    ParsedBatch pb;
+    std::string err;
+    int rc = parse_paf_batch(in, h->contigs, h->index, summary, pb, err);
+    if (rc) return fail(h, rc, err);
+    if (n_rec) *n_rec = pb.n_rec;
+    return BOSSX_OK;
+}
+
 int bossx_select_batch(bossx_engine *h, int32_t slot) {
     if (!h || slot < 0 || slot >= 256) return fail(h, BOSSX_E_INVALID, "batch slot must be in [0, 256)");
     if (size_t(slot) >= h->slots.size()) h->slots.resize(size_t(slot) + 1);
@@ -1088,6 +1107,26 @@ int bossx_import(bossx_engine *h, int32_t contig, int32_t which, const void *src
             if (src_bytes != size_t(L)) return fail(h, BOSSX_E_INVALID, "import size mismatch");
             HIPCHK(hipMemcpy(h->d_touched + c.site_off, src, size_t(L), hipMemcpyHostToDevice));
             h->touched_dirty = true;
+            break;
+        }
+        case 7: {
+            if (src_bytes != size_t(nb * c.n_buckets)) return fail(h, BOSSX_E_INVALID, "import size mismatch");
+            bool any = false;
+            for (size_t i = 0; i < src_bytes; ++i) any = any || static_cast<const uint8_t *>(src)[i];
+            for (int64_t b = 0; b < nb; ++b)
+                HIPCHK(hipMemcpy(h->d_bucket_on + b * h->NBK + c.bucket_off, static_cast<const uint8_t *>(src) + b * c.n_buckets,
+                                 size_t(c.n_buckets), hipMemcpyHostToDevice));
+            if (any) {
+                const uint8_t one = 1;
+                const int32_t one32 = 1;
+                HIPCHK(hipMemcpy(h->d_contig_on + c.filt_index, &one, 1, hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(&h->d_ctrl->any_on, &one32, sizeof(one32), hipMemcpyHostToDevice));
+            }
+            break;
+        }
+        case 9: {
+            if (src_bytes != size_t(c.T * 2 * nb)) return fail(h, BOSSX_E_INVALID, "import size mismatch");
+            HIPCHK(hipMemcpy(h->d_strat + c.strat_off, src, src_bytes, hipMemcpyHostToDevice));
             break;
         }
         default:

@@ -82,6 +82,7 @@ struct ParseInput {
     int32_t n_reads;
     int32_t min_len;
     int32_t nbarcodes;
+    bool summary_only = false;   // choose mappings and fill the summary, no CIGAR walk
 };
 
 void build_emit_tiles(ParsedBatch &pb);

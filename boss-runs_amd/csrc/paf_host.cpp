@@ -188,6 +188,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             summary->qlen[n_rec] = r.qlen;
         }
         ++n_rec;
+        if (in.summary_only) continue;
         if (!r.has_cg) {
             err = "read '" + r.qname + "': mapping without cg tag";   // assert rec.cigar is not None
             return BOSSX_E_PARSE;

@@ -163,6 +163,24 @@ class Engine:
         out["ids"] = ids
         return out
 
+    def paf_summary(self, paf_text, read_ids, min_len=1):
+        """Mapping choice only (filters + best mapper): per-mapping summary arrays, nothing is
+        staged.  `read_ids`: iterable of read names present in the batch."""
+        ids = list(read_ids)
+        n = len(ids)
+        nptr, nlen = self._str_pointers(ids)
+        paf = paf_text.encode() if isinstance(paf_text, str) else bytes(paf_text)
+        s = dict(read_idx=np.zeros(max(n, 1), np.int32), contig_idx=np.zeros(max(n, 1), np.int32),
+                 rev=np.zeros(max(n, 1), np.uint8), tstart=np.zeros(max(n, 1), np.int64),
+                 tend=np.zeros(max(n, 1), np.int64), qlen=np.zeros(max(n, 1), np.int64))
+        summ = _lib.BatchSummary(*[s[k].ctypes.data for k in ("read_idx", "contig_idx", "rev", "tstart", "tend", "qlen")])
+        n_rec = C.c_int32(0)
+        self._ck(self.lib.bossx_paf_summary(self.h, paf, len(paf), nptr.ctypes.data, nlen.ctypes.data, n,
+                                            int(min_len), C.byref(summ), C.byref(n_rec)))
+        out = {key: v[:n_rec.value] for key, v in s.items()}
+        out["ids"] = ids
+        return out
+
     def ingest_paf(self, paf_text, seqs, barcodes=None, min_len=200):
         return self.stage_batch(paf_text, seqs, barcodes, min_len, ingest=True)
 
@@ -351,9 +369,14 @@ class Engine:
             raw = np.ascontiguousarray(np.asarray(arr, dtype=np.uint8).T)
         elif which == "touched":
             raw = np.ascontiguousarray(arr, dtype=np.uint8)
+        elif which == "bucket_switches":
+            raw = np.ascontiguousarray(np.asarray(arr, dtype=np.uint8).T)
+        elif which == "strat":
+            raw = np.ascontiguousarray(arr, dtype=np.uint8)
         else:
             raise ValueError(which)
-        self._ck(self.lib.bossx_import(self.h, contig, EXPORT[which], raw.ctypes.data, raw.nbytes))
+        code = 9 if which == "strat" else EXPORT[which]
+        self._ck(self.lib.bossx_import(self.h, contig, code, raw.ctypes.data, raw.nbytes))
 
     def preload_coverage(self, depth, seed=1):
         self._ck(self.lib.bossx_preload_coverage(self.h, float(depth), int(seed)))

@@ -241,3 +241,50 @@ class BossRuns(Boss):
             self._write_contig_strategies(contig_strats=self.ref.get_strategy_dict())
 
     update_strategy = update_wrapper      # name used by BASELINE.json's north_star
+
+    # ---- checkpoint / resume (absent in the reference: all its state lives in memory)
+    def save_state(self, path) -> None:
+        """Everything the next update depends on, as one .npz: per-contig coverage, site state,
+        entropy, bucket switches and masks (exported from the device), read-start counts, the
+        read-length histogram and the counters."""
+        d = dict(batch=np.array(self.batch), total_reads=np.array(self.total_reads),
+                 threshold=np.array(np.nan if self.threshold is None else self.threshold),
+                 read_lengths=self.rl_dist.read_lengths, rl_hi=np.array(getattr(self.rl_dist, "_hi", 0)),
+                 read_counts=np.array([self.read_counts[n] for n in self.contig_names], dtype=np.int64),
+                 contig_names=np.array(self.contig_names), nbarcodes=np.array(self.nbarcodes))
+        for n, c in self.contigs_filt.items():
+            d["cov_" + n] = c.coverage
+            d["state_" + n] = self.engine.export(c.index, "state")
+            if self.args.gpu.track_entropy:
+                d["ent_" + n] = c.entropy
+            d["buckets_" + n] = c.bucket_switches
+            d["strat_" + n] = np.ascontiguousarray(c.strat)
+            d["on_" + n] = c.switched_on
+            d["starts_" + n] = self.read_starts.read_starts[n]
+        np.savez_compressed(path, **d)
+
+    def load_state(self, path) -> None:
+        """Inverse of save_state on a freshly `init()`-ed object with the same reference."""
+        z = np.load(path)
+        if list(z["contig_names"]) != self.contig_names or int(z["nbarcodes"]) != self.nbarcodes:
+            raise ValueError("checkpoint does not match this reference / barcode set")
+        self.batch = int(z["batch"])
+        self.total_reads = int(z["total_reads"])
+        thr = float(z["threshold"])
+        self.threshold = None if np.isnan(thr) else thr
+        for n, v in zip(self.contig_names, z["read_counts"]):
+            self.read_counts[n] = int(v)
+        self.rl_dist.read_lengths[:] = z["read_lengths"]
+        self.rl_dist._hi = int(z["rl_hi"])
+        self.rl_dist.update(np.zeros(0, dtype=np.int64))          # recompute lam / approx_ccl / time_cost
+        for n, c in self.contigs_filt.items():
+            self.engine.import_state(c.index, "coverage", z["cov_" + n])
+            self.engine.import_state(c.index, "state", z["state_" + n])
+            if self.args.gpu.track_entropy and "ent_" + n in z.files:
+                self.engine.import_state(c.index, "entropy", z["ent_" + n])
+            self.engine.import_state(c.index, "bucket_switches", z["buckets_" + n])
+            self.engine.import_state(c.index, "strat", z["strat_" + n])
+            c.strat = z["strat_" + n].astype(bool)
+            c.switched_on[:] = z["on_" + n]
+            self.read_starts.read_starts[n][:] = z["starts_" + n]
+

@@ -115,6 +115,12 @@ int bossx_stage_batch_ptrs(bossx_engine *h, const char *paf, size_t paf_len,
                            const int32_t *barcodes, int32_t n_reads, int32_t min_len,
                            bossx_batch_summary *summary, int32_t *n_rec, int64_t *aligned_bases);
 int bossx_ingest_staged(bossx_engine *h);
+/* Mapping choice only: Paf.parse_PAF filters + choose_best_mapper per read, summary arrays as
+ * above, nothing staged or ingested.  This is what the simulation's decision step needs from
+ * the truncated-read PAF (runs/simulation.py:63-75).  Reads are identified by name only.     */
+int bossx_paf_summary(bossx_engine *h, const char *paf, size_t paf_len,
+                      const char *const *name_ptrs, const int64_t *name_lens, int32_t n_reads,
+                      int32_t min_len, bossx_batch_summary *summary, int32_t *n_rec);
 /* Staged batches live in numbered slots (default 0) so several batches can be resident in HBM
  * at once; selects the slot the next stage/ingest call uses.                                */
 int bossx_select_batch(bossx_engine *h, int32_t slot);
@@ -241,7 +247,8 @@ int32_t bossx_matrix_chain(const bossx_engine *h);
  *   6 touched    uint8[L]     (change_mask rows of the pending batch)
  *   7 bucket switches uint8[nb][L//20000+1] (export only)
  *   8 benefit tail float64[nb][2][min(L//100+1, n_filt)] (export only; multi-GPU halo rows)
- * bossx_import accepts 0, 2, 5, 6.                                                            */
+ *   9 strat      uint8 [L//100][2][nb] (Contig.strat)
+ * bossx_import accepts 0, 2, 5, 6, 7 (layout [nb][n_buckets]) and 9.                                                            */
 int bossx_export(bossx_engine *h, int32_t contig, int32_t which, void *dst, size_t dst_bytes);
 int bossx_import(bossx_engine *h, int32_t contig, int32_t which, const void *src, size_t src_bytes);
 

@@ -281,3 +281,55 @@ def test_full_size_ecoli_properties(in_tmp):
     # score values are the table's: zero-depth sites never looked up keep score0
     never = (depth == 0) & (runs.engine.export(c.index, "state")[:, 0] & 4 == 0)
     assert np.all(scores1[never, 0] == runs.scoring.score0[0])
+
+
+def test_checkpoint_resume(in_tmp):
+    """save_state / load_state: a resumed run continues bit-identically."""
+    contigs = e2e_reference()
+    a = _product(2, 2, in_tmp)
+    for b in range(3):
+        batch = e2e_batch(contigs, b, 2)
+        a.rl_dist.update(batch["read_lengths"])
+        a.process_batch_paf(batch["paf"], batch["seqs"], barcodes=batch["barcodes"])
+    a.save_state(str(in_tmp / "ckpt.npz"))
+    r = _product(2, 2, in_tmp)
+    r.load_state(str(in_tmp / "ckpt.npz"))
+    assert r.threshold == a.threshold and np.array_equal(r.rl_dist.approx_ccl, a.rl_dist.approx_ccl)
+    for b in range(3, 5):
+        batch = e2e_batch(contigs, b, 2)
+        for x in (a, r):
+            x.rl_dist.update(batch["read_lengths"])
+            x.process_batch_paf(batch["paf"], batch["seqs"], barcodes=batch["barcodes"])
+        assert r.threshold == a.threshold
+        for n, c in a.contigs_filt.items():
+            assert np.array_equal(r.contigs[n].strat, c.strat), (b, n)
+            assert np.array_equal(r.contigs[n].coverage, c.coverage)
+            assert np.array_equal(r.contigs[n].scores, c.scores)
+            assert np.array_equal(r.contigs[n].entropy, c.entropy)
+            assert np.array_equal(r.contigs[n].bucket_switches, c.bucket_switches)
+
+
+def test_simulation_decisions(in_tmp):
+    """The vectorised decision step equals the reference's per-read loop
+    (runs/simulation.py:63-99) restated with the oracle's PAF parser."""
+    from oracle.pafcigar import parse_paf, best_mapper
+    from boss_runs_amd.simulation import make_decisions
+    runs = _product(1, 2, in_tmp)
+    contigs = e2e_reference()
+    for b in range(3):
+        batch = e2e_batch(contigs, b, 2)
+        runs.rl_dist.update(batch["read_lengths"])
+        runs.process_batch_paf(batch["paf"], batch["seqs"], barcodes=batch["barcodes"])
+    assert 0 < runs.contigs["ctgB"].strat.mean() < 1
+    batch = e2e_batch(contigs, 7, 2)
+    got, _ = make_decisions(runs, batch["paf"], list(batch["seqs"].keys()), barcodes=batch["barcodes"])
+    want = {}
+    for rid, recs in parse_paf(batch["paf"], min_len=1).items():
+        rec = best_mapper(recs)
+        start = rec.tend - 1 if rec.rev else rec.tstart
+        try:
+            c = runs.contigs_filt[rec.tname]
+            want[rid] = bool(c.strat[start // 100, rec.rev, batch["barcodes"][rid]])
+        except (KeyError, IndexError):
+            want[rid] = False
+    assert got == want and any(want.values()) and not all(want.values())
