@@ -1,0 +1,120 @@
+"""Host-side product logic on the CPU (no GPU needed): the score table builder, the
+read-length / read-start distributions, the threshold choice from binned statistics and the
+composition ranking — against the golden vectors and the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from scenarios import GOLDEN, e2e_batch, e2e_contig_strings, e2e_reference
+
+from boss_runs_amd.readlengthdist import ReadlengthDist
+from boss_runs_amd.readstartdist import ReadStartDist
+from boss_runs_amd.runs import choose_threshold, fx_to_float, FX_SHIFT
+from boss_runs_amd.scoring import SiteScoring, all_compositions, composition_rank, NCOMP
+
+
+def test_reference_known_answers_product_scoring():
+    # /root/reference/tests/base/test_runs_sequences.py:113-126 through the product's builder
+    m = SiteScoring(1)
+    assert np.isclose(m.score0, 0.04969294) and np.isclose(m.ent0, 0.09302521)
+    sc, en = m.tables()
+    assert sc.shape == (NCOMP, 4) and en.shape == (NCOMP, 4)
+    r = composition_rank(np.array([[28, 0, 0, 0, 0], [2, 0, 0, 0, 0]]))
+    assert np.isclose(sc[r[0], 3], 3.834200141940696e-44) and np.isclose(en[r[0], 3], 3.834200141940696e-44)
+    assert np.isclose(sc[r[1], 3], 0.17253973305650225) and np.isclose(en[r[1], 3], 0.22957118271635163)
+    with pytest.raises(ValueError):
+        SiteScoring(3)
+
+
+def test_composition_rank_is_a_bijection():
+    pats = all_compositions()
+    assert pats.shape == (NCOMP, 5) and int(pats.sum(axis=1).max()) == 29
+    assert np.array_equal(composition_rank(pats), np.arange(NCOMP))
+    assert composition_rank(np.array([0, 0, 0, 0, 0])) == 0 and composition_rank(np.array([29, 0, 0, 0, 0])) == NCOMP - 1
+
+
+@pytest.mark.parametrize("ploidy", [1, 2])
+def test_product_table_vs_golden(ploidy):
+    g = np.load(os.path.join(GOLDEN, "g_tables.npz"))
+    m = SiteScoring(ploidy)
+    assert np.array_equal(g["phi_p%d" % ploidy], m.phi) and np.array_equal(g["priors_p%d" % ploidy], m.priors)
+    sc, en = m.tables()
+    pats = g["patterns"]
+    r = composition_rank(pats)
+    # numpy's SIMD log/pow may differ by ulps between CPU generations: 1e-9 relative
+    assert np.allclose(sc[r].T, g["score_p%d" % ploidy], rtol=1e-9, atol=1e-30)
+    assert np.allclose(en[r].T, g["entropy_p%d" % ploidy], rtol=1e-12, atol=0)
+    # and bit-identical to the oracle on this host
+    from oracle.model import SiteModel
+    e2, s2 = SiteModel(ploidy).entropy_and_score(pats)
+    assert np.array_equal(sc[r].T, s2) and np.array_equal(en[r].T, e2)
+
+
+def test_product_readlengthdist_vs_golden():
+    g = np.load(os.path.join(GOLDEN, "g_dists.npz"))
+    r = ReadlengthDist()
+    assert np.array_equal(r.approx_ccl, g["default_approx_ccl"])
+    r.update({'a': 1, 'b': 2, 'c': 3})                       # test_readlengthdist.py:21-32
+    assert int(r.lam) == 6000 and not hasattr(r, 'longest_read') and not hasattr(r, 'time_cost')
+    for k in range(3):
+        r.update({"x%d" % i: int(v) for i, v in enumerate(g["lens%d" % k])})
+        assert np.array_equal(r.approx_ccl, g["approx_ccl%d" % k])
+        assert r.lam == float(g["lam%d" % k]) and r.time_cost == float(g["time_cost%d" % k])
+
+
+def test_product_readstartdist_vs_oracle():
+    from oracle.dists import OReadStartDist
+    from oracle.pafcigar import parse_paf, best_mapper
+
+    class C:
+        def __init__(self, L):
+            self.length = L
+    contigs = e2e_reference()
+    cs = {"ctgA": C(150_000), "ctgB": C(260_000)}
+    names = ["ctgA", "ctgB", "ctgREJ"]
+    o = OReadStartDist(cs)
+    p = ReadStartDist(cs)
+    for b in range(3):
+        batch = e2e_batch(contigs, b, 1)
+        paf = parse_paf(batch["paf"], min_len=200)
+        o.count_read_starts(paf)
+        recs = [best_mapper(v) for v in paf.values()]
+        ci = np.array([names.index(r.tname) if r.tname in names else -1 for r in recs])
+        p.count_starts(names, ci, np.array([r.rev for r in recs]), np.array([r.tstart for r in recs]),
+                       np.array([r.tend for r in recs]))
+        assert np.array_equal(o.merge(), p.merge())
+        fh_c, target_rs = p.fhat_compact()
+        want = o.update_f_pointmass()
+        got = p.expand(fh_c, want.shape[0])
+        assert target_rs == o.target_size and got.shape == want.shape
+        assert np.allclose(got, want, rtol=1e-13, atol=0)      # only the normaliser's rounding differs
+
+
+def test_choose_threshold_vs_oracle_find_strategy():
+    from oracle.strategy import find_strategy
+    rng = np.random.default_rng(3)
+    for trial in range(5):
+        T, nb = 4000, 2
+        benefit = rng.gamma(0.3, 2.0, size=(T, 2, nb)) * (rng.random((T, 2, nb)) > 0.2)
+        fhat = rng.random((T, 2))
+        fhat /= fhat.sum()
+        fh3 = np.repeat(fhat[:, :, None], nb, axis=2)
+        detail = {}
+        strat, thr = find_strategy(benefit, benefit, fh3, 5000.0, detail=detail)
+        # binned statistics as the device produces them (exact sums, here via Python ints)
+        norm = benefit.max()
+        exps = np.abs(np.frexp(benefit[benefit != 0] / norm)[1])
+        counts = np.bincount(exps, minlength=1088).astype(np.int64)
+        fgrid = np.zeros(1088)
+        for e in np.nonzero(counts)[0]:
+            fgrid[e] = float(np.sum(fh3[benefit != 0][exps == e]))
+        ubar0 = float(np.sum(fh3 * benefit))
+        t, size, uniq = choose_threshold(norm, counts, fgrid, ubar0, 5000.0)
+        assert t == thr and size == detail["strat_size"] and np.array_equal(uniq, detail["exponents"])
+
+
+def test_fixed_point_conversion():
+    for v in (0.0, 1.0, 1e-6, 0.123456789, 3.5e-12):
+        n = int(v * (1 << FX_SHIFT))
+        assert fx_to_float(n & ((1 << 64) - 1), n >> 64) == n / (1 << FX_SHIFT)
