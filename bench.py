@@ -180,6 +180,7 @@ def main():
         t0 = time.perf_counter()
         s = eng.stage_batch(b["paf"], b["seqs"], barcodes=b["barcodes"] if nb > 1 else None)
         t_parse.append(time.perf_counter() - t0)
+        b["read_lengths_arr"] = np.fromiter(b["read_lengths"].values(), dtype=np.int64, count=len(b["read_lengths"]))
         batches.append(b)
         summaries.append(s)
     aligned = float(np.mean([s["aligned"] for s in summaries]))
@@ -191,9 +192,9 @@ def main():
         else:
             eng.update_begin(runs.args.optional.bucket_threshold)
         if distributed:
-            runs.account_batch(summaries[i], batches[i]["read_lengths"], len(batches[i]["seqs"]))
+            runs.account_batch(summaries[i], batches[i]["read_lengths_arr"], len(batches[i]["seqs"]))
         else:
-            runs.rl_dist.update(batches[i]["read_lengths"])
+            runs.rl_dist.update(batches[i]["read_lengths_arr"])
             runs.launch_benefit()    # the chain needs only the read-length windows
             runs._account_reads(summaries[i], len(batches[i]["seqs"]))
         runs.update_wrapper()

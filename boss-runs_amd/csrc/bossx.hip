@@ -45,6 +45,8 @@ struct bossx_engine {
     int32_t *d_err = nullptr;
     Ctrl *d_ctrl = nullptr;
     uint8_t *d_contig_on = nullptr;
+    long long *d_limbs = nullptr;       // multi-GPU: SUM-reducible statistics
+    double *d_tails = nullptr;          // multi-GPU: last n_filt rows of every block
     // contig tables (device)
     int64_t *d_tile_off = nullptr, *d_site_off = nullptr, *d_length = nullptr, *d_bin_off = nullptr,
             *d_row_off = nullptr, *d_strat_off = nullptr, *d_bucket_off = nullptr;
@@ -262,7 +264,7 @@ void bossx_destroy(bossx_engine *h) {
     void *ptrs[] = {h->d_cov, h->d_meta, h->d_touched, h->d_strat, h->d_bucket_on, h->d_entropy, h->d_ds,
                     h->d_benefit, h->d_lut_score, h->d_lut_ent, h->d_fhat, h->d_bucket_sums, h->d_drop_count,
                     h->d_stats, h->d_err, h->d_tile_off, h->d_site_off, h->d_length, h->d_bin_off, h->d_row_off,
-                    h->d_strat_off, h->d_bucket_off, h->d_drop_thr, h->d_local, h->d_ctrl, h->d_contig_on};
+                    h->d_strat_off, h->d_bucket_off, h->d_drop_thr, h->d_local, h->d_ctrl, h->d_contig_on, h->d_limbs, h->d_tails};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &st : h->slots) { if (st.d_ops) hipFree(st.d_ops); if (st.d_tiles) hipFree(st.d_tiles); if (st.d_blob) hipFree(st.d_blob); if (st.d_segs) hipFree(st.d_segs); if (st.d_tilerefs) hipFree(st.d_tilerefs); }
     if (h->d_tile_ref) hipFree(h->d_tile_ref);
@@ -374,6 +376,8 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
     if ((rc = dev_alloc(h, &h->d_err, 1, true))) return rc;
     if ((rc = dev_alloc(h, &h->d_ctrl, 1, true))) return rc;
     if ((rc = dev_alloc(h, &h->d_contig_on, h->filt.size(), true))) return rc;
+    if ((rc = dev_alloc(h, &h->d_limbs, size_t(BOSSX_HIST_BINS + 1) * 5, true))) return rc;
+    if ((rc = dev_alloc(h, &h->d_tails, h->filt.size() * h->filt.size() * 2 * size_t(nb), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_lut_score, size_t(BOSSX_NCOMP) * 4, true))) return rc;
     if ((rc = dev_alloc(h, &h->d_lut_ent, size_t(BOSSX_NCOMP) * 4, true))) return rc;
     if ((rc = upload_vec(h, &h->d_tile_off, tile_off))) return rc;
@@ -784,10 +788,11 @@ int launch_hist(bossx_engine *h, const bossx_fhat_desc *fh, int gate) {
     return BOSSX_OK;
 }
 
-int launch_mask(bossx_engine *h, int gate) {
+int launch_mask(bossx_engine *h, int gate, bool with_tails = false) {
     MaskParams P;
     P.benefit = h->d_benefit; P.bucket_on = h->d_bucket_on; P.strat = h->d_strat; P.ct = table_of(h);
     P.B = h->B; P.NBK = h->NBK; P.rows = h->rows; P.nb = h->nb; P.gate = gate; P.ctrl = h->d_ctrl;
+    P.tails = with_tails ? h->d_tails : nullptr; P.tail_k = int32_t(h->filt.size());
     const int64_t blocks = std::min<int64_t>((h->rows + 255) / 256, 4096);
     time_begin(h, BOSSX_K_MASK);
     hipLaunchKernelGGL(strategy_mask_kernel, dim3(uint32_t(std::max<int64_t>(blocks, 1))), dim3(256), 0, h->stream, P);
@@ -844,6 +849,81 @@ int bossx_update_begin(bossx_engine *h, double bucket_threshold) {
     if (rc) return rc;
     launch_buckets(h, bucket_threshold);
     HIPCHK(hipGetLastError());
+    return BOSSX_OK;
+}
+
+int bossx_device_ptr(bossx_engine *h, int32_t which, void **ptr, size_t *bytes) {
+    if (!h || !h->finalized || !ptr || !bytes) return fail(h, BOSSX_E_INVALID, "bad device_ptr call");
+    switch (which) {
+        case BOSSX_PTR_ARMED: *ptr = &h->d_ctrl->any_on; *bytes = sizeof(int32_t); break;
+        case BOSSX_PTR_NORMALISER: *ptr = &h->d_ctrl->max_bits; *bytes = sizeof(unsigned long long); break;
+        case BOSSX_PTR_LIMBS: *ptr = h->d_limbs; *bytes = size_t(BOSSX_HIST_BINS + 1) * 5 * sizeof(long long); break;
+        case BOSSX_PTR_TAILS: *ptr = h->d_tails; *bytes = h->filt.size() * h->filt.size() * 2 * size_t(h->nb) * sizeof(double); break;
+        default: return fail(h, BOSSX_E_INVALID, "unknown device pointer selector");
+    }
+    return BOSSX_OK;
+}
+
+int bossx_dist_hist(bossx_engine *h, const bossx_fhat_desc *fh) {
+    if (!h || !h->finalized || !fh || !fh->fhat_c) return fail(h, BOSSX_E_INVALID, "bad dist_hist call");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int rc = upload_fhat(h, fh);
+    if (rc) return rc;
+    if ((rc = launch_hist(h, fh, 1))) return rc;
+    hipLaunchKernelGGL(stats_to_limbs_kernel, dim3((BOSSX_HIST_BINS + 1 + 255) / 256), dim3(256), 0, h->stream, h->d_stats,
+                       h->d_stats + BOSSX_HIST_BINS, h->d_stats + BOSSX_HIST_BINS * 3, h->d_limbs, h->d_ctrl, 1);
+    HIPCHK(hipGetLastError());
+    return BOSSX_OK;
+}
+
+int bossx_dist_pick(bossx_engine *h, double tc) {
+    if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "bad dist_pick call");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    PickParams PP;
+    PP.counts = h->d_stats; PP.fgrid = h->d_stats + BOSSX_HIST_BINS; PP.ubar = h->d_stats + BOSSX_HIST_BINS * 3;
+    PP.limbs = h->d_limbs; PP.ctrl = h->d_ctrl; PP.tc = tc; PP.gate = 1;
+    hipLaunchKernelGGL(threshold_pick_kernel, dim3(1), dim3(64), 0, h->stream, PP);
+    MaskParams P;
+    P.benefit = h->d_benefit; P.bucket_on = h->d_bucket_on; P.strat = h->d_strat; P.ct = table_of(h);
+    P.B = h->B; P.NBK = h->NBK; P.rows = h->rows; P.nb = h->nb; P.gate = 1; P.ctrl = h->d_ctrl;
+    P.tails = nullptr; P.tail_k = int32_t(h->filt.size());
+    hipLaunchKernelGGL(export_tails_kernel, dim3(64), dim3(256), 0, h->stream, P, h->d_tails);
+    HIPCHK(hipGetLastError());
+    return BOSSX_OK;
+}
+
+int bossx_dist_finish(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, bossx_update_result *res) {
+    if (!h || !h->finalized || !res) return fail(h, BOSSX_E_INVALID, "bad dist_finish call");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int rc = launch_mask(h, 1, true);
+    if (rc) return rc;
+    const size_t need = sizeof(Ctrl) + sizeof(int32_t) + h->filt.size();
+    if ((rc = ensure_pin(h, need + 64))) return rc;
+    char *pin = static_cast<char *>(h->h_pin);
+    Ctrl *hc = reinterpret_cast<Ctrl *>(pin);
+    int32_t *herr = reinterpret_cast<int32_t *>(pin + sizeof(Ctrl));
+    uint8_t *hon = reinterpret_cast<uint8_t *>(pin + sizeof(Ctrl) + sizeof(int32_t));
+    HIPCHK(hipMemcpyAsync(hc, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(herr, h->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(hon, h->d_contig_on, h->filt.size(), hipMemcpyDeviceToHost, h->stream));
+    if (strat_all) HIPCHK(hipMemcpyAsync(strat_all, h->d_strat, size_t(h->strat_bytes), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (*herr) {
+        HIPCHK(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
+        return fail(h, BOSSX_E_RANGE, "a read contains a base other than A/C/G/T inside an aligned segment");
+    }
+    if (contig_on) {
+        for (size_t i = 0; i < h->contigs.size(); ++i) contig_on[i] = 0;
+        for (size_t k = 0; k < h->filt.size(); ++k) contig_on[size_t(h->filt[k])] = hon[k];
+    }
+    res->updated = hc->any_on; res->any_on = hc->any_on;
+    res->strat_size = hc->strat_size; res->n_bins = hc->n_bins;
+    res->threshold = hc->threshold; res->ubar0 = hc->ubar0;
+    memcpy(&res->normaliser, &hc->max_bits, sizeof(double));
+    if (res->updated && (hc->err & 2)) {
+        HIPCHK(hipMemsetAsync(&h->d_ctrl->err, 0, sizeof(int32_t), h->stream));
+        return fail(h, BOSSX_E_EMPTY, "no non-zero benefit (np.max of an empty array)");
+    }
     return BOSSX_OK;
 }
 
@@ -910,7 +990,7 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
         if ((rc = launch_hist(h, &fh, 1))) return rc;
         PickParams PP;
         PP.counts = h->d_stats; PP.fgrid = h->d_stats + BOSSX_HIST_BINS; PP.ubar = h->d_stats + BOSSX_HIST_BINS * 3;
-        PP.ctrl = h->d_ctrl; PP.tc = up->tc; PP.gate = 1;
+        PP.limbs = nullptr; PP.ctrl = h->d_ctrl; PP.tc = up->tc; PP.gate = 1;
         hipLaunchKernelGGL(threshold_pick_kernel, dim3(1), dim3(64), 0, h->stream, PP);
         if ((rc = launch_mask(h, 1))) return rc;
     }

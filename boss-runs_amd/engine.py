@@ -239,6 +239,35 @@ class Engine:
         self._ck(self.lib.bossx_update_benefit(self.h, w.ctypes.data, m.ctypes.data))
         self._benefit_done = tuple(w.tolist())
 
+    def device_ptr(self, which):
+        """(address, nbytes) of a device-resident statistics buffer (0 armed flag, 1 normaliser,
+        2 limbs, 3 tails) for zero-copy wrapping by torch (multi-GPU in-stream collectives)."""
+        ptr = C.c_void_p()
+        nbytes = C.c_size_t()
+        self._ck(self.lib.bossx_device_ptr(self.h, int(which), C.byref(ptr), C.byref(nbytes)))
+        return ptr.value, nbytes.value
+
+    def dist_hist(self, fhat_c, target_rs, target):
+        f = np.ascontiguousarray(fhat_c, dtype=np.float64)
+        desc = _lib.FhatDesc(f.ctypes.data, f.shape[0], 20, int(target_rs), int(target))
+        self._keep = f                       # the upload is asynchronous
+        self._ck(self.lib.bossx_dist_hist(self.h, C.byref(desc)))
+
+    def dist_pick(self, tc):
+        self._ck(self.lib.bossx_dist_pick(self.h, float(tc)))
+
+    def dist_finish(self):
+        if getattr(self, "strat_all", None) is None:
+            self.strat_all = np.ones(max(int(self.lib.bossx_strat_bytes(self.h)), 1), dtype=np.uint8)
+        on = np.zeros(len(self.names), dtype=np.uint8)
+        res = _lib.UpdateResult()
+        self._ck(self.lib.bossx_dist_finish(self.h, self.strat_all.ctypes.data, on.ctypes.data, C.byref(res)))
+        self._sweep_done = False
+        self._benefit_done = None
+        return dict(updated=bool(res.updated), any_on=bool(res.any_on), threshold=res.threshold,
+                    normaliser=res.normaliser, ubar0=res.ubar0, strat_size=res.strat_size,
+                    n_bins=res.n_bins, contig_on=on.astype(bool))
+
     def arm(self):
         self._ck(self.lib.bossx_arm(self.h))
 

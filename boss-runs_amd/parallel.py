@@ -117,6 +117,14 @@ def limbs_to_float(limbs):
     return out.reshape(limbs.shape[:-1])
 
 
+class _DeviceBuffer:
+    """Zero-copy view of engine-owned HBM for torch (`__cuda_array_interface__`)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": tuple(shape),
+                                         "typestr": typestr, "version": 2}
+
+
 class DistributedBossRuns(BossRuns):
     """`BossRuns` over several GPUs.  Construct on every rank with the same arguments, after
     `torch.distributed.init_process_group`; with world size 1 it degenerates to the stage-wise
@@ -139,7 +147,32 @@ class DistributedBossRuns(BossRuns):
         self.owner = partition_contigs([l * nb for l in lens], self.comm.world)
         self.owner_of = {n: o for (n, _), o in zip(keep, self.owner)}
         rank = self.comm.rank
+        # RCCL path: the engine shares torch's stream and its statistics buffers are wrapped as
+        # tensors, so the update's collectives run in-stream (no host round trips)
+        import os
+        self.instream = (engine is None and self.comm.on and self.comm.device != "cpu"
+                         and not os.environ.get("BOSSX_HOST_COLLECTIVES"))
+        if self.instream:
+            from .engine import Engine
+            torch = self.comm.torch
+            engine = Engine(nbarcodes=nb, device=torch.cuda.current_device(),
+                            track_entropy=self.args.gpu.track_entropy,
+                            stream=torch.cuda.current_stream().cuda_stream)
         super().init(contigs=contigs, engine=engine, is_local=lambda name, k: self.owner[k] == rank)
+        if self.instream:
+            torch = self.comm.torch
+            eng = self.engine
+            nfilt = len(self.contigs_filt)
+
+            def wrap(which, shape, typestr):
+                ptr, nbytes = eng.device_ptr(which)
+                t = torch.as_tensor(_DeviceBuffer(ptr, shape, typestr), device=self.comm.device)
+                assert t.data_ptr() == ptr and t.numel() * t.element_size() == nbytes
+                return t
+            self.t_armed = wrap(0, (1,), "<i4")
+            self.t_norm = wrap(1, (1,), "<i8")            # bit pattern of a non-negative double
+            self.t_limbs = wrap(2, ((_lib.HIST_BINS + 1) * 5,), "<i8")
+            self.t_tails = wrap(3, (nfilt * nfilt * 2 * nb,), "<f8")
         self.local_filt = {n: c for n, c in self.contigs_filt.items() if not c.remote}
         self.armed = False
         self._begun = False
@@ -198,7 +231,47 @@ class DistributedBossRuns(BossRuns):
             self.engine.update_begin(self.args.optional.bucket_threshold)
             self._begun = True
 
+    def _update_instream(self) -> None:
+        """The update with device-resident statistics: four in-stream RCCL all-reduces between
+        asynchronous engine stages, one synchronisation at the end (bossx.h, bossx_device_ptr)."""
+        eng, dist = self.engine, self.comm.dist
+        MAXOP, SUMOP = dist.ReduceOp.MAX, dist.ReduceOp.SUM
+        self.begin_update()
+        self._begun = False
+        dist.all_reduce(self.t_armed, op=MAXOP)                  # core.py:111 is a global decision
+        have_rl = hasattr(self.rl_dist, "time_cost")
+        if have_rl:
+            windows = np.concatenate(([400 // 100], self.rl_dist.approx_ccl // 100)).astype(np.int32)
+            eng.update_benefit(windows, MULT)                    # gated on the (now global) flag
+            dist.all_reduce(self.t_norm, op=MAXOP)
+            fhat_c, target_rs = self.read_starts.fhat_compact()
+            eng.dist_hist(fhat_c, target_rs, self.ref.n_sites // 100)
+            dist.all_reduce(self.t_limbs, op=SUMOP)
+            eng.dist_pick(self.rl_dist.time_cost // 100)
+            dist.all_reduce(self.t_tails, op=SUMOP)
+        self.comm.n_collectives += 4 if have_rl else 1
+        res = eng.dist_finish()
+        for cont in self.local_filt.values():
+            if res["contig_on"][cont.index]:
+                cont.switched_on[:] = True
+        self.armed = res["any_on"]
+        if not self.armed:
+            return
+        if not have_rl:
+            raise AttributeError("'ReadlengthDist' object has no attribute 'time_cost'")
+        self.threshold = res["threshold"]
+        self.last_stats = dict(normaliser=res["normaliser"], ubar0=res["ubar0"],
+                               strat_size=res["strat_size"], n_bins=res["n_bins"])
+        for cont in self.local_filt.values():
+            cont.strat = eng.strat_view(cont.index)
+        if self.gather_masks and (self.comm.world > 1 or self.comm.force):
+            self._gather_masks()
+        if self.write_masks and self.comm.rank == 0:
+            self._write_contig_strategies(contig_strats=self.ref.get_strategy_dict())
+
     def update_wrapper(self) -> None:
+        if getattr(self, "instream", False):
+            return self._update_instream()
         eng, comm = self.engine, self.comm
         device_side = hasattr(eng, "update_begin")        # the HIP engine; test doubles lack it
         thr_b = self.args.optional.bucket_threshold

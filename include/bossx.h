@@ -216,6 +216,27 @@ int bossx_update_benefit(bossx_engine *h, const int32_t *windows, const double *
  * decision is global: any contig on any rank, core.py:111), so gated stages run on ranks whose
  * own contigs are still below the bucket threshold.  bossx_get_max waits for the chain and
  * returns this device's max(additional_benefit) (0 if the gated chain did not run).           */
+/* Device-resident multi-GPU update: the statistics stay in HBM and are all-reduced in-stream
+ * (RCCL through torch.distributed on tensors that alias the buffers below; the engine must
+ * have been created on that stream), so an update has no host round trip before its end:
+ *     bossx_update_begin                      sweep + bucket switches
+ *     all-reduce MAX  ARMED flag              (int32[1])
+ *     bossx_update_benefit                    chain (gated on the flag)
+ *     all-reduce MAX  NORMALISER              (int64[1]: bit pattern of a non-negative double)
+ *     bossx_dist_hist                         histogram with the global normaliser -> LIMBS
+ *     all-reduce SUM  LIMBS                   (int64[(BOSSX_HIST_BINS + 1) * 5], exact)
+ *     bossx_dist_pick                         global threshold; publishes the block TAILS
+ *     all-reduce SUM  TAILS                   (float64[n_filt * n_filt * 2 * nb], one non-zero
+ *                                              contributor per element: exact)
+ *     bossx_dist_finish                       masks (halo rows from the tails), D2H, sync     */
+#define BOSSX_PTR_ARMED      0
+#define BOSSX_PTR_NORMALISER 1
+#define BOSSX_PTR_LIMBS      2
+#define BOSSX_PTR_TAILS      3
+int bossx_device_ptr(bossx_engine *h, int32_t which, void **ptr, size_t *bytes);
+int bossx_dist_hist(bossx_engine *h, const bossx_fhat_desc *fh);
+int bossx_dist_pick(bossx_engine *h, double tc);
+int bossx_dist_finish(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, bossx_update_result *res);
 int bossx_arm(bossx_engine *h);
 int bossx_get_max(bossx_engine *h, double *max_benefit);
 int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all,

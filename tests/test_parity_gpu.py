@@ -143,16 +143,20 @@ def test_export_import_roundtrip(in_tmp):
     assert np.array_equal(c2.entropy, ent)
 
 
-def test_distributed_protocol_single_rank_nccl(in_tmp, monkeypatch):
-    """The multi-GPU protocol on one GPU with the collectives forced on (nccl = RCCL): device
-    tensors, dtypes and the stage-wise engine calls; result must equal the fused update."""
+@pytest.mark.parametrize("host_collectives", [False, True])
+def test_distributed_protocol_single_rank_nccl(in_tmp, monkeypatch, host_collectives):
+    """The multi-GPU protocol on one GPU with the collectives forced on (nccl = RCCL), in both
+    forms: in-stream all-reduces on tensors aliasing the engine's device buffers, and the
+    host-staged form; result must equal the fused single-GPU update."""
+    if host_collectives:
+        monkeypatch.setenv("BOSSX_HOST_COLLECTIVES", "1")
     import torch
     import torch.distributed as dist
     from boss_runs_amd.config import BossConfig
     from boss_runs_amd.parallel import DistributedBossRuns
     monkeypatch.setenv("BOSSX_FORCE_COLLECTIVES", "1")
     monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
-    monkeypatch.setenv("MASTER_PORT", "29631")
+    monkeypatch.setenv("MASTER_PORT", "29632" if host_collectives else "29631")
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
@@ -162,6 +166,7 @@ def test_distributed_protocol_single_rank_nccl(in_tmp, monkeypatch):
         args.optional.reject_refs = E2E_REJECT
         d = DistributedBossRuns(args)
         d.init(contigs=e2e_contig_strings(contigs))
+        assert d.instream == (not host_collectives)
         f = _product(1, 1, in_tmp)
         for b in range(3):
             batch = e2e_batch(contigs, b, 1)
