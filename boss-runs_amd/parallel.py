@@ -132,10 +132,11 @@ class DistributedBossRuns(BossRuns):
 
     READ_CAP = 8192      # max reads per rank and batch in the sharded-reads exchange
 
-    def init(self, contigs, engine=None, sharded_reads=True, gather_masks=True) -> None:
+    def init(self, contigs, engine=None, sharded_reads=True, gather_masks=True, comm=None) -> None:
         """`contigs`: list of (name, sequence) — every rank may pass the full list, or a bare
-        length in place of the sequence for contigs it does not own."""
-        self.comm = Comm()
+        length in place of the sequence for contigs it does not own.  `comm` replaces the
+        torch.distributed wrapper (tests)."""
+        self.comm = comm or Comm()
         self.sharded_reads = sharded_reads
         self.gather_masks = gather_masks
         contigs = list(contigs)

@@ -338,3 +338,79 @@ def test_simulation_decisions(in_tmp):
         except (KeyError, IndexError):
             want[rid] = False
     assert got == want and any(want.values()) and not all(want.values())
+
+
+def test_two_rank_device_protocol_emulated_on_one_gpu(in_tmp):
+    """Cross-rank logic of the device-resident multi-GPU update without a second GPU: two
+    engines on cuda:0 own different contigs; the four in-stream all-reduces are emulated by
+    reducing the two engines' aliased statistics tensors.  Exercises remote-contig geometry in
+    every kernel, the exact limb sums, and the halo rows served from the published tails.
+    Result must equal the single-engine fused update."""
+    import torch
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.parallel import DistributedBossRuns
+    from boss_runs_amd.runs import MULT
+
+    class FakeComm:
+        def __init__(self, rank):
+            self.torch, self.dist, self.on, self.force = torch, None, True, False
+            self.rank, self.world, self.n_collectives = rank, 2, 0
+            self.device = torch.device("cuda", 0)
+
+    nb = 2
+    contigs = e2e_reference()
+    torch.cuda.set_device(0)
+    ranks = []
+    for r in range(2):
+        args = BossConfig()
+        args.general.name = "emu%d" % r
+        args.optional.ploidy = 2
+        args.optional.reject_refs = E2E_REJECT
+        args.general.barcodes = ["barcode01", "barcode02"]
+        d = DistributedBossRuns(args)
+        d.init(contigs=e2e_contig_strings(contigs), sharded_reads=False, gather_masks=False, comm=FakeComm(r))
+        assert d.instream
+        ranks.append(d)
+    assert ranks[0].contigs["ctgB"].remote and ranks[1].contigs["ctgA"].remote
+    f = _product(2, nb, in_tmp)
+
+    def reduce_pair(name, op):
+        ts = [getattr(d, name) for d in ranks]
+        torch.cuda.synchronize()
+        red = torch.maximum(ts[0], ts[1]) if op == "max" else ts[0] + ts[1]
+        for t in ts:
+            t.copy_(red)
+        torch.cuda.synchronize()
+
+    for b in range(4):
+        batch = e2e_batch(contigs, b, nb)
+        f.rl_dist.update(batch["read_lengths"])
+        f.process_batch_paf(batch["paf"], batch["seqs"], barcodes=batch["barcodes"])
+        for d in ranks:                      # replicated reads: every rank sees the whole batch
+            summ = d.engine.ingest_paf(batch["paf"], batch["seqs"], barcodes=batch["barcodes"])
+            d.begin_update()
+            d.account_batch(summ, batch["read_lengths"], len(batch["seqs"]))
+            d._begun = False
+        reduce_pair("t_armed", "max")
+        windows = np.concatenate(([4], ranks[0].rl_dist.approx_ccl // 100)).astype(np.int32)
+        for d in ranks:
+            d.engine.update_benefit(windows, MULT)
+        reduce_pair("t_norm", "max")
+        for d in ranks:
+            fh, trs = d.read_starts.fhat_compact()
+            d.engine.dist_hist(fh, trs, d.ref.n_sites // 100)
+        reduce_pair("t_limbs", "sum")
+        for d in ranks:
+            d.engine.dist_pick(d.rl_dist.time_cost // 100)
+        reduce_pair("t_tails", "sum")
+        res = [d.engine.dist_finish() for d in ranks]
+        if f.threshold is None:
+            assert not res[0]["any_on"] and not res[1]["any_on"]
+            continue
+        for r, d in enumerate(ranks):
+            assert res[r]["any_on"] and res[r]["threshold"] == f.threshold, (b, r)
+            assert res[r]["normaliser"] == f.last_stats["normaliser"]
+            for n, c in d.contigs_filt.items():
+                if not c.remote:
+                    assert np.array_equal(d.engine.strat_view(c.index), f.contigs[n].strat), (b, r, n)
+    assert f.threshold is not None
