@@ -265,7 +265,7 @@ def main():
         if not a.no_large and world == 1:
             del runs, eng
             out["roofline_large"] = large_sweep(local_rank)
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:
             _, times = cpu_baseline(contigs, batches, a.cpu_updates)
             t_med = float(np.median(times))
             out["cpu_baseline"] = {

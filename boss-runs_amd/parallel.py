@@ -156,9 +156,14 @@ class DistributedBossRuns(BossRuns):
         if self.instream:
             from .engine import Engine
             torch = self.comm.torch
+            # a dedicated (non-default) stream: its handle is non-zero, so the engine really
+            # launches on it, and c10d orders every collective issued under
+            # `torch.cuda.stream(self.tstream)` against the engine's kernels on that stream
+            self.tstream = torch.cuda.Stream()
+            assert self.tstream.cuda_stream != 0
             engine = Engine(nbarcodes=nb, device=torch.cuda.current_device(),
                             track_entropy=self.args.gpu.track_entropy,
-                            stream=torch.cuda.current_stream().cuda_stream)
+                            stream=self.tstream.cuda_stream)
         super().init(contigs=contigs, engine=engine, is_local=lambda name, k: self.owner[k] == rank)
         if self.instream:
             torch = self.comm.torch
@@ -235,21 +240,22 @@ class DistributedBossRuns(BossRuns):
     def _update_instream(self) -> None:
         """The update with device-resident statistics: four in-stream RCCL all-reduces between
         asynchronous engine stages, one synchronisation at the end (bossx.h, bossx_device_ptr)."""
-        eng, dist = self.engine, self.comm.dist
+        eng, dist, torch = self.engine, self.comm.dist, self.comm.torch
         MAXOP, SUMOP = dist.ReduceOp.MAX, dist.ReduceOp.SUM
         self.begin_update()
         self._begun = False
-        dist.all_reduce(self.t_armed, op=MAXOP)                  # core.py:111 is a global decision
         have_rl = hasattr(self.rl_dist, "time_cost")
-        if have_rl:
-            windows = np.concatenate(([400 // 100], self.rl_dist.approx_ccl // 100)).astype(np.int32)
-            eng.update_benefit(windows, MULT)                    # gated on the (now global) flag
-            dist.all_reduce(self.t_norm, op=MAXOP)
-            fhat_c, target_rs = self.read_starts.fhat_compact()
-            eng.dist_hist(fhat_c, target_rs, self.ref.n_sites // 100)
-            dist.all_reduce(self.t_limbs, op=SUMOP)
-            eng.dist_pick(self.rl_dist.time_cost // 100)
-            dist.all_reduce(self.t_tails, op=SUMOP)
+        with torch.cuda.stream(self.tstream):                    # collectives ordered on the engine's stream
+            dist.all_reduce(self.t_armed, op=MAXOP)              # core.py:111 is a global decision
+            if have_rl:
+                windows = np.concatenate(([400 // 100], self.rl_dist.approx_ccl // 100)).astype(np.int32)
+                eng.update_benefit(windows, MULT)                # gated on the (now global) flag
+                dist.all_reduce(self.t_norm, op=MAXOP)
+                fhat_c, target_rs = self.read_starts.fhat_compact()
+                eng.dist_hist(fhat_c, target_rs, self.ref.n_sites // 100)
+                dist.all_reduce(self.t_limbs, op=SUMOP)
+                eng.dist_pick(self.rl_dist.time_cost // 100)
+                dist.all_reduce(self.t_tails, op=SUMOP)
         self.comm.n_collectives += 4 if have_rl else 1
         res = eng.dist_finish()
         for cont in self.local_filt.values():

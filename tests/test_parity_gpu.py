@@ -167,6 +167,8 @@ def test_distributed_protocol_single_rank_nccl(in_tmp, monkeypatch, host_collect
         d = DistributedBossRuns(args)
         d.init(contigs=e2e_contig_strings(contigs))
         assert d.instream == (not host_collectives)
+        if d.instream:
+            assert d.tstream.cuda_stream != 0      # the engine really shares torch's stream
         f = _product(1, 1, in_tmp)
         for b in range(3):
             batch = e2e_batch(contigs, b, 1)
