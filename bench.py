@@ -241,7 +241,7 @@ def main():
         achieved = kern[roof_k]["gbs"] or 0.0
         traffic, traffic_src = pmc_traffic(a.workload, "site_sweep_kernel")
         out = {
-            "metric": "decision-update Mbp scored/sec (4000-read batch); ms_per_step = decision-update wall-clock",
+            "metric": "decision-update wall-clock (ms) + Mbp scored/sec, 4000-read batch",
             "value": value, "unit": "Mbp/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u16+f64", "data": "synthetic",
@@ -258,7 +258,14 @@ def main():
                          "note": "site_sweep = sweep<false> + sweep<true> launches (fused CIGAR expansion + "
                                  "coverage increment + scoring + bin sums); at this size the working set is "
                                  "cache resident and the kernel is latency bound; see roofline_large"},
+            "metric_note": "value = Mbp scored/s (reference positions brought up to date per second); "
+                           "ms_per_step = decision-update wall-clock",
             "kernels": kern, "dominant_kernel_by_time": dom,
+            # the chain is a serial FP64 recurrence (1 % of the data): its bound is the dependent
+            # matrix-op latency, not HBM — 52 cycles per 4 bins measured (scripts/mfma_f64_probe.hip)
+            "chain_latency": {"kernel": "benefit_chain", "bound": "dependent-op latency",
+                              "bins": int(eng.merged_bins), "ns_per_bin": 1e6 * kern["benefit_chain"]["avg_ms"] / max(int(eng.merged_bins), 1),
+                              "floor_cycles_per_bin": 13.0, "on_fp64_matrix_core": eng.matrix_chain},
             "host": {"stage_batch_ms_mean": 1e3 * float(np.mean(t_parse))},
             "move_sum_on_fp64_matrix_core": eng.matrix_chain,
         }

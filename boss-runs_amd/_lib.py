@@ -117,6 +117,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and os.path.exists("/opt/rocm/bin/hipcc") and not os.environ.get("BOSSX_NO_AUTOBUILD"):
+        # a clean checkout: build the HIP extension in-tree (same as __graft_entry__.build())
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "ARCH=gfx950"], check=False,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     if not os.path.exists(LIB_PATH):
         raise BossxError(
             "HIP extension not built: %s is missing. Run `python -c 'import __graft_entry__ as g; "
