@@ -416,3 +416,48 @@ def test_two_rank_device_protocol_emulated_on_one_gpu(in_tmp):
                 if not c.remote:
                     assert np.array_equal(d.engine.strat_view(c.index), f.contigs[n].strat), (b, r, n)
     assert f.threshold is not None
+
+
+@pytest.mark.parametrize("mode", ["fused", "staged"])
+def test_awkward_geometry_vs_oracle(in_tmp, mode):
+    """Contig lengths that are not multiples of the 100-bp window, the 2000-site tile or the
+    20-kb bucket; 3 barcodes; diploid; bucket_threshold 2; reads clipped at contig ends.  Every
+    partial tile / bin / bucket and the multi-contig row drift must match the oracle exactly."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.runs import BossRuns
+    from oracle.pipeline import OracleRuns
+    nb = 3
+    lens = [100_003, 123_457, 199_999, 100_100]
+    contigs = synth.make_reference(lens, seed=21, names=["w1", "w2", "w3", "w4"])
+    strs = [(n, synth.codes_to_str(c)) for n, c in contigs]
+    args = BossConfig()
+    args.general.name = "awk"
+    args.optional.ploidy = 2
+    args.optional.bucket_threshold = 2
+    args.general.barcodes = ["barcode%02d" % (i + 1) for i in range(nb)]
+    runs = BossRuns(args)
+    runs.init(contigs=strs)
+    if mode == "staged":
+        runs.update_wrapper = runs.update_wrapper_staged
+        runs._fused = False
+    o = OracleRuns(strs, ploidy=2, nbarcodes=nb, bucket_threshold=2)
+    for b in range(4):
+        batch = synth.make_batch(contigs, 900, seed=700 + b, mean_len=4000.0, nbarcodes=nb)
+        o.process_batch(batch["paf"], batch["seqs"], read_lengths=batch["read_lengths"], barcodes=batch["barcodes"])
+        runs.rl_dist.update(batch["read_lengths"])
+        runs.process_batch_paf(batch["paf"], batch["seqs"], barcodes=batch["barcodes"])
+        assert runs.threshold == o.threshold, b
+        for n, oc in o.contigs.items():
+            pc = runs.contigs[n]
+            assert np.array_equal(pc.coverage, oc.coverage), (b, n)
+            assert np.array_equal(pc.scores, oc.scores), (b, n)
+            assert np.array_equal(pc.bucket_switches, oc.bucket_switches), (b, n)
+            assert np.array_equal(pc.strat, oc.strat), (b, n)
+            if o.threshold is not None:
+                assert np.array_equal(pc.scores_ds, oc.scores_ds), (b, n)
+                assert np.array_equal(pc.additional_benefit, oc.additional_benefit), (b, n)
+    assert o.threshold is not None
+    # some, but not all, buckets are on: the gate is exercised
+    sw = np.concatenate([c.bucket_switches.reshape(-1) for c in o.contigs.values()])
+    assert sw.any()
