@@ -95,6 +95,8 @@ PROTOTYPES = {
     "bossx_strat_bytes": (C.c_int64, [C.c_void_p]),
     "bossx_strat_offset": (C.c_int64, [C.c_void_p, C.c_int32]),
     "bossx_get_strat": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "bossx_strat_bits_bytes": (C.c_int64, [C.c_void_p]),
+    "bossx_get_strat_bits": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bossx_n_contigs": (C.c_int32, [C.c_void_p]),
     "bossx_contig_length": (C.c_int64, [C.c_void_p, C.c_int32]),
     "bossx_n_sites": (C.c_int64, [C.c_void_p]),

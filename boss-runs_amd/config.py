@@ -26,6 +26,9 @@ class GpuConfig:
     """Additions of this build (no reference counterpart)."""
     device: int = 0
     track_entropy: bool = True
+    # "npz": masks/boss.npz as the reference writes it; "bits": masks/boss.bits (masks.py, 8x
+    # smaller, mapped by the consumer); "both"
+    mask_format: str = "npz"
 
 
 @dataclass

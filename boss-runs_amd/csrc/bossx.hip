@@ -37,6 +37,7 @@ struct bossx_engine {
     // device state
     uint16_t *d_cov = nullptr;
     uint8_t *d_meta = nullptr, *d_touched = nullptr, *d_strat = nullptr, *d_bucket_on = nullptr;
+    uint8_t *d_strat_bits = nullptr;   // packed masks (allocated on first use)
     double *d_entropy = nullptr, *d_ds = nullptr, *d_benefit = nullptr;
     double *d_lut_score = nullptr, *d_lut_ent = nullptr, *d_fhat = nullptr;
     unsigned long long *d_bucket_sums = nullptr, *d_stats = nullptr;
@@ -264,7 +265,8 @@ void bossx_destroy(bossx_engine *h) {
     void *ptrs[] = {h->d_cov, h->d_meta, h->d_touched, h->d_strat, h->d_bucket_on, h->d_entropy, h->d_ds,
                     h->d_benefit, h->d_lut_score, h->d_lut_ent, h->d_fhat, h->d_bucket_sums, h->d_drop_count,
                     h->d_stats, h->d_err, h->d_tile_off, h->d_site_off, h->d_length, h->d_bin_off, h->d_row_off,
-                    h->d_strat_off, h->d_bucket_off, h->d_drop_thr, h->d_local, h->d_ctrl, h->d_contig_on, h->d_limbs, h->d_tails};
+                    h->d_strat_off, h->d_bucket_off, h->d_drop_thr, h->d_local, h->d_ctrl, h->d_contig_on, h->d_limbs, h->d_tails,
+                    h->d_strat_bits};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &st : h->slots) { if (st.d_ops) hipFree(st.d_ops); if (st.d_tiles) hipFree(st.d_tiles); if (st.d_blob) hipFree(st.d_blob); if (st.d_segs) hipFree(st.d_segs); if (st.d_tilerefs) hipFree(st.d_tilerefs); }
     if (h->d_tile_ref) hipFree(h->d_tile_ref);
@@ -892,6 +894,26 @@ int bossx_dist_pick(bossx_engine *h, double tc) {
     return BOSSX_OK;
 }
 
+// Device-to-host copy of every mask: as bytes (Contig.strat layout) or packed 8:1.
+static int copy_masks(bossx_engine *h, uint8_t *dst, bool bits) {
+    if (!bits) {
+        HIPCHK(hipMemcpyAsync(dst, h->d_strat, size_t(h->strat_bytes), hipMemcpyDeviceToHost, h->stream));
+        return BOSSX_OK;
+    }
+    const int64_t nout = (h->strat_bytes + 7) / 8;
+    if (!h->d_strat_bits) {
+        int rc = dev_alloc(h, &h->d_strat_bits, size_t(nout > 0 ? nout : 1));
+        if (rc) return rc;
+    }
+    if (nout == 0) return BOSSX_OK;
+    const int64_t blocks = std::min<int64_t>((nout + 255) / 256, 4096);
+    hipLaunchKernelGGL(pack_strat_kernel, dim3(unsigned(blocks)), dim3(256), 0, h->stream,
+                       h->d_strat, h->d_strat_bits, h->strat_bytes);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(dst, h->d_strat_bits, size_t(nout), hipMemcpyDeviceToHost, h->stream));
+    return BOSSX_OK;
+}
+
 int bossx_dist_finish(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, bossx_update_result *res) {
     if (!h || !h->finalized || !res) return fail(h, BOSSX_E_INVALID, "bad dist_finish call");
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -906,7 +928,7 @@ int bossx_dist_finish(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, b
     HIPCHK(hipMemcpyAsync(hc, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(herr, h->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(hon, h->d_contig_on, h->filt.size(), hipMemcpyDeviceToHost, h->stream));
-    if (strat_all) HIPCHK(hipMemcpyAsync(strat_all, h->d_strat, size_t(h->strat_bytes), hipMemcpyDeviceToHost, h->stream));
+    if (strat_all && (rc = copy_masks(h, strat_all, false))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     if (*herr) {
         HIPCHK(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
@@ -1007,8 +1029,7 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
     HIPCHK(hipMemcpyAsync(herr, h->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(hon, h->d_contig_on, h->filt.size(), hipMemcpyDeviceToHost, h->stream));
     if (counts) HIPCHK(hipMemcpyAsync(hst, h->d_stats, kStatWords * 8, hipMemcpyDeviceToHost, h->stream));
-    if (strat_all && have_strategy_inputs)
-        HIPCHK(hipMemcpyAsync(strat_all, h->d_strat, size_t(h->strat_bytes), hipMemcpyDeviceToHost, h->stream));
+    if (strat_all && have_strategy_inputs && (rc = copy_masks(h, strat_all, (up->flags & BOSSX_UPDATE_STRAT_BITS) != 0))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     if (*herr) {
         HIPCHK(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
@@ -1047,6 +1068,15 @@ int bossx_get_strat(bossx_engine *h, int32_t contig, uint8_t *dst) {
     return BOSSX_OK;
 }
 
+int bossx_get_strat_bits(bossx_engine *h, uint8_t *dst) {
+    if (!h || !h->finalized || !dst) return fail(h, BOSSX_E_INVALID, "bad get_strat_bits call");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int rc = copy_masks(h, dst, true);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return BOSSX_OK;
+}
+
 int32_t bossx_n_contigs(const bossx_engine *h) { return h ? int32_t(h->contigs.size()) : 0; }
 int64_t bossx_contig_length(const bossx_engine *h, int32_t c) {
     return (h && c >= 0 && c < int32_t(h->contigs.size())) ? h->contigs[size_t(c)].length : -1;
@@ -1055,6 +1085,7 @@ int64_t bossx_n_sites(const bossx_engine *h) { return h ? h->n_sites_all : 0; }
 int64_t bossx_merged_bins(const bossx_engine *h) { return h ? h->B : 0; }
 int32_t bossx_matrix_chain(const bossx_engine *h) { return (h && h->matrix_chain) ? 1 : 0; }
 int64_t bossx_strat_bytes(const bossx_engine *h) { return h ? h->strat_bytes : 0; }
+int64_t bossx_strat_bits_bytes(const bossx_engine *h) { return h ? (h->strat_bytes + 7) / 8 : 0; }
 int64_t bossx_strat_offset(const bossx_engine *h, int32_t c) {
     if (!h || c < 0 || c >= int32_t(h->contigs.size()) || h->contigs[size_t(c)].rejected || h->contigs[size_t(c)].remote) return -1;
     return h->contigs[size_t(c)].strat_off;

@@ -277,11 +277,12 @@ class Engine:
         return mx.value
 
     def update(self, bucket_threshold, windows=None, mult=None, tc=0.0, fhat_c=None, target_rs=0,
-               want_stats=False):
+               want_stats=False, bits=False):
         """bossx_update: one fused decision update.  Without `fhat_c` only the sweep and the
         bucket switches run.  Returns dict(updated, any_on, threshold, normaliser, ubar0,
         strat_size, n_bins, contig_on[, counts, fgrid_fx, ubar_fx]); masks land in
-        `self.strat_all` (bytes of every non-rejected contig, add order)."""
+        `self.strat_all` (bytes of every non-rejected contig, add order) or, with `bits`,
+        packed 8:1 in `self.strat_bits` (bossx_get_strat_bits layout)."""
         up = _lib.UpdateParams()
         f = None
         if fhat_c is not None:
@@ -304,8 +305,15 @@ class Engine:
             up.flags |= 2
         self._sweep_done = False
         self._benefit_done = None
-        if getattr(self, "strat_all", None) is None:
-            self.strat_all = np.ones(max(int(self.lib.bossx_strat_bytes(self.h)), 1), dtype=np.uint8)
+        if bits:
+            up.flags |= 4
+            if getattr(self, "strat_bits", None) is None:
+                self.strat_bits = np.full(max(int(self.lib.bossx_strat_bits_bytes(self.h)), 1), 0xFF, dtype=np.uint8)
+            masks = self.strat_bits
+        else:
+            if getattr(self, "strat_all", None) is None:
+                self.strat_all = np.ones(max(int(self.lib.bossx_strat_bytes(self.h)), 1), dtype=np.uint8)
+            masks = self.strat_all
         on = np.zeros(len(self.names), dtype=np.uint8)
         res = _lib.UpdateResult()
         counts = fg = ub = None
@@ -313,7 +321,7 @@ class Engine:
             counts = np.zeros(_lib.HIST_BINS, dtype=np.int64)
             fg = np.zeros((_lib.HIST_BINS, 2), dtype=np.uint64)
             ub = np.zeros(2, dtype=np.uint64)
-        self._ck(self.lib.bossx_update(self.h, C.byref(up), self.strat_all.ctypes.data, on.ctypes.data,
+        self._ck(self.lib.bossx_update(self.h, C.byref(up), masks.ctypes.data, on.ctypes.data,
                                        C.byref(res), None if counts is None else counts.ctypes.data,
                                        None if fg is None else fg.ctypes.data,
                                        None if ub is None else ub.ctypes.data))
@@ -329,6 +337,18 @@ class Engine:
         off = int(self.lib.bossx_strat_offset(self.h, contig))
         T = self.lengths[contig] // 100
         return self.strat_all[off: off + T * 2 * self.nb].view(np.bool_).reshape(T, 2, self.nb)
+
+    def strat_offset(self, contig):
+        return int(self.lib.bossx_strat_offset(self.h, contig))
+
+    def get_strat_bits(self, out=None):
+        """bossx_get_strat_bits: every mask packed 8:1 (np.packbits order)."""
+        n = max(int(self.lib.bossx_strat_bits_bytes(self.h)), 1)
+        if out is None:
+            out = np.empty(n, dtype=np.uint8)
+        assert out.size >= n and out.flags.c_contiguous
+        self._ck(self.lib.bossx_get_strat_bits(self.h, out.ctypes.data))
+        return out
 
     def apply_threshold(self, threshold):
         self._ck(self.lib.bossx_apply_threshold(self.h, float(threshold)))

@@ -45,9 +45,21 @@ class Contig:
         nb = self.nbarcodes
         self.switched_on = np.zeros(nb, dtype="bool")
         if rej:
-            self.strat = np.zeros(1, dtype="bool")                       # reference.py:116
+            self._strat = np.zeros(1, dtype="bool")                       # reference.py:116
         else:
-            self.strat = np.ones((self.length // 100, 2, nb), dtype="bool")   # reference.py:118
+            self._strat = np.ones((self.length // 100, 2, nb), dtype="bool")   # reference.py:118
+
+    @property
+    def strat(self):
+        """bool[length//100, 2, nb]; with the bit-packed mask path the array is unpacked from
+        the packed buffer on first access after an update."""
+        if callable(self._strat):
+            self._strat = self._strat()
+        return self._strat
+
+    @strat.setter
+    def strat(self, value):
+        self._strat = value
 
     # device-resident state, reference layout ------------------------------------------------
     def _export(self, which):

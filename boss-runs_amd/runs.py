@@ -16,6 +16,7 @@ import numpy as np
 from . import _lib
 from .config import BossConfig
 from .engine import Engine
+from .masks import write_mask_bits
 from .readlengthdist import ReadlengthDist
 from .readstartdist import ReadStartDist
 from .reference import Reference
@@ -106,16 +107,37 @@ class BossRuns(Boss):
         self.threshold = None
         self.last_stats = {}
         self.write_masks = True
+        self.mask_format = getattr(a.gpu, "mask_format", "npz")
+        if self.mask_format not in ("npz", "bits", "both"):
+            raise ValueError("gpu.mask_format must be 'npz', 'bits' or 'both'")
         self._fused = True             # False when update_wrapper is replaced by the staged form
         self.keep_stats = False        # also fetch the threshold statistics (tests)
         self.log_fractions = True
-        self._write_contig_strategies(contig_strats=self.ref.get_strategy_dict())
+        self._publish_masks(bits=None)
 
     def _write_contig_strategies(self, contig_strats) -> None:
         """boss/runs/core.py:59-69."""
         cpath_tmp = f'{self.out_dir}/masks/boss_tmp.npz'
         np.savez(cpath_tmp, **contig_strats)
         Path(cpath_tmp).rename(f'{self.out_dir}/masks/boss.npz')
+
+    def _mask_entries(self):
+        """(name, rows, rejected, bit offset) per contig in add order for masks.write_mask_bits."""
+        out = []
+        for name, c in self.contigs.items():
+            off = 0 if c.rej else self.engine.strat_offset(c.index)
+            out.append((name, 1 if c.rej else c.length // 100, c.rej, off))
+        return out
+
+    def _publish_masks(self, bits) -> None:
+        """Write the strategy in the configured format(s).  `bits`: the packed buffer of this
+        update, or None to fetch it from the device (init: all ones)."""
+        if self.mask_format in ("npz", "both"):
+            self._write_contig_strategies(contig_strats=self.ref.get_strategy_dict())
+        if self.mask_format in ("bits", "both"):
+            if bits is None:
+                bits = self.engine.get_strat_bits()
+            write_mask_bits(f'{self.out_dir}/masks/boss.bits', self._mask_entries(), bits, self.nbarcodes)
 
     # ---- batch entry points ---------------------------------------------------------------
     def process_batch_runs(self, new_reads, new_quals) -> None:
@@ -182,10 +204,11 @@ class BossRuns(Boss):
         # produces masks, as in the reference.
         fhat_c, target_rs = self.read_starts.fhat_compact()
         have_rl = hasattr(self.rl_dist, "time_cost")
+        use_bits = self._fused and self.mask_format != "npz"   # masks come back packed 8:1 (masks.py)
         if have_rl:
             windows = np.concatenate(([400 // 100], self.rl_dist.approx_ccl // 100)).astype(np.int32)
             res = eng.update(thr, windows, MULT, tc=self.rl_dist.time_cost // 100, fhat_c=fhat_c,
-                             target_rs=target_rs, want_stats=self.keep_stats)
+                             target_rs=target_rs, want_stats=self.keep_stats, bits=use_bits)
         else:
             res = eng.update(thr)
         for cname, cont in self.contigs_filt.items():
@@ -207,13 +230,26 @@ class BossRuns(Boss):
             self.last_stats.update(exponents=uniq, counts=counts[uniq],
                                    f_grid=np.array([fx_to_float(*res["fgrid_fx"][e]) for e in uniq]))
         for cname, cont in self.contigs_filt.items():
-            cont.strat = eng.strat_view(cont.index)
+            if use_bits:
+                cont.strat = self._lazy_strat(cont)          # unpacked on first access
+            else:
+                cont.strat = eng.strat_view(cont.index)
             if self.log_fractions:
                 f_perc = np.count_nonzero(cont.strat[:, 0]) / cont.strat.shape[0]
                 r_perc = np.count_nonzero(cont.strat[:, 1]) / cont.strat.shape[0]
                 logging.info(f'{cname}: {f_perc}, {r_perc}')
         if self.write_masks:
-            self._write_contig_strategies(contig_strats=self.ref.get_strategy_dict())
+            self._publish_masks(bits=eng.strat_bits if use_bits else None)
+
+    def _lazy_strat(self, cont):
+        bits, off = self.engine.strat_bits, self.engine.strat_offset(cont.index)
+        rows, nb = cont.length // 100, self.nbarcodes
+
+        def unpack():
+            n = rows * 2 * nb
+            flat = np.unpackbits(bits[off >> 3: (off + n + 7) >> 3])[(off & 7):(off & 7) + n]
+            return flat.view(np.bool_).reshape(rows, 2, nb)
+        return unpack
 
     def update_wrapper_staged(self) -> None:
         """The same update through the stage-wise C-ABI (sweep / bucket sums / benefit /
@@ -238,7 +274,7 @@ class BossRuns(Boss):
         for cname, cont in self.contigs_filt.items():
             cont.strat = self.engine.get_strat(cont.index)
         if self.write_masks:
-            self._write_contig_strategies(contig_strats=self.ref.get_strategy_dict())
+            self._publish_masks(bits=None)
 
     update_strategy = update_wrapper      # name used by BASELINE.json's north_star
 

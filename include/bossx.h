@@ -183,6 +183,7 @@ int bossx_apply_threshold(bossx_engine *h, double threshold);
  *      statistics arrays are those of bossx_histogram.                                       */
 #define BOSSX_UPDATE_SWEEP_DONE   1  /* bossx_update_begin already enqueued sweep + bucket switches */
 #define BOSSX_UPDATE_BENEFIT_DONE 2  /* bossx_update_benefit already enqueued the move_sum chain     */
+#define BOSSX_UPDATE_STRAT_BITS   4  /* `strat_all` receives the masks packed 8:1 (bossx_get_strat_bits) */
 typedef struct bossx_update_params {
     int32_t windows[BOSSX_NWIN];
     int32_t flags;
@@ -248,6 +249,15 @@ int64_t bossx_strat_offset(const bossx_engine *h, int32_t contig);
 /* Contig.strat as bool bytes, reference layout [length//100][2][nbarcodes] (a rejected
  * contig has the single byte 0, reference.py:116).  Synchronises.                           */
 int bossx_get_strat(bossx_engine *h, int32_t contig, uint8_t *dst);
+
+/* All masks (the bossx_strat_bytes buffer, non-rejected contigs back to back in add order)
+ * packed 8:1 on the device in np.packbits order (element 8i+j = bit 7-j of byte i): element
+ * bossx_strat_offset(c) + (row*2 + strand)*nbarcodes + barcode of the unpacked buffer is
+ * Contig.strat[row, strand, barcode].  This is the payload of the bit-packed mask file the
+ * readfish-side consumer maps (dynamic_readfish.py:169-210 replacement).
+ * `dst` holds bossx_strat_bits_bytes bytes.  Synchronises.                                  */
+int64_t bossx_strat_bits_bytes(const bossx_engine *h);
+int bossx_get_strat_bits(bossx_engine *h, uint8_t *dst);
 
 /* ---- geometry / introspection ----------------------------------------------------------- */
 int32_t bossx_n_contigs(const bossx_engine *h);

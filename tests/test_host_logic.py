@@ -118,3 +118,61 @@ def test_fixed_point_conversion():
     for v in (0.0, 1.0, 1e-6, 0.123456789, 3.5e-12):
         n = int(v * (1 << FX_SHIFT))
         assert fx_to_float(n & ((1 << 64) - 1), n >> 64) == n / (1 << FX_SHIFT)
+
+
+def test_mask_bits_file_roundtrip_and_lookup(tmp_path):
+    """masks.py: the bit-packed mask file gives back exactly the arrays of boss.npz and the
+    reader answers like dynamic_readfish.py:169-210 (`arr[:, rev, b][pos // 100]`, rejected -> 0,
+    unknown contig / out of range -> 1, negative rows wrap like numpy)."""
+    import os
+    from boss_runs_amd.masks import MaskFile, MaskReader, write_mask_bits
+    rng = np.random.default_rng(5)
+    nb = 3
+    strats = {"c1": rng.random((1501, 2, nb)) < 0.3, "rejX": np.zeros(1, dtype=bool),
+              "c2": rng.random((1000, 2, nb)) < 0.7, "c3": rng.random((7, 2, nb)) < 0.5}
+    entries, flat, off = [], [], 0
+    for name, a in strats.items():
+        rej = a.shape[0] == 1 and a.ndim == 1
+        entries.append((name, 1 if rej else a.shape[0], rej, 0 if rej else off))
+        if not rej:
+            flat.append(a.reshape(-1).astype(np.uint8))
+            off += a.size
+    bits = np.packbits(np.concatenate(flat))
+    path = tmp_path / "boss.bits"
+    write_mask_bits(path, entries, bits, nb)
+    mf = MaskFile(path)
+    got = mf.to_dict()
+    assert list(got) == list(strats)
+    for name, a in strats.items():
+        assert got[name].dtype == np.bool_ and np.array_equal(got[name], a), name
+    index = {1: 0, 2: 1, 7: 2}
+    rd = MaskReader(path, barcodes_index=index)
+    assert rd.check_coord("c1", 0, 0, "barcode01") == 1          # nothing loaded: accept all
+    assert rd.reload() == 1 and rd.reload() == 0                 # mtime gate (dynamic_readfish.py:101)
+
+    def ref_check(contig, pos, rev, barcode):
+        if contig not in strats:
+            return 1
+        arr = strats[contig]
+        if arr.shape[0] == 1:
+            return 0
+        try:
+            b = index[int(barcode.split('barcode')[1])]
+            return int(arr[:, int(rev), b][pos // 100])
+        except Exception:
+            return 1
+    for _ in range(3000):
+        contig = ["c1", "c2", "c3", "rejX", "nope"][rng.integers(5)]
+        pos = int(rng.integers(-900, 160_000))
+        rev = bool(rng.integers(2))
+        bc = ["barcode01", "barcode02", "barcode07", "barcode09"][rng.integers(4)]
+        assert rd.check_coord(contig, pos, rev, bc) == ref_check(contig, pos, rev, bc), (contig, pos, rev, bc)
+    # a rewritten file is picked up; an unreadable one accepts everything
+    strats["c3"][:] = True
+    flat[2] = strats["c3"].reshape(-1).astype(np.uint8)
+    write_mask_bits(path, entries, np.packbits(np.concatenate(flat)), nb)
+    os.utime(path, (rd.last_mask_mtime + 5, rd.last_mask_mtime + 5))
+    assert rd.reload() == 1 and rd.check_coord("c3", 650, 1, "barcode02") == 1
+    path.write_bytes(b"garbage")
+    os.utime(path, (rd.last_mask_mtime + 5, rd.last_mask_mtime + 5))
+    assert rd.reload() == 1 and rd.check_coord("rejX", 0, 0, "barcode01") == 1

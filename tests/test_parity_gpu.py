@@ -4,6 +4,7 @@ benefits are compared bit-for-bit too because the product's table and the oracle
 built by the same numpy on the same host (tolerance 1e-6 relative is the stated bound across
 machines)."""
 import os
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -461,3 +462,52 @@ def test_awkward_geometry_vs_oracle(in_tmp, mode):
     # some, but not all, buckets are on: the gate is exercised
     sw = np.concatenate([c.bucket_switches.reshape(-1) for c in o.contigs.values()])
     assert sw.any()
+
+
+def test_mask_bits_path_equals_npz(in_tmp):
+    """gpu.mask_format='both': the device-packed masks (pack_strat_kernel, BOSSX_UPDATE_STRAT_BITS)
+    written as boss.bits decode to exactly the arrays of boss.npz, which equal the oracle's; the
+    mapped reader answers like the reference's consumer on the npz."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.masks import MaskFile, MaskReader
+    from boss_runs_amd.runs import BossRuns
+    from oracle.pipeline import OracleRuns
+    nb = 2
+    contigs = synth.make_reference([150_300, 100_100, 210_050], seed=4, names=["m1", "m2", "m3"])
+    strs = [(n, synth.codes_to_str(c)) for n, c in contigs] + [("rejme", "ACGT" * 30_000)]
+    args = BossConfig()
+    args.general.name = "mbits"
+    args.optional.bucket_threshold = 0
+    args.optional.reject_refs = "rejme"
+    args.general.barcodes = ["barcode01", "barcode02"]
+    args.gpu.mask_format = "both"
+    runs = BossRuns(args)
+    runs.init(contigs=strs)
+    mdir = Path(runs.out_dir) / "masks"
+    mf = MaskFile(mdir / "boss.bits")                 # all-ones start (core.py:53-55)
+    assert all(v.all() for n, v in mf.to_dict().items() if n != "rejme")
+    o = OracleRuns(strs, ploidy=1, nbarcodes=nb, bucket_threshold=0, reject_refs=("rejme",))
+    rd = MaskReader(mdir / "boss.bits", barcodes_index=runs.barcodes_index)
+    rng = np.random.default_rng(0)
+    for b in range(3):
+        batch = synth.make_batch(contigs, 700, seed=40 + b, mean_len=5000.0, nbarcodes=nb)
+        o.process_batch(batch["paf"], batch["seqs"], read_lengths=batch["read_lengths"], barcodes=batch["barcodes"])
+        runs.rl_dist.update(batch["read_lengths"])
+        runs.process_batch_paf(batch["paf"], batch["seqs"], barcodes=batch["barcodes"])
+        npz = np.load(mdir / "boss.npz")
+        got = MaskFile(mdir / "boss.bits").to_dict()
+        assert list(got) == list(npz.keys())
+        for n in npz.keys():
+            assert np.array_equal(got[n], npz[n]), (b, n)
+            assert np.array_equal(npz[n], o.contigs[n].strat), (b, n)
+        assert np.array_equal(runs.engine.get_strat_bits(), runs.engine.strat_bits)
+        rd.last_mask_mtime = 0.0
+        assert rd.reload() == 1
+        for _ in range(500):
+            n = ["m1", "m2", "m3", "rejme"][rng.integers(4)]
+            pos, rev, bc = int(rng.integers(0, 150_000)), int(rng.integers(2)), int(rng.integers(nb))
+            arr = npz[n]
+            want = 0 if arr.shape[0] == 1 else (int(arr[:, rev, bc][pos // 100]) if pos // 100 < arr.shape[0] else 1)
+            assert rd.check_coord(n, pos, rev, "barcode%02d" % (bc + 1)) == want
+    assert 0 < sum(int(v.sum()) for v in got.values()) < sum(v.size for v in got.values())
