@@ -69,6 +69,12 @@ PROTOTYPES = {
                                          C.POINTER(C.c_int64)]),
     "bossx_paf_summary": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int32,
                                     C.c_int32, C.POINTER(BatchSummary), C.POINTER(C.c_int32)]),
+    "bossx_host_parse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                   C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                   C.POINTER(BatchSummary), C.POINTER(C.c_int32), C.POINTER(C.c_int64),
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                   C.c_char_p, C.c_size_t]),
     "bossx_ingest_staged": (C.c_int, [C.c_void_p]),
     "bossx_select_batch": (C.c_int, [C.c_void_p, C.c_int32]),
     "bossx_ingest_paf": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_void_p,

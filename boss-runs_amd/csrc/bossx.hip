@@ -9,6 +9,7 @@
 #include <limits>
 #include <memory>
 #include <string>
+#include <thread>
 
 #include "engine.hpp"
 #include "kernels.hip.inc"
@@ -62,6 +63,7 @@ struct bossx_engine {
         TileRef *d_tilerefs = nullptr; size_t tilerefs_cap = 0;
         ParsedBatch pb;
         bool valid = false;
+        bool emit_tiles_built = false;
     };
     std::vector<Staged> slots = std::vector<Staged>(1);
     int32_t slot = 0;
@@ -72,6 +74,7 @@ struct bossx_engine {
     // pinned scratch
     void *h_pin = nullptr; size_t pin_cap = 0;
     void *h_blob_pin = nullptr; size_t blob_pin_cap = 0;
+    EmitOp *h_ops_pin = nullptr; size_t ops_pin_cap = 0;   // parser output, pinned (H2D at PCIe rate)
     std::vector<int32_t> drop_thr_host;
     // timing
     bool timing = false;
@@ -190,23 +193,24 @@ int flush_pending(bossx_engine *h) {
     ParsedBatch &pb = st.pb;
     const uint32_t n = uint32_t(pb.tiles.size());
     hipLaunchKernelGGL(tile_ref_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, st.d_tilerefs, n, h->d_tile_ref, 0);
-    if (pb.tile_first_op.empty()) {            // emit-order tiling is only needed on this path
-        build_emit_tiles(pb);
-        if (pb.tile_first_op.size() > st.tiles_cap) {
+    const uint32_t n_tiles = uint32_t((pb.total_emit + kEmitTile - 1) / kEmitTile);
+    if (!st.emit_tiles_built) {                // emit-order tiling is only needed on this path
+        if (size_t(n_tiles) + 1 > st.tiles_cap) {
             if (st.d_tiles) HIPCHK(hipFree(st.d_tiles));
             st.d_tiles = nullptr;
-            st.tiles_cap = pb.tile_first_op.size() * 9 / 8 + 64;
+            st.tiles_cap = (size_t(n_tiles) + 1) * 9 / 8 + 64;
             int rc = dev_alloc(h, &st.d_tiles, st.tiles_cap);
             if (rc) return rc;
         }
-        HIPCHK(hipMemcpy(st.d_tiles, pb.tile_first_op.data(), pb.tile_first_op.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(emit_tiles_kernel, dim3(n_tiles / 256 + 1), dim3(256), 0, h->stream, st.d_ops,
+                           uint32_t(pb.n_ops), n_tiles, st.d_tiles);
+        st.emit_tiles_built = true;
     }
-    const uint32_t n_tiles = uint32_t((pb.total_emit + kEmitTile - 1) / kEmitTile);
     time_begin(h, BOSSX_K_INGEST);
     hipLaunchKernelGGL(ingest_scatter_kernel, dim3(n_tiles), dim3(256), 0, h->stream, st.d_ops, st.d_tiles,
-                       uint32_t(pb.ops.size()), pb.total_emit, st.d_blob, reinterpret_cast<uint32_t *>(h->d_cov),
+                       uint32_t(pb.n_ops), pb.total_emit, st.d_blob, reinterpret_cast<uint32_t *>(h->d_cov),
                        h->d_touched, uint64_t(h->Gp / 2), h->d_err);
-    time_end(h, BOSSX_K_INGEST, 6.0 * double(pb.total_emit) + 16.0 * double(pb.ops.size()));
+    time_end(h, BOSSX_K_INGEST, 6.0 * double(pb.total_emit) + 16.0 * double(pb.n_ops));
     HIPCHK(hipGetLastError());
     h->pending_slot = -1;
     h->touched_dirty = true;
@@ -272,6 +276,7 @@ void bossx_destroy(bossx_engine *h) {
     if (h->d_tile_ref) hipFree(h->d_tile_ref);
     if (h->h_pin) hipHostFree(h->h_pin);
     if (h->h_blob_pin) hipHostFree(h->h_blob_pin);
+    if (h->h_ops_pin) hipHostFree(h->h_ops_pin);
     for (int k = 0; k < BOSSX_K_COUNT; ++k) { if (h->ev0[k]) hipEventDestroy(h->ev0[k]); if (h->ev1[k]) hipEventDestroy(h->ev1[k]); }
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
@@ -453,7 +458,18 @@ int bossx_stage_batch(bossx_engine *h, const char *paf, size_t paf_len, const ch
     if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "stage_batch before finalize");
     if (n_reads < 0 || (n_reads > 0 && (!names || !name_off || !seqs || !seq_off))) return fail(h, BOSSX_E_INVALID, "bad batch arrays");
     HIPCHK(hipSetDevice(h->cfg.device));
+    // the pinned run buffer may still feed the previous batch's upload
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t ops_need = ops_capacity_for(paf ? paf_len : 0);
+    if (ops_need > h->ops_pin_cap) {
+        if (h->h_ops_pin) HIPCHK(hipHostFree(h->h_ops_pin));
+        h->h_ops_pin = nullptr; h->ops_pin_cap = 0;
+        const size_t cap = ops_need * 5 / 4;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->h_ops_pin), cap * sizeof(EmitOp), hipHostMallocDefault));
+        h->ops_pin_cap = cap;
+    }
     ParseInput in{paf ? paf : "", paf ? paf_len : 0, names, name_off, seq_off, barcodes, n_reads, min_len, h->nb};
+    in.ops_buf = h->h_ops_pin; in.ops_cap = h->ops_pin_cap;
     ParsedBatch pb;
     std::string err;
     int rc = parse_paf_batch(in, h->contigs, h->index, summary, pb, err);
@@ -470,10 +486,11 @@ int bossx_stage_batch(bossx_engine *h, const char *paf, size_t paf_len, const ch
     }
     bossx_engine::Staged &st = h->slots[size_t(h->slot)];
     st.valid = false;
-    if (pb.ops.size() > st.ops_cap) {
+    st.emit_tiles_built = false;
+    if (pb.n_ops > st.ops_cap) {
         if (st.d_ops) HIPCHK(hipFree(st.d_ops));
         st.d_ops = nullptr;
-        st.ops_cap = pb.ops.size() * 9 / 8 + 1024;
+        st.ops_cap = pb.n_ops * 9 / 8 + 1024;
         if ((rc = dev_alloc(h, &st.d_ops, st.ops_cap))) return rc;
     }
     if (blob_bytes + 16 > st.blob_cap) {
@@ -494,10 +511,11 @@ int bossx_stage_batch(bossx_engine *h, const char *paf, size_t paf_len, const ch
         st.tilerefs_cap = pb.tiles.size() * 9 / 8 + 64;
         if ((rc = dev_alloc(h, &st.d_tilerefs, st.tilerefs_cap))) return rc;
     }
-    if (!pb.ops.empty()) {
+    if (pb.n_ops) {
         HIPCHK(hipMemcpyAsync(st.d_segs, pb.segs.data(), pb.segs.size() * sizeof(TileSeg), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(st.d_tilerefs, pb.tiles.data(), pb.tiles.size() * sizeof(TileRef), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(st.d_ops, pb.ops.data(), pb.ops.size() * sizeof(EmitOp), hipMemcpyHostToDevice, h->stream));
+        for (const OpsChunk &ck : pb.chunks)
+            HIPCHK(hipMemcpyAsync(st.d_ops + ck.dev_off, ck.host, ck.n * sizeof(EmitOp), hipMemcpyHostToDevice, h->stream));
         if (blob_bytes) HIPCHK(hipMemcpyAsync(st.d_blob, seqs, blob_bytes, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));   // inputs are borrowed for the call only
     }
@@ -531,7 +549,21 @@ int bossx_stage_batch_ptrs(bossx_engine *h, const char *paf, size_t paf_len, con
         h->blob_pin_cap = cap;
     }
     char *blob = static_cast<char *>(h->h_blob_pin);
-    for (int32_t i = 0; i < n_reads; ++i) memcpy(blob + seq_off[size_t(i)], seq_ptrs[i], size_t(seq_lens[i]));
+    {
+        // parallel gather, ranges balanced by bytes
+        const int nt = (blob_bytes > (size_t(1) << 20)) ? parse_threads() : 1;
+        auto gather = [&](int t) {
+            const size_t lo_b = blob_bytes * size_t(t) / size_t(nt), hi_b = blob_bytes * size_t(t + 1) / size_t(nt);
+            const int64_t *b = std::lower_bound(seq_off.data(), seq_off.data() + n_reads, int64_t(lo_b));
+            const int64_t *e = std::lower_bound(seq_off.data(), seq_off.data() + n_reads, int64_t(hi_b));
+            for (int32_t i = int32_t(b - seq_off.data()), ie = int32_t(e - seq_off.data()); i < ie; ++i)
+                memcpy(blob + seq_off[size_t(i)], seq_ptrs[i], size_t(seq_lens[i]));
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(gather, t);
+        gather(0);
+        for (auto &th : pool) th.join();
+    }
     return bossx_stage_batch(h, paf, paf_len, names.data(), name_off.data(), blob, seq_off.data(), barcodes, n_reads,
                              min_len, summary, n_rec, aligned_bases);
 }
@@ -577,7 +609,7 @@ int bossx_ingest_staged(bossx_engine *h) {
     HIPCHK(hipGetLastError());
     h->pending_slot = h->slot;
     h->pending_emit = double(pb.total_emit);
-    h->pending_ops = double(pb.ops.size());
+    h->pending_ops = double(pb.n_ops);
     return BOSSX_OK;
 }
 

@@ -64,11 +64,19 @@ struct TileRef {
     uint32_t pad;
 };
 
+// The emit runs are written by the parser's threads into the caller's buffer (ParseInput::
+// ops_buf) as one dense chunk per thread; on the device the chunks are laid back to back.
+struct OpsChunk {
+    const EmitOp *host;
+    size_t n;
+    size_t dev_off;           // index of the chunk's first run in the device array
+};
+
 struct ParsedBatch {
-    std::vector<EmitOp> ops;
-    std::vector<TileSeg> segs;             // grouped by tile (counting sort)
+    std::vector<OpsChunk> chunks;
+    size_t n_ops = 0;
+    std::vector<TileSeg> segs;             // grouped by tile; op_lo/op_hi are device indices
     std::vector<TileRef> tiles;            // touched tiles, ascending
-    std::vector<uint32_t> tile_first_op;   // emit-order tiles (fallback scatter only; build_emit_tiles)
     uint64_t total_emit = 0;
     std::vector<uint64_t> emitted_per_contig;   // indexed by contig add order
     int32_t n_rec = 0;
@@ -83,9 +91,13 @@ struct ParseInput {
     int32_t min_len;
     int32_t nbarcodes;
     bool summary_only = false;   // choose mappings and fill the summary, no CIGAR walk
+    EmitOp *ops_buf = nullptr;   // storage for the emit runs: ops_capacity_for(paf_len) entries
+    size_t ops_cap = 0;
+    int32_t n_threads = 0;       // 0: parse_threads()
 };
 
-void build_emit_tiles(ParsedBatch &pb);
+size_t ops_capacity_for(size_t paf_len);
+int parse_threads();             // BOSSX_PARSE_THREADS, default min(8, hardware threads)
 
 // Parses the PAF text, picks the best mapping per read and expands CIGARs into emit runs.
 // Returns BOSSX_OK or an error code with `err` filled.  Nothing is produced on error.

@@ -14,7 +14,21 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <climits>
+#include <cstdint>
 #include <string_view>
+#include <thread>
+
+#ifdef BOSSX_PARSE_TIMING
+#include <chrono>
+#include <cstdio>
+#define PT(x) auto x = std::chrono::steady_clock::now()
+#define PTMS(a, b) std::chrono::duration<double, std::milli>(b - a).count()
+#define PTREPORT() fprintf(stderr, "index+pass1 %.2f  plan %.2f  walk %.2f  merge %.2f ms\n", PTMS(T0, T1), PTMS(T1, T2), PTMS(T2, T3), PTMS(T3, T4))
+#else
+#define PT(x)
+#define PTREPORT()
+#endif
 
 namespace bossx {
 namespace {
@@ -73,9 +87,198 @@ constexpr CigarTable kCigarOp{};
 
 }  // namespace
 
+namespace {
+
+struct LineOut {
+    std::vector<Rec> recs;       // records that pass the min_len / primary filters, line order
+    int64_t n_lines = 0;
+    int64_t err_line = 0;        // 1-based within the range, 0 = none
+    std::string err_msg;
+};
+
+// Paf.parse_PAF / PafLine.__init__ over the lines of [p, end) (paf.py:18-75, 631-672).
+void parse_lines(const char *p, const char *end, int64_t min_len, LineOut &lo) {
+    std::vector<std::string_view> f;
+    auto fail = [&](const char *msg) { lo.err_line = lo.n_lines; lo.err_msg = msg; };
+    while (p < end) {
+        const char *nl = static_cast<const char *>(memchr(p, '\n', size_t(end - p)));
+        const char *le = nl ? nl : end;
+        std::string_view line = strip(std::string_view(p, size_t(le - p)));
+        p = nl ? nl + 1 : end;
+        ++lo.n_lines;
+        if (line.empty()) continue;
+        f.clear();
+        size_t s = 0;
+        while (true) {
+            size_t t = line.find('\t', s);
+            if (t == std::string_view::npos) { f.push_back(line.substr(s)); break; }
+            f.push_back(line.substr(s, t - s));
+            s = t + 1;
+        }
+        if (f.size() < 12) return fail(": fewer than 12 columns");
+        Rec r;
+        int64_t tlen, nmatch;
+        bool ok = parse_int(f[1], r.qlen) && parse_int(f[2], r.qstart) && parse_int(f[3], r.qend) &&
+                  parse_int(f[6], tlen) && parse_int(f[7], r.tstart) && parse_int(f[8], r.tend) &&
+                  parse_int(f[9], nmatch) && parse_int(f[10], r.alnlen) && parse_int(f[11], r.mapq);
+        if (!ok) return fail(": non-integer core column");
+        r.rev = !(f[4].size() == 1 && f[4][0] == '+');   // paf.py:58
+        r.as = 0; r.has_cg = false; r.cg = nullptr; r.cg_len = 0;
+        bool primary = false;
+        for (size_t k = 12; k < f.size(); ++k) {
+            std::string_view tag = f[k];
+            size_t c1 = tag.find(':');
+            size_t c2 = c1 == std::string_view::npos ? c1 : tag.find(':', c1 + 1);
+            if (c1 == std::string_view::npos || c2 == std::string_view::npos ||
+                tag.find(':', c2 + 1) != std::string_view::npos)
+                return fail(": malformed tag");   // x.split(':') unpack
+            std::string_view key = tag.substr(0, c1), val = tag.substr(c2 + 1);
+            if (key == "AS") {
+                if (!parse_int(val, r.as)) return fail(": AS is not an integer");
+            } else if (key == "cg") {
+                r.has_cg = true; r.cg = val.data(); r.cg_len = val.size();
+            } else if (key == "tp") {
+                primary = (val == "P");
+            }
+        }
+        if (r.alnlen < min_len) continue;     // paf.py:666-667
+        if (!primary) continue;               // paf.py:668-669
+        r.qname = normalise_name(f[0]);
+        r.tname = normalise_name(f[5]);
+        lo.recs.push_back(std::move(r));
+    }
+}
+
+// One chosen mapping, resolved against the batch and the contig table (sequential pre-pass).
+struct Plan {
+    const Rec *rec;
+    int32_t read, cidx, bc;
+    uint64_t emit0;          // index of its first emitted base in the batch-wide emit order
+    size_t ops_at;           // where its emit runs start in the caller's buffer (upper-bound spacing)
+};
+
+struct WalkError {
+    int64_t group = INT64_MAX;
+    int code = BOSSX_OK;
+    std::string msg;
+};
+
+struct WalkOut {
+    const EmitOp *base = nullptr;
+    size_t n_ops = 0;                      // runs written, contiguous from `base`
+    std::vector<TileSeg> segs;             // op_lo / op_hi relative to the thread's base
+    std::vector<uint32_t> seg_tile;
+    std::vector<uint64_t> emitted_per_contig;
+    WalkError err;
+};
+
+// CIGAR walk of plans [p0, p1): emit runs written densely from `base`, tile segments collected.
+void walk_plans(const ParseInput &in, const std::vector<ContigInfo> &contigs, const std::vector<Plan> &plans,
+                size_t p0, size_t p1, EmitOp *base, WalkOut &wo) {
+    wo.emitted_per_contig.assign(contigs.size(), 0);
+    wo.base = base;
+    EmitOp *w = base;
+    for (size_t pi = p0; pi < p1; ++pi) {
+        const Plan &pl = plans[pi];
+        if (pl.cidx < 0) continue;           // ignored contig (pre-pass marks it)
+        const Rec &r = *pl.rec;
+        auto fail = [&](int code, std::string msg) { wo.err.group = int64_t(pi); wo.err.code = code; wo.err.msg = std::move(msg); };
+        const ContigInfo &c = contigs[size_t(pl.cidx)];
+        const int64_t seq_b = in.seq_off[pl.read], seq_len = in.seq_off[pl.read + 1] - seq_b;
+        const int64_t tlo = r.tstart < r.tend ? r.tstart : r.tend;
+        const int64_t thi = r.tstart < r.tend ? r.tend : r.tstart;
+        // query walk: '+' reads seq[qstart + i]; '-' reads comp(seq[len-1-(qlen-qend) - i])
+        // (sequences.py:707-716: slice [qlen-qend, qlen-qstart) of the reverse complement)
+        int64_t q = r.rev ? (seq_len - 1 - (r.qlen - r.qend)) : r.qstart;
+        const int64_t qstep = r.rev ? -1 : 1;
+        const int64_t q_need = r.qend - r.qstart;
+        int64_t consumed = 0, ref_pos = tlo;
+        uint64_t cur_emit = pl.emit0;
+        EmitOp *const first = w;
+        const uint32_t meta_base = (uint32_t(pl.bc) << 8) | (r.rev ? kOpRev : 0u);
+        const char *cp = r.cg, *ce = r.cg + r.cg_len;
+        while (cp < ce) {
+            int64_t len = 0;
+            const char *d0 = cp;
+            unsigned d;
+            while (cp < ce && (d = unsigned(*cp) - unsigned('0')) < 10u) { len = len * 10 + int64_t(d); ++cp; }
+            if (cp == d0 || cp >= ce) return fail(BOSSX_E_PARSE, "read '" + r.qname + "': malformed CIGAR");
+            const char op = *cp++;
+            if (!kCigarOp[static_cast<unsigned char>(op)]) return fail(BOSSX_E_PARSE, "read '" + r.qname + "': unknown CIGAR op");
+            if (len == 0) continue;
+            if (op == 'I') {                       // consumes query, emits nothing (sequences.py:781)
+                consumed += len; q += qstep * len;
+                continue;
+            }
+            const bool del = (op == 'D');          // emits code 4, consumes nothing (sequences.py:782,793)
+            if (!del) {
+                const int64_t q_last = q + qstep * (len - 1);
+                if (q < 0 || q >= seq_len || q_last < 0 || q_last >= seq_len)
+                    return fail(BOSSX_E_PARSE, "read '" + r.qname + "': CIGAR walks outside the read");   // shape mismatch in cig_rep[notdel] = int_seq[start:end]
+            }
+            if (ref_pos + len > c.length)
+                return fail(BOSSX_E_RANGE, "read '" + r.qname + "': mapping extends past the end of " + c.name);
+            const uint64_t site = uint64_t(c.site_off + ref_pos);
+            w->emit_start = uint32_t(cur_emit);
+            w->site_lo = uint32_t(site & 0xffffffffu);
+            w->qpos = del ? 0u : uint32_t(seq_b + q);
+            w->meta = uint32_t((site >> 32) & 0xffu) | meta_base | (del ? kOpDel : 0u);
+            ++w;
+            cur_emit += uint64_t(len);
+            ref_pos += len;
+            if (!del) { consumed += len; q += qstep * len; }
+        }
+        if (consumed != q_need)
+            return fail(BOSSX_E_PARSE, "read '" + r.qname + "': CIGAR consumes " + std::to_string(consumed) +
+                                       " query bases, PAF says " + std::to_string(q_need));
+        if (ref_pos - tlo != thi - tlo)
+            return fail(BOSSX_E_PARSE, "read '" + r.qname + "': CIGAR spans " + std::to_string(ref_pos - tlo) +
+                                       " reference bases, PAF says " + std::to_string(thi - tlo));   // sequences.py:732
+        wo.emitted_per_contig[size_t(pl.cidx)] += uint64_t(thi - tlo);
+        // split the read's emitted stretch at sweep-tile boundaries (padded site space)
+        if (w > first) {
+            const uint64_t site0 = uint64_t(c.site_off + tlo);
+            const uint64_t site1 = uint64_t(c.site_off + thi);
+            const uint64_t e0 = pl.emit0;
+            const EmitOp *op = first, *const last = w - 1;
+            for (uint64_t t = site0 / kTileSites; t * kTileSites < site1; ++t) {
+                const uint64_t s_lo = std::max<uint64_t>(t * kTileSites, site0);
+                const uint64_t s_hi = std::min<uint64_t>((t + 1) * kTileSites, site1);
+                // pieces of at most kSegMax emitted bases, each with its exact emit-run range
+                for (uint64_t p_lo = s_lo; p_lo < s_hi; p_lo += kSegMax) {
+                    const uint64_t p_hi = std::min<uint64_t>(p_lo + kSegMax, s_hi);
+                    TileSeg sg;
+                    sg.e_lo = uint32_t(e0 + (p_lo - site0));
+                    sg.e_hi = uint32_t(e0 + (p_hi - site0));
+                    // emit_start is compared modulo 2^32 only within one read (< 2^32 bases)
+                    while (op < last && uint32_t(op[1].emit_start - uint32_t(e0)) <= uint32_t(sg.e_lo - uint32_t(e0))) ++op;
+                    sg.op_lo = uint32_t(op - base);
+                    const EmitOp *oh = op;
+                    while (oh < last && uint32_t(oh[1].emit_start - uint32_t(e0)) < uint32_t(sg.e_hi - uint32_t(e0))) ++oh;
+                    sg.op_hi = uint32_t(oh - base);
+                    wo.segs.push_back(sg);
+                    wo.seg_tile.push_back(uint32_t(t));
+                }
+            }
+        }
+    }
+    wo.n_ops = size_t(w - base);
+}
+
+}  // namespace
+
+size_t ops_capacity_for(size_t paf_len) { return paf_len / 2 + paf_len / 16 + 64; }
+
+int parse_threads() {
+    if (const char *e = getenv("BOSSX_PARSE_THREADS")) { const int v = atoi(e); if (v >= 1) return std::min(v, 64); }
+    const unsigned hc = std::thread::hardware_concurrency();
+    return int(std::max(1u, std::min(hc ? hc : 1u, 16u)));
+}
+
 int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs,
                     const std::unordered_map<std::string, int32_t> &contig_index,
                     bossx_batch_summary *summary, ParsedBatch &out, std::string &err) {
+    PT(T0);
     out = ParsedBatch();
     out.emitted_per_contig.assign(contigs.size(), 0);
 
@@ -87,93 +290,74 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         read_index[nm] = i;   // later duplicates win, like a dict
     }
 
-    // ---- pass 1: lines -> best record per query name, first-appearance order -------------
+    // ---- pass 1 (threads over line ranges): lines -> filtered records, in line order; then the
+    // best record per query name, groups in first-appearance order --------------------------
     std::vector<Group> groups;
-    std::unordered_map<std::string, int32_t> group_of;
-    const char *p = in.paf, *end = in.paf + in.paf_len;
-    int64_t lineno = 0;
-    std::vector<std::string_view> f;
-    while (p < end) {
-        const char *nl = static_cast<const char *>(memchr(p, '\n', size_t(end - p)));
-        const char *le = nl ? nl : end;
-        std::string_view line = strip(std::string_view(p, size_t(le - p)));
-        p = nl ? nl + 1 : end;
-        ++lineno;
-        if (line.empty()) continue;
-        f.clear();
-        size_t s = 0;
-        while (true) {
-            size_t t = line.find('\t', s);
-            if (t == std::string_view::npos) { f.push_back(line.substr(s)); break; }
-            f.push_back(line.substr(s, t - s));
-            s = t + 1;
+    {
+        int nt = in.n_threads > 0 ? in.n_threads : parse_threads();
+        if (in.paf_len < (size_t(1) << 16)) nt = 1;
+        std::vector<const char *> cuts(size_t(nt) + 1, in.paf + in.paf_len);
+        cuts[0] = in.paf;
+        for (int t = 1; t < nt; ++t) {
+            const char *c = in.paf + in.paf_len * size_t(t) / size_t(nt);
+            if (c < cuts[size_t(t) - 1]) c = cuts[size_t(t) - 1];
+            const char *nl = static_cast<const char *>(memchr(c, '\n', size_t(in.paf + in.paf_len - c)));
+            cuts[size_t(t)] = nl ? nl + 1 : in.paf + in.paf_len;
         }
-        if (f.size() < 12) {
-            err = "PAF line " + std::to_string(lineno) + ": fewer than 12 columns";
-            return BOSSX_E_PARSE;
+        std::vector<LineOut> los(static_cast<size_t>(nt));
+        auto work = [&](int t) { parse_lines(cuts[size_t(t)], cuts[size_t(t) + 1], in.min_len, los[size_t(t)]); };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto &th : pool) th.join();
+        int64_t line_base = 0;
+        for (const LineOut &lo : los) {          // first failing line in file order
+            if (lo.err_line) { err = "PAF line " + std::to_string(line_base + lo.err_line) + lo.err_msg; return BOSSX_E_PARSE; }
+            line_base += lo.n_lines;
         }
-        Rec r;
-        int64_t tlen, nmatch;
-        bool ok = parse_int(f[1], r.qlen) && parse_int(f[2], r.qstart) && parse_int(f[3], r.qend) &&
-                  parse_int(f[6], tlen) && parse_int(f[7], r.tstart) && parse_int(f[8], r.tend) &&
-                  parse_int(f[9], nmatch) && parse_int(f[10], r.alnlen) && parse_int(f[11], r.mapq);
-        if (!ok) {
-            err = "PAF line " + std::to_string(lineno) + ": non-integer core column";
-            return BOSSX_E_PARSE;
-        }
-        r.rev = !(f[4].size() == 1 && f[4][0] == '+');   // paf.py:58
-        r.as = 0; r.has_cg = false; r.cg = nullptr; r.cg_len = 0;
-        bool primary = false;
-        for (size_t k = 12; k < f.size(); ++k) {
-            std::string_view tag = f[k];
-            size_t c1 = tag.find(':');
-            size_t c2 = c1 == std::string_view::npos ? c1 : tag.find(':', c1 + 1);
-            if (c1 == std::string_view::npos || c2 == std::string_view::npos ||
-                tag.find(':', c2 + 1) != std::string_view::npos) {
-                err = "PAF line " + std::to_string(lineno) + ": malformed tag";   // x.split(':') unpack
-                return BOSSX_E_PARSE;
-            }
-            std::string_view key = tag.substr(0, c1), val = tag.substr(c2 + 1);
-            if (key == "AS") {
-                if (!parse_int(val, r.as)) {
-                    err = "PAF line " + std::to_string(lineno) + ": AS is not an integer";
-                    return BOSSX_E_PARSE;
+        std::unordered_map<std::string_view, int32_t> group_of;
+        size_t n_recs = 0;
+        for (const LineOut &lo : los) n_recs += lo.recs.size();
+        group_of.reserve(n_recs * 2 + 1);
+        groups.reserve(n_recs);
+        for (LineOut &lo : los) {
+            for (Rec &r : lo.recs) {
+                auto it = group_of.find(std::string_view(r.qname));
+                if (it == group_of.end()) {
+                    groups.push_back(Group{std::move(r), r.mapq, r.as});
+                    group_of.emplace(std::string_view(groups.back().best.qname), int32_t(groups.size() - 1));
+                } else {
+                    Group &g = groups[size_t(it->second)];
+                    // argsort by (mapq, AS), last element wins; stable for ties (paf.py:716-721)
+                    if (r.mapq > g.key_q || (r.mapq == g.key_q && r.as >= g.key_dp)) {
+                        g.key_q = r.mapq; g.key_dp = r.as;
+                        std::string keep = std::move(g.best.qname);     // the map's key views this buffer
+                        g.best = std::move(r);
+                        g.best.qname = std::move(keep);
+                    }
                 }
-            } else if (key == "cg") {
-                r.has_cg = true; r.cg = val.data(); r.cg_len = val.size();
-            } else if (key == "tp") {
-                primary = (val == "P");
-            }
-        }
-        if (r.alnlen < in.min_len) continue;     // paf.py:666-667
-        if (!primary) continue;                   // paf.py:668-669
-        r.qname = normalise_name(f[0]);
-        r.tname = normalise_name(f[5]);
-        auto it = group_of.find(r.qname);
-        if (it == group_of.end()) {
-            group_of.emplace(r.qname, int32_t(groups.size()));
-            groups.push_back(Group{r, r.mapq, r.as});
-        } else {
-            Group &g = groups[size_t(it->second)];
-            // argsort by (mapq, AS), last element wins; stable for ties (paf.py:716-721)
-            if (r.mapq > g.key_q || (r.mapq == g.key_q && r.as >= g.key_dp)) {
-                g.best = r; g.key_q = r.mapq; g.key_dp = r.as;
             }
         }
     }
 
-    // ---- pass 2: chosen mappings -> emit runs ------------------------------------------------
+    PT(T1);
+    // ---- pass 2a (sequential, O(#reads)): resolve every chosen mapping, fill the summary, lay
+    // out the emit order.  A failing record stops the pre-pass; records before it are still
+    // walked so that the first failure in record order is the one reported (the reference
+    // raises inside its per-record loop, sequences.py:700-735).
+    std::vector<Plan> plans;
+    plans.reserve(groups.size());
+    WalkError pre_err;
     uint64_t cur_emit = 0;
-    out.ops.reserve(in.paf_len / 3 + 16);
-    std::vector<TileSeg> raw_segs;
-    std::vector<uint32_t> raw_tile;
+    size_t ops_at = 0;
     int32_t n_rec = 0;
-    for (const Group &g : groups) {
-        const Rec &r = g.best;
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        const Rec &r = groups[gi].best;
+        auto pre_fail = [&](int code, std::string msg) { pre_err.group = int64_t(gi); pre_err.code = code; pre_err.msg = std::move(msg); };
         auto ri = read_index.find(std::string_view(r.qname));
         if (ri == read_index.end()) {
-            err = "read '" + r.qname + "' is mapped in the PAF but absent from the batch";
-            return BOSSX_E_KEY;       // seqs[rec.qname], sequences.py:708/713
+            pre_fail(BOSSX_E_KEY, "read '" + r.qname + "' is mapped in the PAF but absent from the batch");
+            break;                      // seqs[rec.qname], sequences.py:708/713
         }
         const int32_t read = ri->second;
         int32_t cidx = -1;
@@ -190,142 +374,220 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         ++n_rec;
         if (in.summary_only) continue;
         if (!r.has_cg) {
-            err = "read '" + r.qname + "': mapping without cg tag";   // assert rec.cigar is not None
-            return BOSSX_E_PARSE;
+            pre_fail(BOSSX_E_PARSE, "read '" + r.qname + "': mapping without cg tag");   // assert rec.cigar is not None
+            break;
         }
-        if (cidx < 0 || contigs[size_t(cidx)].rejected || contigs[size_t(cidx)].remote) continue;   // core.py:83-86: only (local) contigs_filt
-        const ContigInfo &c = contigs[size_t(cidx)];
-        const int64_t seq_b = in.seq_off[read], seq_len = in.seq_off[read + 1] - seq_b;
-        const int64_t tlo = r.tstart < r.tend ? r.tstart : r.tend;
-        const int64_t thi = r.tstart < r.tend ? r.tend : r.tstart;
-        int32_t bc = in.barcodes ? in.barcodes[read] : 0;
-        if (bc < 0 || bc >= in.nbarcodes) {
-            err = "read '" + r.qname + "': barcode index out of range";
-            return BOSSX_E_RANGE;
+        Plan pl{&r, read, cidx, 0, cur_emit, ops_at};
+        if (cidx < 0 || contigs[size_t(cidx)].rejected || contigs[size_t(cidx)].remote) {
+            pl.cidx = -1;               // core.py:83-86: only (local) contigs_filt receive coverage
+        } else {
+            pl.bc = in.barcodes ? in.barcodes[read] : 0;
+            if (pl.bc < 0 || pl.bc >= in.nbarcodes) {
+                pre_fail(BOSSX_E_RANGE, "read '" + r.qname + "': barcode index out of range");
+                break;
+            }
+            const int64_t span = r.tstart < r.tend ? r.tend - r.tstart : r.tstart - r.tend;
+            cur_emit += uint64_t(span);
+            ops_at += r.cg_len / 2 + 1;           // every run is at least one digit + one letter
         }
-        // query walk: '+' reads seq[qstart + i]; '-' reads comp(seq[len-1-(qlen-qend) - i])
-        // (sequences.py:707-716: slice [qlen-qend, qlen-qstart) of the reverse complement)
-        int64_t q = r.rev ? (seq_len - 1 - (r.qlen - r.qend)) : r.qstart;
-        const int64_t qstep = r.rev ? -1 : 1;
-        const int64_t q_need = r.qend - r.qstart;
-        int64_t consumed = 0, ref_pos = tlo;
-        const size_t first_op = out.ops.size();
-        const char *cp = r.cg, *ce = r.cg + r.cg_len;
-        while (cp < ce) {
-            int64_t len = 0;
-            const char *d0 = cp;
-            while (cp < ce && *cp >= '0' && *cp <= '9') { len = len * 10 + (*cp - '0'); ++cp; }
-            if (cp == d0 || cp >= ce) {
-                err = "read '" + r.qname + "': malformed CIGAR";
-                return BOSSX_E_PARSE;
-            }
-            const char op = *cp++;
-            if (!kCigarOp[static_cast<unsigned char>(op)]) {
-                err = "read '" + r.qname + "': unknown CIGAR op";
-                return BOSSX_E_PARSE;
-            }
-            if (len == 0) continue;
-            if (op == 'I') {                       // consumes query, emits nothing (sequences.py:781)
-                consumed += len; q += qstep * len;
-                continue;
-            }
-            const bool del = (op == 'D');          // emits code 4, consumes nothing (sequences.py:782,793)
-            if (!del) {
-                const int64_t q_last = q + qstep * (len - 1);
-                if (q < 0 || q >= seq_len || q_last < 0 || q_last >= seq_len) {
-                    err = "read '" + r.qname + "': CIGAR walks outside the read";
-                    return BOSSX_E_PARSE;       // shape mismatch in cig_rep[notdel] = int_seq[start:end]
-                }
-            }
-            if (ref_pos + len > c.length) {
-                err = "read '" + r.qname + "': mapping extends past the end of " + c.name;
-                return BOSSX_E_RANGE;
-            }
-            const uint64_t site = uint64_t(c.site_off + ref_pos);
-            EmitOp e;
-            e.emit_start = uint32_t(cur_emit);
-            e.site_lo = uint32_t(site & 0xffffffffu);
-            e.qpos = del ? 0u : uint32_t(seq_b + q);
-            e.meta = uint32_t((site >> 32) & 0xffu) | (uint32_t(bc) << 8) | (r.rev ? kOpRev : 0u) |
-                     (del ? kOpDel : 0u);
-            out.ops.push_back(e);
-            cur_emit += uint64_t(len);
-            ref_pos += len;
-            if (!del) { consumed += len; q += qstep * len; }
-        }
-        if (consumed != q_need) {
-            err = "read '" + r.qname + "': CIGAR consumes " + std::to_string(consumed) +
-                  " query bases, PAF says " + std::to_string(q_need);
-            out.ops.resize(first_op);
-            return BOSSX_E_PARSE;
-        }
-        if (ref_pos - tlo != thi - tlo) {
-            err = "read '" + r.qname + "': CIGAR spans " + std::to_string(ref_pos - tlo) +
-                  " reference bases, PAF says " + std::to_string(thi - tlo);   // sequences.py:732
-            return BOSSX_E_PARSE;
-        }
-        out.emitted_per_contig[size_t(cidx)] += uint64_t(thi - tlo);
-        // split the read's emitted stretch at sweep-tile boundaries (padded site space)
-        if (out.ops.size() > first_op) {
-            const uint64_t site0 = uint64_t(c.site_off + tlo);
-            const uint64_t site1 = uint64_t(c.site_off + thi);
-            const uint64_t e0 = out.ops[first_op].emit_start;
-            size_t op = first_op;
-            for (uint64_t t = site0 / kTileSites; t * kTileSites < site1; ++t) {
-                const uint64_t s_lo = std::max<uint64_t>(t * kTileSites, site0);
-                const uint64_t s_hi = std::min<uint64_t>((t + 1) * kTileSites, site1);
-                // pieces of at most kSegMax emitted bases, each with its exact emit-run range
-                for (uint64_t p_lo = s_lo; p_lo < s_hi; p_lo += kSegMax) {
-                    const uint64_t p_hi = std::min<uint64_t>(p_lo + kSegMax, s_hi);
-                    TileSeg sg;
-                    sg.e_lo = uint32_t(e0 + (p_lo - site0));
-                    sg.e_hi = uint32_t(e0 + (p_hi - site0));
-                    while (op + 1 < out.ops.size() && out.ops[op + 1].emit_start <= sg.e_lo) ++op;
-                    sg.op_lo = uint32_t(op);
-                    size_t oh = op;
-                    while (oh + 1 < out.ops.size() && out.ops[oh + 1].emit_start < sg.e_hi) ++oh;
-                    sg.op_hi = uint32_t(oh);
-                    raw_segs.push_back(sg);
-                    raw_tile.push_back(uint32_t(t));
-                }
-            }
-        }
+        plans.push_back(pl);
     }
-    // group segments by tile (stable sort of the small tile-id list)
-    {
-        std::vector<uint32_t> order(raw_segs.size());
-        for (size_t i = 0; i < order.size(); ++i) order[i] = uint32_t(i);
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return raw_tile[a] < raw_tile[b]; });
-        out.segs.reserve(order.size());
-        for (uint32_t idx : order) {
-            const uint32_t t = raw_tile[idx];
-            if (out.tiles.empty() || out.tiles.back().tile != t)
-                out.tiles.push_back(TileRef{t, uint32_t(out.segs.size()), uint32_t(out.segs.size()), 0});
-            out.segs.push_back(raw_segs[idx]);
-            out.tiles.back().seg_hi = uint32_t(out.segs.size());
+
+    PT(T2);
+    // ---- pass 2b (threads over contiguous record ranges): CIGAR walk -> emit runs + segments ----
+    std::vector<WalkOut> wos;
+    if (!in.summary_only && !plans.empty()) {
+        if (!in.ops_buf || in.ops_cap < ops_at + 1) {
+            err = "internal: emit-run buffer too small";
+            return BOSSX_E_INVALID;
         }
+        int nt = in.n_threads > 0 ? in.n_threads : parse_threads();
+        if (plans.size() < 256) nt = 1;
+        nt = int(std::min<size_t>(size_t(nt), plans.size()));
+        // balance by CIGAR bytes (ops_at is their running upper bound)
+        std::vector<size_t> cut(size_t(nt) + 1, plans.size());
+        cut[0] = 0;
+        for (int t = 1; t < nt; ++t) {
+            const size_t want = ops_at * size_t(t) / size_t(nt);
+            size_t lo = cut[size_t(t) - 1], hi = plans.size();
+            while (lo < hi) { const size_t mid = (lo + hi) / 2; if (plans[mid].ops_at < want) lo = mid + 1; else hi = mid; }
+            cut[size_t(t)] = lo;
+        }
+        wos.resize(size_t(nt));
+        auto work = [&](int t) {
+            const size_t p0 = cut[size_t(t)], p1 = cut[size_t(t) + 1];
+            EmitOp *base = in.ops_buf + (p0 < plans.size() ? plans[p0].ops_at : ops_at);
+            walk_plans(in, contigs, plans, p0, p1, base, wos[size_t(t)]);
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto &th : pool) th.join();
     }
+    PT(T3);
+    // first failure in record order
+    const WalkError *first_err = pre_err.code ? &pre_err : nullptr;
+    for (const WalkOut &wo : wos)
+        if (wo.err.code && (!first_err || wo.err.group < first_err->group)) first_err = &wo.err;
+    if (first_err) { err = first_err->msg; return first_err->code; }
     if (cur_emit >= (1ull << 32) - kEmitTile) {
         err = "batch too large: more than 2^32 aligned bases";
         return BOSSX_E_RANGE;
     }
+
+    // ---- merge: device positions of the chunks, segments grouped by tile (stable) ------------
+    size_t n_segs = 0, dev_off = 0;
+    for (const WalkOut &wo : wos) n_segs += wo.segs.size();
+    std::vector<uint32_t> tile_of, order, tmp;
+    tile_of.reserve(n_segs);
+    std::vector<const TileSeg *> seg_ptr;
+    seg_ptr.reserve(n_segs);
+    std::vector<uint32_t> seg_base;
+    seg_base.reserve(n_segs);
+    uint32_t max_tile = 0;
+    for (WalkOut &wo : wos) {
+        if (wo.n_ops) out.chunks.push_back(OpsChunk{wo.base, wo.n_ops, dev_off});
+        for (size_t i = 0; i < wo.segs.size(); ++i) {
+            tile_of.push_back(wo.seg_tile[i]);
+            max_tile = std::max(max_tile, wo.seg_tile[i]);
+            seg_ptr.push_back(&wo.segs[i]);
+            seg_base.push_back(uint32_t(dev_off));
+        }
+        for (size_t c = 0; c < contigs.size(); ++c) out.emitted_per_contig[c] += wo.emitted_per_contig[c];
+        dev_off += wo.n_ops;
+    }
+    out.n_ops = dev_off;
+    // stable LSD radix sort of the segment indices by tile id, 11 bits per pass
+    order.resize(n_segs);
+    for (size_t i = 0; i < n_segs; ++i) order[i] = uint32_t(i);
+    tmp.resize(n_segs);
+    for (uint32_t shift = 0; shift < 32 && (max_tile >> shift) != 0; shift += 11) {
+        uint32_t count[2049] = {0};
+        for (size_t i = 0; i < n_segs; ++i) ++count[((tile_of[order[i]] >> shift) & 2047u) + 1];
+        for (int b = 0; b < 2048; ++b) count[b + 1] += count[b];
+        for (size_t i = 0; i < n_segs; ++i) tmp[count[(tile_of[order[i]] >> shift) & 2047u]++] = order[i];
+        order.swap(tmp);
+    }
+    out.segs.reserve(n_segs);
+    for (uint32_t idx : order) {
+        const uint32_t t = tile_of[idx];
+        if (out.tiles.empty() || out.tiles.back().tile != t)
+            out.tiles.push_back(TileRef{t, uint32_t(out.segs.size()), uint32_t(out.segs.size()), 0});
+        TileSeg sg = *seg_ptr[idx];
+        sg.op_lo += seg_base[idx]; sg.op_hi += seg_base[idx];
+        out.segs.push_back(sg);
+        out.tiles.back().seg_hi = uint32_t(out.segs.size());
+    }
+    PT(T4);
+    PTREPORT();
     out.total_emit = cur_emit;
     out.n_rec = n_rec;
     return BOSSX_OK;
 }
 
-// Emit-order tiling for the fallback scatter kernel: tile t -> the run that holds element
-// t * kEmitTile (built on demand; the normal path bins by sweep tile instead).
-void build_emit_tiles(ParsedBatch &pb) {
-    const size_t n_tiles = size_t((pb.total_emit + kEmitTile - 1) / kEmitTile);
-    pb.tile_first_op.assign(n_tiles + 1, 0);
-    size_t op = 0;
-    for (size_t t = 0; t < n_tiles; ++t) {
-        const uint64_t e = uint64_t(t) * kEmitTile;
-        while (op + 1 < pb.ops.size() && pb.ops[op + 1].emit_start <= e) ++op;
-        pb.tile_first_op[t] = uint32_t(op);
-    }
-    pb.tile_first_op[n_tiles] = pb.ops.empty() ? 0u : uint32_t(pb.ops.size() - 1);
-}
-
 }  // namespace bossx
+
+// ------------------------------------------------------------------------------------------
+// Host-only check entry (include/bossx.h): the front end without a device.  Parses like
+// bossx_stage_batch_ptrs and expands the emit runs base by base exactly as the ingest kernels
+// read them, so CPU tests can compare the parser (and its thread partition) with the oracle.
+// ------------------------------------------------------------------------------------------
+extern "C" int bossx_host_parse(const char *const *contig_names, const int64_t *contig_lengths,
+                                const int32_t *contig_flags, int32_t n_contigs, int32_t nbarcodes,
+                                const char *paf, size_t paf_len, const char *const *name_ptrs,
+                                const int64_t *name_lens, const char *const *seq_ptrs, const int64_t *seq_lens,
+                                const int32_t *barcodes, int32_t n_reads, int32_t min_len, int32_t n_threads,
+                                bossx_batch_summary *summary, int32_t *n_rec, int64_t *aligned_bases,
+                                int32_t *out_contig, int64_t *out_pos, uint8_t *out_code, uint8_t *out_barcode,
+                                int64_t out_cap, char *err_buf, size_t err_cap) {
+    using namespace bossx;
+    auto fail = [&](int code, const std::string &msg) {
+        if (err_buf && err_cap) { strncpy(err_buf, msg.c_str(), err_cap - 1); err_buf[err_cap - 1] = '\0'; }
+        return code;
+    };
+    if (n_contigs < 0 || n_reads < 0 || nbarcodes < 1) return fail(BOSSX_E_INVALID, "bad host_parse call");
+    std::vector<ContigInfo> contigs(static_cast<size_t>(n_contigs));
+    std::unordered_map<std::string, int32_t> index;
+    int64_t site = 0;
+    for (int32_t i = 0; i < n_contigs; ++i) {
+        ContigInfo &c = contigs[size_t(i)];
+        c.name = contig_names[i]; c.length = contig_lengths[i];
+        c.rejected = (contig_flags[i] & BOSSX_CONTIG_REJECTED) != 0;
+        c.remote = (contig_flags[i] & BOSSX_CONTIG_REMOTE) != 0;
+        index[c.name] = i;
+        if (c.rejected || c.remote) continue;
+        c.site_off = site;
+        c.n_tiles = (c.length + kTileSites - 1) / kTileSites;
+        site += c.n_tiles * kTileSites;
+    }
+    std::vector<int64_t> name_off(size_t(n_reads) + 1, 0), seq_off(size_t(n_reads) + 1, 0);
+    for (int32_t i = 0; i < n_reads; ++i) {
+        name_off[size_t(i) + 1] = name_off[size_t(i)] + name_lens[i];
+        seq_off[size_t(i) + 1] = seq_off[size_t(i)] + seq_lens[i];
+    }
+    std::string names(size_t(name_off[size_t(n_reads)]), '\0'), blob(size_t(seq_off[size_t(n_reads)]), '\0');
+    for (int32_t i = 0; i < n_reads; ++i) {
+        memcpy(&names[size_t(name_off[size_t(i)])], name_ptrs[i], size_t(name_lens[i]));
+        memcpy(&blob[size_t(seq_off[size_t(i)])], seq_ptrs[i], size_t(seq_lens[i]));
+    }
+    std::vector<EmitOp> buf(ops_capacity_for(paf ? paf_len : 0));
+    ParseInput in{paf ? paf : "", paf ? paf_len : 0, names.data(), name_off.data(), seq_off.data(), barcodes, n_reads, min_len, nbarcodes};
+    in.ops_buf = buf.data(); in.ops_cap = buf.size(); in.n_threads = n_threads;
+    ParsedBatch pb;
+    std::string err;
+    int rc = parse_paf_batch(in, contigs, index, summary, pb, err);
+    if (rc) return fail(rc, err);
+    if (n_rec) *n_rec = pb.n_rec;
+    if (aligned_bases) *aligned_bases = int64_t(pb.total_emit);
+    // the device array: chunks back to back
+    std::vector<EmitOp> ops(pb.n_ops);
+    for (const OpsChunk &ck : pb.chunks) memcpy(ops.data() + ck.dev_off, ck.host, ck.n * sizeof(EmitOp));
+    for (size_t i = 1; i < ops.size(); ++i)
+        if (ops[i].emit_start <= ops[i - 1].emit_start) return fail(BOSSX_E_INVALID, "emit runs are not strictly increasing");
+    // segments: every emitted base exactly once, inside its tile, inside its run range
+    uint64_t seg_total = 0;
+    for (const TileRef &tr : pb.tiles) {
+        for (uint32_t k = tr.seg_lo; k < tr.seg_hi; ++k) {
+            const TileSeg &sg = pb.segs[k];
+            if (sg.e_hi <= sg.e_lo || sg.e_hi - sg.e_lo > uint32_t(kSegMax) || sg.op_hi < sg.op_lo || sg.op_hi >= ops.size())
+                return fail(BOSSX_E_INVALID, "malformed tile segment");
+            if (ops[sg.op_lo].emit_start > sg.e_lo || (sg.op_lo + 1 < ops.size() && ops[sg.op_lo + 1].emit_start <= sg.e_lo))
+                return fail(BOSSX_E_INVALID, "segment does not start in its first run");
+            if (ops[sg.op_hi].emit_start >= sg.e_hi || (sg.op_hi + 1 < ops.size() && ops[sg.op_hi + 1].emit_start < sg.e_hi))
+                return fail(BOSSX_E_INVALID, "segment does not end in its last run");
+            const EmitOp &o = ops[sg.op_lo];
+            const uint64_t s0 = ((uint64_t(o.meta & 0xffu) << 32) | o.site_lo) + (sg.e_lo - o.emit_start);
+            if (s0 / kTileSites != tr.tile || (s0 + (sg.e_hi - sg.e_lo) - 1) / kTileSites != tr.tile)
+                return fail(BOSSX_E_INVALID, "segment crosses its tile");
+            seg_total += sg.e_hi - sg.e_lo;
+        }
+    }
+    if (seg_total != pb.total_emit) return fail(BOSSX_E_INVALID, "segments do not cover the batch");
+    if (!out_contig) return BOSSX_OK;
+    if (out_cap < int64_t(pb.total_emit)) return fail(BOSSX_E_INVALID, "output arrays too small");
+    for (size_t i = 0; i < ops.size(); ++i) {
+        const EmitOp &o = ops[i];
+        const uint64_t e_end = i + 1 < ops.size() ? ops[i + 1].emit_start : pb.total_emit;
+        const uint64_t site0 = (uint64_t(o.meta & 0xffu) << 32) | o.site_lo;
+        int32_t cidx = -1;
+        for (int32_t c = 0; c < n_contigs; ++c) {
+            const ContigInfo &ci = contigs[size_t(c)];
+            if (!ci.rejected && !ci.remote && int64_t(site0) >= ci.site_off && int64_t(site0) < ci.site_off + ci.n_tiles * kTileSites) cidx = c;
+        }
+        for (uint64_t e = o.emit_start; e < e_end; ++e) {
+            const uint64_t j = e - o.emit_start;
+            uint8_t code = 4;
+            if (!(o.meta & kOpDel)) {
+                const bool rev = (o.meta & kOpRev) != 0;
+                const char ch = blob[size_t(rev ? o.qpos - j : o.qpos + j)];
+                code = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 255;
+                if (rev && code != 255) code = uint8_t(3 - code);
+            }
+            out_contig[e] = cidx;
+            out_pos[e] = int64_t(site0 + j) - contigs[size_t(cidx)].site_off;
+            out_code[e] = code;
+            out_barcode[e] = uint8_t((o.meta >> 8) & 0xffu);
+        }
+    }
+    return BOSSX_OK;
+}

@@ -447,3 +447,52 @@ class Engine:
 
     def synchronize(self):
         self._ck(self.lib.bossx_synchronize(self.h))
+
+
+def host_parse(contigs, paf_text, seqs, barcodes=None, nbarcodes=1, min_len=200, n_threads=0, expand=True):
+    """bossx_host_parse: the native PAF/CIGAR front end without a device (CPU test hook).
+    `contigs`: list of (name, length, flags).  Returns the per-mapping summary plus, with
+    `expand`, one entry per aligned reference base: contig index, position, code (0..3 ACGT,
+    4 deletion, 255 other), barcode."""
+    lib = _lib.load()
+    ids = list(seqs.keys())
+    vals = list(seqs.values())
+    n = len(ids)
+    nptr, nlen = Engine._str_pointers(ids)
+    sptr, slen = Engine._str_pointers(vals)
+    cnames = [c[0].encode() for c in contigs]
+    cptr = (C.c_char_p * max(len(contigs), 1))(*cnames)
+    clen = np.ascontiguousarray([c[1] for c in contigs] or [0], dtype=np.int64)
+    cflag = np.ascontiguousarray([c[2] for c in contigs] or [0], dtype=np.int32)
+    paf = paf_text.encode() if isinstance(paf_text, str) else bytes(paf_text)
+    bc = None
+    if barcodes is not None:
+        bc = np.ascontiguousarray([barcodes[i] for i in ids] if isinstance(barcodes, dict) else barcodes, dtype=np.int32)
+    s = dict(read_idx=np.zeros(max(n, 1), np.int32), contig_idx=np.zeros(max(n, 1), np.int32),
+             rev=np.zeros(max(n, 1), np.uint8), tstart=np.zeros(max(n, 1), np.int64),
+             tend=np.zeros(max(n, 1), np.int64), qlen=np.zeros(max(n, 1), np.int64))
+    summ = _lib.BatchSummary(*[s[k].ctypes.data for k in ("read_idx", "contig_idx", "rev", "tstart", "tend", "qlen")])
+    n_rec = C.c_int32(0)
+    aligned = C.c_int64(0)
+    errbuf = C.create_string_buffer(512)
+
+    def call(oc, op, ocode, obc, cap):
+        rc = lib.bossx_host_parse(C.cast(cptr, C.c_void_p), clen.ctypes.data, cflag.ctypes.data, len(contigs),
+                                  int(nbarcodes), paf, len(paf), nptr.ctypes.data, nlen.ctypes.data,
+                                  sptr.ctypes.data, slen.ctypes.data, None if bc is None else bc.ctypes.data,
+                                  n, int(min_len), int(n_threads), C.byref(summ), C.byref(n_rec), C.byref(aligned),
+                                  oc, op, ocode, obc, cap, errbuf, len(errbuf))
+        if rc:
+            raise _lib.ERRORS.get(rc, _lib.BossxError)(errbuf.value.decode("utf-8", "replace"))
+    call(None, None, None, None, 0)
+    out = {key: v[:n_rec.value] for key, v in s.items()}
+    out["aligned"] = aligned.value
+    out["ids"] = ids
+    if expand:
+        m = max(aligned.value, 1)
+        oc, op = np.zeros(m, np.int32), np.zeros(m, np.int64)
+        ocode, obc = np.zeros(m, np.uint8), np.zeros(m, np.uint8)
+        call(oc.ctypes.data, op.ctypes.data, ocode.ctypes.data, obc.ctypes.data, m)
+        k = aligned.value
+        out.update(contig=oc[:k], pos=op[:k], code=ocode[:k], barcode=obc[:k])
+    return out

@@ -121,6 +121,23 @@ int bossx_ingest_staged(bossx_engine *h);
 int bossx_paf_summary(bossx_engine *h, const char *paf, size_t paf_len,
                       const char *const *name_ptrs, const int64_t *name_lens, int32_t n_reads,
                       int32_t min_len, bossx_batch_summary *summary, int32_t *n_rec);
+/* Host-only check of the PAF front end: no engine, no device.  Parses exactly like
+ * bossx_stage_batch_ptrs (same filters, mapping choice, CIGAR walk, error codes; `n_threads`
+ * 0 = default) for contigs given as names / lengths / BOSSX_CONTIG_* flags, verifies the tile
+ * segments it would upload, and expands the emit runs base by base the way the ingest kernels
+ * read them: for emitted base e, out_contig/out_pos = where it lands, out_code = 0..3 (A C G T
+ * on the reference strand), 4 (deletion), 255 (not A/C/G/T), out_barcode = barcode index.  The
+ * out_* arrays may be NULL (counts and checks only).  Used by the CPU test-suite to hold the
+ * native parser to CoverageConverter.convert_records (sequences.py:678-794).                  */
+int bossx_host_parse(const char *const *contig_names, const int64_t *contig_lengths,
+                     const int32_t *contig_flags, int32_t n_contigs, int32_t nbarcodes,
+                     const char *paf, size_t paf_len, const char *const *name_ptrs,
+                     const int64_t *name_lens, const char *const *seq_ptrs, const int64_t *seq_lens,
+                     const int32_t *barcodes, int32_t n_reads, int32_t min_len, int32_t n_threads,
+                     bossx_batch_summary *summary, int32_t *n_rec, int64_t *aligned_bases,
+                     int32_t *out_contig, int64_t *out_pos, uint8_t *out_code, uint8_t *out_barcode,
+                     int64_t out_cap, char *err_buf, size_t err_cap);
+
 /* Staged batches live in numbered slots (default 0) so several batches can be resident in HBM
  * at once; selects the slot the next stage/ingest call uses.                                */
 int bossx_select_batch(bossx_engine *h, int32_t slot);

@@ -176,3 +176,98 @@ def test_mask_bits_file_roundtrip_and_lookup(tmp_path):
     path.write_bytes(b"garbage")
     os.utime(path, (rd.last_mask_mtime + 5, rd.last_mask_mtime + 5))
     assert rd.reload() == 1 and rd.check_coord("rejX", 0, 0, "barcode01") == 1
+
+
+def _oracle_expansion(paf_text, seqs, contig_names, barcodes=None, min_len=200):
+    """Per aligned base (contig index, position, code, barcode) from the oracle's restatement of
+    convert_records, in record order."""
+    from oracle.pafcigar import parse_paf, best_mapper, expand_cigar, _COMP
+    cidx = {n: i for i, n in enumerate(contig_names)}
+    oc, op, ocode, obc = [], [], [], []
+    for rid, recs in parse_paf(paf_text, min_len=min_len).items():
+        rec = best_mapper(recs) if len(recs) > 1 else recs[0]
+        if rec.tname not in cidx:
+            continue
+        if rec.rev:
+            seq = seqs[rec.qname].translate(_COMP)[::-1]
+            qs, qe = rec.qlen - rec.qend, rec.qlen - rec.qstart
+        else:
+            seq, qs, qe = seqs[rec.qname], rec.qstart, rec.qend
+        q = expand_cigar(rec.cigar, seq, qs, qe)
+        start = min(rec.tstart, rec.tend)
+        oc.append(np.full(q.size, cidx[rec.tname], np.int32))
+        op.append(np.arange(start, start + q.size, dtype=np.int64))
+        ocode.append(q.astype(np.uint8))
+        obc.append(np.full(q.size, 0 if barcodes is None else barcodes[rec.qname], np.uint8))
+    cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
+    return cat(oc, np.int32), cat(op, np.int64), cat(ocode, np.uint8), cat(obc, np.uint8)
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_native_parser_vs_oracle_expansion(threads):
+    """The C++ PAF/CIGAR front end (threaded line parse + CIGAR walk, tile segments) against the
+    oracle's restatement of Paf.parse_PAF / choose_best_mapper / _parse_cigar, base by base, on
+    the golden CIGAR fixture and on a synthetic 1500-read batch.  No device involved."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.engine import host_parse
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g_cigar.npz"))
+    paf_text = g["paf"].tobytes().decode()
+    seqs = dict(zip(g["read_ids"].tolist(), g["read_seqs"].tolist()))
+    tnames = sorted({str(g["inc%03d_tname" % k]) for k in range(int(g["n_inc"]))})
+    contigs = [(n, 400_000, 0) for n in tnames]
+    got = host_parse(contigs, paf_text, seqs, n_threads=threads)
+    want = _oracle_expansion(paf_text, seqs, tnames)
+    for key, w in zip(("contig", "pos", "code", "barcode"), want):
+        assert np.array_equal(got[key], w), key
+    assert got["aligned"] == want[0].size > 0
+
+    ref = synth.make_reference([150_300, 260_100, 120_000], seed=3, names=["a", "b", "rej"])
+    batch = synth.make_batch(ref, 1500, seed=77, mean_len=5000.0, nbarcodes=4)
+    contigs = [("a", 150_300, 0), ("b", 260_100, 0), ("rej", 4, 1)]
+    got = host_parse(contigs, batch["paf"], batch["seqs"], barcodes=batch["barcodes"], nbarcodes=4, n_threads=threads)
+    want = _oracle_expansion(batch["paf"], batch["seqs"], ["a", "b"], barcodes=batch["barcodes"])
+    for key, w in zip(("contig", "pos", "code", "barcode"), want):
+        assert np.array_equal(got[key], w), key
+    # summary: one entry per chosen mapping, in first-appearance order of the read ids
+    from oracle.pafcigar import parse_paf, best_mapper
+    recs = [best_mapper(r) if len(r) > 1 else r[0] for r in parse_paf(batch["paf"], min_len=200).values()]
+    assert [got["ids"][i] for i in got["read_idx"]] == [r.qname for r in recs]
+    assert np.array_equal(got["tstart"], [r.tstart for r in recs])
+    assert np.array_equal(got["rev"], [int(r.rev) for r in recs])
+
+
+def test_native_parser_errors_are_first_in_record_order():
+    """With several faulty records the failure reported is the first one in record order,
+    whatever the thread partition (the reference raises inside its per-record loop)."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.engine import host_parse
+    ref = synth.make_reference([200_000], seed=9, names=["c"])
+    batch = synth.make_batch(ref, 600, seed=5, mean_len=3000.0)
+    lines = batch["paf"].strip().split("\n")
+    contigs = [("c", 200_000, 0)]
+
+    def corrupt(i, how):
+        f = lines[i].split("\t")
+        if how == "cigar":
+            f = [x.replace("cg:Z:", "cg:Z:7M", 1) if x.startswith("cg:Z:") else x for x in f]
+        elif how == "name":
+            f[0] = "ghost_read"
+        lines_c = list(lines)
+        lines_c[i] = "\t".join(f)
+        return lines_c
+    for threads in (1, 4):
+        bad = corrupt(400, "cigar")
+        with pytest.raises(ValueError, match="CIGAR"):
+            host_parse(contigs, "\n".join(bad), batch["seqs"], n_threads=threads, expand=False)
+        bad = corrupt(400, "cigar")
+        bad[100] = corrupt(100, "name")[100]
+        with pytest.raises(KeyError):
+            host_parse(contigs, "\n".join(bad), batch["seqs"], n_threads=threads, expand=False)
+        bad = corrupt(100, "cigar")
+        bad[400] = corrupt(400, "name")[400]
+        with pytest.raises(ValueError, match="CIGAR"):
+            host_parse(contigs, "\n".join(bad), batch["seqs"], n_threads=threads, expand=False)
+        bad = list(lines)
+        bad[300] = "\t".join(bad[300].split("\t")[:7])
+        with pytest.raises(ValueError, match="PAF line 301"):
+            host_parse(contigs, "\n".join(bad), batch["seqs"], n_threads=threads, expand=False)
