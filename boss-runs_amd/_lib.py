@@ -69,6 +69,7 @@ PROTOTYPES = {
                                          C.POINTER(C.c_int64)]),
     "bossx_paf_summary": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int32,
                                     C.c_int32, C.POINTER(BatchSummary), C.POINTER(C.c_int32)]),
+    "bossx_py_str_pointers": (C.c_int, [C.py_object, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bossx_host_parse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                    C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
@@ -141,6 +142,21 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+_pylib = None
+
+
+def load_gil():
+    """The same library through ctypes.PyDLL (calls keep the GIL): for bossx_py_str_pointers."""
+    global _pylib
+    if _pylib is None:
+        load()
+        _pylib = C.PyDLL(LIB_PATH)
+        res, args = PROTOTYPES["bossx_py_str_pointers"]
+        _pylib.bossx_py_str_pointers.restype = res
+        _pylib.bossx_py_str_pointers.argtypes = args
+    return _pylib
 
 
 def check(lib, handle, rc):

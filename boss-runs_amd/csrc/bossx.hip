@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -460,6 +461,8 @@ int bossx_stage_batch(bossx_engine *h, const char *paf, size_t paf_len, const ch
     HIPCHK(hipSetDevice(h->cfg.device));
     // the pinned run buffer may still feed the previous batch's upload
     HIPCHK(hipStreamSynchronize(h->stream));
+    const bool timing = getenv("BOSSX_STAGE_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     const size_t ops_need = ops_capacity_for(paf ? paf_len : 0);
     if (ops_need > h->ops_pin_cap) {
         if (h->h_ops_pin) HIPCHK(hipHostFree(h->h_ops_pin));
@@ -474,6 +477,7 @@ int bossx_stage_batch(bossx_engine *h, const char *paf, size_t paf_len, const ch
     std::string err;
     int rc = parse_paf_batch(in, h->contigs, h->index, summary, pb, err);
     if (rc) return fail(h, rc, err);
+    const auto t1 = std::chrono::steady_clock::now();
     if (n_rec) *n_rec = pb.n_rec;
     if (aligned_bases) *aligned_bases = int64_t(pb.total_emit);
     // the previous staged batch may still be read by an in-flight ingest kernel
@@ -519,6 +523,13 @@ int bossx_stage_batch(bossx_engine *h, const char *paf, size_t paf_len, const ch
         if (blob_bytes) HIPCHK(hipMemcpyAsync(st.d_blob, seqs, blob_bytes, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));   // inputs are borrowed for the call only
     }
+    if (timing) {
+        const auto t2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[bossx] stage_batch: parse %.2f ms, alloc+upload %.2f ms (%.1f MB)\n",
+                std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                std::chrono::duration<double, std::milli>(t2 - t1).count(),
+                double(pb.n_ops * sizeof(EmitOp) + blob_bytes + pb.segs.size() * sizeof(TileSeg)) / 1e6);
+    }
     st.pb = std::move(pb);
     st.valid = true;
     return BOSSX_OK;
@@ -549,6 +560,7 @@ int bossx_stage_batch_ptrs(bossx_engine *h, const char *paf, size_t paf_len, con
         h->blob_pin_cap = cap;
     }
     char *blob = static_cast<char *>(h->h_blob_pin);
+    const auto tg0 = std::chrono::steady_clock::now();
     {
         // parallel gather, ranges balanced by bytes
         const int nt = (blob_bytes > (size_t(1) << 20)) ? parse_threads() : 1;
@@ -564,6 +576,9 @@ int bossx_stage_batch_ptrs(bossx_engine *h, const char *paf, size_t paf_len, con
         gather(0);
         for (auto &th : pool) th.join();
     }
+    if (getenv("BOSSX_STAGE_TIMING"))
+        fprintf(stderr, "[bossx] stage_batch: gather %.2f ms\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg0).count());
     return bossx_stage_batch(h, paf, paf_len, names.data(), name_off.data(), blob, seq_off.data(), barcodes, n_reads,
                              min_len, summary, n_rec, aligned_bases);
 }

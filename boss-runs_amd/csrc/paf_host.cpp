@@ -591,3 +591,25 @@ extern "C" int bossx_host_parse(const char *const *contig_names, const int64_t *
     }
     return BOSSX_OK;
 }
+
+// Binding helper for CPython callers (include/bossx.h): buffer pointer + length of every str in
+// the Python list `list` through the interpreter's own PyList_GetItem / PyUnicode_AsUTF8AndSize
+// (passed in by address, so this library does not link against libpython).  Must be called
+// with the GIL held (ctypes.PyDLL).
+extern "C" int bossx_py_str_pointers(void *list, int64_t n, void *list_get_item, void *as_utf8_and_size,
+                                     const char **ptrs, int64_t *lens) {
+    using get_t = void *(*)(void *, long);             // Py_ssize_t == long on LP64
+    using utf_t = const char *(*)(void *, long *);
+    static_assert(sizeof(long) == sizeof(void *), "LP64 only");
+    get_t get = reinterpret_cast<get_t>(list_get_item);
+    utf_t utf = reinterpret_cast<utf_t>(as_utf8_and_size);
+    if (!get || !utf || !list || n < 0 || (n > 0 && (!ptrs || !lens))) return BOSSX_E_INVALID;
+    for (int64_t i = 0; i < n; ++i) {
+        void *item = get(list, long(i));               // borrowed reference
+        long sz = 0;
+        const char *p = item ? utf(item, &sz) : nullptr;
+        if (!p) return BOSSX_E_INVALID;                // the interpreter has set the exception
+        ptrs[i] = p; lens[i] = int64_t(sz);
+    }
+    return BOSSX_OK;
+}

@@ -90,19 +90,18 @@ class Engine:
         """Pointers/lengths of the (ASCII) buffers inside Python str objects — no copies; the
         caller keeps the strings alive for the duration of the C call."""
         if cls._as_utf8 is None:
-            api = C.pythonapi.PyUnicode_AsUTF8AndSize
-            api.restype = C.c_void_p
-            api.argtypes = [C.py_object, C.POINTER(C.c_ssize_t)]
-            cls._as_utf8 = api
-        api = cls._as_utf8
+            cls._as_utf8 = (C.cast(C.pythonapi.PyList_GetItem, C.c_void_p).value,
+                            C.cast(C.pythonapi.PyUnicode_AsUTF8AndSize, C.c_void_p).value)
+        if not isinstance(strings, list):
+            strings = list(strings)
         n = len(strings)
         ptrs = np.empty(max(n, 1), dtype=np.uint64)
         lens = np.empty(max(n, 1), dtype=np.int64)
-        sz = C.c_ssize_t()
-        ref = C.byref(sz)
-        for i, s in enumerate(strings):
-            ptrs[i] = api(s, ref)
-            lens[i] = sz.value
+        if n:
+            rc = _lib.load_gil().bossx_py_str_pointers(strings, n, cls._as_utf8[0], cls._as_utf8[1],
+                                                       ptrs.ctypes.data, lens.ctypes.data)
+            if rc:
+                raise TypeError("read names and sequences must be str")
         return ptrs, lens
 
     def stage_batch(self, paf_text, seqs, barcodes=None, min_len=200, ingest=False, packed=None):

@@ -121,6 +121,13 @@ int bossx_ingest_staged(bossx_engine *h);
 int bossx_paf_summary(bossx_engine *h, const char *paf, size_t paf_len,
                       const char *const *name_ptrs, const int64_t *name_lens, int32_t n_reads,
                       int32_t min_len, bossx_batch_summary *summary, int32_t *n_rec);
+/* CPython binding helper: pointer + length of the UTF-8 buffer of each str in the Python list
+ * `list` (a PyObject*), obtained through the addresses of the interpreter's PyList_GetItem and
+ * PyUnicode_AsUTF8AndSize; lets the ctypes layer hand a dict of reads to
+ * bossx_stage_batch_ptrs without one ctypes call per read.  Call with the GIL held.            */
+int bossx_py_str_pointers(void *list, int64_t n, void *list_get_item, void *as_utf8_and_size,
+                          const char **ptrs, int64_t *lens);
+
 /* Host-only check of the PAF front end: no engine, no device.  Parses exactly like
  * bossx_stage_batch_ptrs (same filters, mapping choice, CIGAR walk, error codes; `n_threads`
  * 0 = default) for contigs given as names / lengths / BOSSX_CONTIG_* flags, verifies the tile

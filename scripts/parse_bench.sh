@@ -16,4 +16,4 @@ with open('gpurun_out/pb/reads.txt', 'w') as f:
 PY
 g++ -O2 -pthread -DBOSSX_PARSE_TIMING -std=c++17 -Iinclude -Iboss-runs_amd/csrc scripts/parse_bench.cpp boss-runs_amd/csrc/paf_host.cpp -o gpurun_out/pb/parse_bench
 echo "nproc $(nproc)"
-for t in 1 2 4 8 16; do echo "threads $t"; gpurun_out/pb/parse_bench gpurun_out/pb/paf.txt gpurun_out/pb/reads.txt 4641652 $t 2>&1 | tail -2; done
+for t in 1 2 4 8 16; do echo "threads $t"; gpurun_out/pb/parse_bench gpurun_out/pb/paf.txt gpurun_out/pb/reads.txt 4641652 $t 2>&1 | grep -v "^rc" | tail -1; done
