@@ -22,6 +22,15 @@ struct bossx_engine {
     std::string err;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // second stream: the benefit chain of an update runs next to that update's sweep
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_chain = nullptr;
+    uint32_t *d_tile_done = nullptr;   // [n_tiles] sweep -> chain hand-off flags (epoch stamped)
+    uint32_t epoch = 0;
+    bool overlap_ok = false;           // decided at finalize (BOSSX_OVERLAP / BOSSX_NO_OVERLAP / size); cleared after a chain time-out
+    bool host_armed = false;           // the host has seen ctrl.any_on set
+    bool sweep_in_flight = false;      // update_begin enqueued a sweep that no update has consumed yet
+    bool chain_on_stream2 = false;     // update_benefit put the chain on stream2 (ev_chain pending)
     bool finalized = false;
     bool lut_set = false;
     bool all_local = true;
@@ -139,7 +148,7 @@ ContigTable table_of(const bossx_engine *h) {
     return t;
 }
 
-void time_begin(bossx_engine *h, int k) {
+void time_begin(bossx_engine *h, int k, hipStream_t stream = nullptr) {
     if (!h->timing) return;
     if (h->ev_pending[k]) {      // collect the previous launch before re-recording
         hipEventSynchronize(h->ev1[k]);
@@ -147,14 +156,14 @@ void time_begin(bossx_engine *h, int k) {
         if (hipEventElapsedTime(&ms, h->ev0[k], h->ev1[k]) == hipSuccess) { h->ms_last[k] = ms; h->ms_total[k] += ms; }
         h->ev_pending[k] = false;
     }
-    hipEventRecord(h->ev0[k], h->stream);
+    hipEventRecord(h->ev0[k], stream ? stream : h->stream);
 }
 
-void time_end(bossx_engine *h, int k, double bytes) {
+void time_end(bossx_engine *h, int k, double bytes, hipStream_t stream = nullptr) {
     h->launches[k]++;
     h->bytes_last[k] = bytes;
     if (!h->timing) return;
-    hipEventRecord(h->ev1[k], h->stream);
+    hipEventRecord(h->ev1[k], stream ? stream : h->stream);
     h->ev_pending[k] = true;
 }
 
@@ -182,6 +191,8 @@ SweepParams sweep_params(bossx_engine *h) {
     P.lut_score = h->d_lut_score; P.lut_ent = h->d_lut_ent; P.ct = table_of(h);
     P.Gp = h->Gp; P.B = h->B; P.NBK = h->NBK; P.nb = h->nb;
     P.score0 = h->score0; P.tiny = std::numeric_limits<double>::min();
+    P.tile_done = h->d_tile_done; P.epoch = h->epoch;
+    P.publish = (h->overlap_ok && h->host_armed) ? 1 : 0;
     return P;
 }
 
@@ -259,6 +270,9 @@ int bossx_create(const bossx_config *cfg, bossx_engine **out) {
     for (int k = 0; k < BOSSX_K_COUNT; ++k) {
         if (hipEventCreate(&h->ev0[k]) != hipSuccess || hipEventCreate(&h->ev1[k]) != hipSuccess) return BOSSX_E_HIP;
     }
+    if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_begin, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming) != hipSuccess) return BOSSX_E_HIP;
     *out = e.release();
     return BOSSX_OK;
 }
@@ -267,6 +281,10 @@ void bossx_destroy(bossx_engine *h) {
     if (!h) return;
     hipSetDevice(h->cfg.device);
     hipStreamSynchronize(h->stream);
+    if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
+    if (h->ev_begin) hipEventDestroy(h->ev_begin);
+    if (h->ev_chain) hipEventDestroy(h->ev_chain);
+    if (h->d_tile_done) hipFree(h->d_tile_done);
     void *ptrs[] = {h->d_cov, h->d_meta, h->d_touched, h->d_strat, h->d_bucket_on, h->d_entropy, h->d_ds,
                     h->d_benefit, h->d_lut_score, h->d_lut_ent, h->d_fhat, h->d_bucket_sums, h->d_drop_count,
                     h->d_stats, h->d_err, h->d_tile_off, h->d_site_off, h->d_length, h->d_bin_off, h->d_row_off,
@@ -376,6 +394,11 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
     if ((rc = dev_alloc(h, &h->d_benefit, size_t(nb * 2 * h->B), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_strat, size_t(h->strat_bytes)))) return rc;
     HIPCHK(hipMemsetAsync(h->d_strat, 1, size_t(h->strat_bytes), h->stream));       // reference.py:118
+    if ((rc = dev_alloc(h, &h->d_tile_done, size_t(h->n_tiles > 0 ? h->n_tiles : 1), true))) return rc;
+    // The chain of an update runs next to that update's sweep where the sweep is long enough to be
+    // worth hiding (measured: +2-3 % at 110-390 Mb, -3 % at 4.6 Mb where the host's own work
+    // already covers the sweep).  BOSSX_OVERLAP=1 / BOSSX_NO_OVERLAP=1 force it either way.
+    h->overlap_ok = getenv("BOSSX_NO_OVERLAP") ? false : (getenv("BOSSX_OVERLAP") ? true : h->Gp >= (int64_t(32) << 20));
     if ((rc = dev_alloc(h, &h->d_bucket_on, size_t(nb * h->NBK), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_bucket_sums, size_t(nb * h->NBK), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_drop_count, size_t(h->n_tiles), true))) return rc;
@@ -651,6 +674,7 @@ int launch_sweep(bossx_engine *h) {
     HIPCHK(hipMemcpyAsync(h->d_drop_thr, thr.data(), thr.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemsetAsync(h->d_bucket_sums, 0, size_t(h->nb * h->NBK) * sizeof(unsigned long long), h->stream));
     HIPCHK(hipMemsetAsync(h->d_ds, 0, size_t(h->nb * h->B) * sizeof(double), h->stream));
+    ++h->epoch;                                  // stamps the tile flags of this sweep
     SweepParams P = sweep_params(h);
     time_begin(h, BOSSX_K_SWEEP);
     if (h->n_tiles > 0)
@@ -746,28 +770,37 @@ int fill_chain_params(bossx_engine *h, const int32_t *windows, const double *mul
         return fail(h, BOSSX_E_WINDOW, "read-length window exceeds the LDS ring (reads longer than ~790 kb in the 95th percentile)");
     P.ds = h->d_ds; P.benefit = h->d_benefit; P.ctrl = h->d_ctrl; P.ct = table_of(h);
     P.B = h->B; P.nb = h->nb; P.ring = ring; P.gate = 0;
+    P.tile_done = nullptr; P.epoch = h->epoch; P.wait_ticks = 200000000ll;   // 2 s
     P.probe = getenv("BOSSX_CHAIN_PROBE") ? reinterpret_cast<long long *>(h->d_stats + kStatWords + 8) : nullptr;
     P.max_limit = std::min<int64_t>(h->B, h->n_sites_all / kWindow);
     lds = size_t(ring) * sizeof(double);
     if (lds > 32 * 1024) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_kernel<true>),
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_kernel<true, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_kernel<false>),
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_kernel<true, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_kernel<false, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_kernel<false, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
     }
     return BOSSX_OK;
 }
 
-void launch_chain(bossx_engine *h, const ChainParams &P, size_t lds) {
-    time_begin(h, BOSSX_K_BENEFIT);
-    if (h->matrix_chain)
-        hipLaunchKernelGGL(benefit_chain_kernel<true>, dim3(uint32_t(h->filt.size() * size_t(h->nb) * 2)), dim3(kChainThreads),
-                           lds, h->stream, P);
-    else
-        hipLaunchKernelGGL(benefit_chain_kernel<false>, dim3(uint32_t(h->filt.size() * size_t(h->nb) * 2)), dim3(kChainThreads),
-                           lds, h->stream, P);
+void launch_chain(bossx_engine *h, const ChainParams &P, size_t lds, hipStream_t stream = nullptr) {
+    if (!stream) stream = h->stream;
+    time_begin(h, BOSSX_K_BENEFIT, stream);
+    const dim3 grid(uint32_t(h->filt.size() * size_t(h->nb) * 2)), block(kChainThreads);
+    const bool live = P.tile_done != nullptr;
+    if (h->matrix_chain) {
+        if (live) hipLaunchKernelGGL((benefit_chain_kernel<true, true>), grid, block, lds, stream, P);
+        else hipLaunchKernelGGL((benefit_chain_kernel<true, false>), grid, block, lds, stream, P);
+    } else {
+        if (live) hipLaunchKernelGGL((benefit_chain_kernel<false, true>), grid, block, lds, stream, P);
+        else hipLaunchKernelGGL((benefit_chain_kernel<false, false>), grid, block, lds, stream, P);
+    }
     // algorithmic bytes: read the downsampled scores once per direction, write both strands
-    time_end(h, BOSSX_K_BENEFIT, double(h->B) * h->nb * (2 * 8.0 + 2 * 8.0));
+    time_end(h, BOSSX_K_BENEFIT, double(h->B) * h->nb * (2 * 8.0 + 2 * 8.0), stream);
 }
 
 }  // namespace
@@ -894,10 +927,13 @@ int bossx_update_begin(bossx_engine *h, double bucket_threshold) {
     if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "bad update_begin call");
     if (!h->lut_set) return fail(h, BOSSX_E_INVALID, "update before set_lut");
     HIPCHK(hipSetDevice(h->cfg.device));
+    // everything enqueued so far precedes a chain that update_benefit may put on stream2
+    HIPCHK(hipEventRecord(h->ev_begin, h->stream));
     int rc = launch_sweep(h);
     if (rc) return rc;
     launch_buckets(h, bucket_threshold);
     HIPCHK(hipGetLastError());
+    h->sweep_in_flight = true;
     return BOSSX_OK;
 }
 
@@ -1002,6 +1038,7 @@ int bossx_arm(bossx_engine *h) {
     const int32_t one = 1;
     HIPCHK(hipMemcpyAsync(&h->d_ctrl->any_on, &one, sizeof(one), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->host_armed = true;
     return BOSSX_OK;
 }
 
@@ -1022,9 +1059,23 @@ int bossx_update_benefit(bossx_engine *h, const int32_t *windows, const double *
     size_t lds = 0;
     int rc = fill_chain_params(h, windows, mult, CP, lds);
     if (rc) return rc;
-    HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream));
     CP.gate = 1;
-    launch_chain(h, CP, lds);
+    if (h->overlap_ok && h->host_armed && h->sweep_in_flight) {
+        // The strategy is switched on (the gate is known to be open) and this update's sweep is in
+        // flight on the main stream: run the chain NEXT TO it on stream2.  The sweep hands tiles
+        // out from both contig ends and publishes each tile's bin sums (tile_done == epoch); the
+        // chain's prefetch wave waits for the tiles of a chunk before reading it.
+        HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_begin, 0));
+        HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream2));
+        CP.tile_done = h->d_tile_done; CP.epoch = h->epoch;
+        if (getenv("BOSSX_OVERLAP_SELFTEST")) { CP.epoch = h->epoch + 1; CP.wait_ticks = 500000; }   // never satisfied: exercises the time-out path
+        launch_chain(h, CP, lds, h->stream2);
+        HIPCHK(hipEventRecord(h->ev_chain, h->stream2));
+        h->chain_on_stream2 = true;
+    } else {
+        HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream));
+        launch_chain(h, CP, lds);
+    }
     HIPCHK(hipGetLastError());
     return BOSSX_OK;
 }
@@ -1050,21 +1101,7 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
         if ((rc = launch_sweep(h))) return rc;
         launch_buckets(h, up->bucket_threshold);
     }
-    if (have_strategy_inputs) {
-        if (!(up->flags & BOSSX_UPDATE_BENEFIT_DONE)) {
-            HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream));
-            CP.gate = 1;
-            launch_chain(h, CP, lds);
-        }
-        if ((rc = launch_hist(h, &fh, 1))) return rc;
-        PickParams PP;
-        PP.counts = h->d_stats; PP.fgrid = h->d_stats + BOSSX_HIST_BINS; PP.ubar = h->d_stats + BOSSX_HIST_BINS * 3;
-        PP.limbs = nullptr; PP.ctrl = h->d_ctrl; PP.tc = up->tc; PP.gate = 1;
-        hipLaunchKernelGGL(threshold_pick_kernel, dim3(1), dim3(64), 0, h->stream, PP);
-        if ((rc = launch_mask(h, 1))) return rc;
-    }
-    HIPCHK(hipGetLastError());
-    // results
+    h->sweep_in_flight = false;
     const size_t need = sizeof(Ctrl) + sizeof(int32_t) + h->filt.size() + (counts ? kStatWords * 8 : 0);
     if ((rc = ensure_pin(h, need + 64))) return rc;
     char *pin = static_cast<char *>(h->h_pin);
@@ -1072,12 +1109,45 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
     int32_t *herr = reinterpret_cast<int32_t *>(pin + sizeof(Ctrl));
     uint8_t *hon = reinterpret_cast<uint8_t *>(pin + sizeof(Ctrl) + sizeof(int32_t));
     unsigned long long *hst = reinterpret_cast<unsigned long long *>(pin + ((sizeof(Ctrl) + sizeof(int32_t) + h->filt.size() + 15) & ~size_t(15)));
-    HIPCHK(hipMemcpyAsync(hc, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(herr, h->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(hon, h->d_contig_on, h->filt.size(), hipMemcpyDeviceToHost, h->stream));
-    if (counts) HIPCHK(hipMemcpyAsync(hst, h->d_stats, kStatWords * 8, hipMemcpyDeviceToHost, h->stream));
-    if (strat_all && have_strategy_inputs && (rc = copy_masks(h, strat_all, (up->flags & BOSSX_UPDATE_STRAT_BITS) != 0))) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    bool chain_done = (up->flags & BOSSX_UPDATE_BENEFIT_DONE) != 0;
+    for (int attempt = 0;; ++attempt) {
+        if (have_strategy_inputs) {
+            if (!chain_done) {
+                HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream));
+                CP.gate = 1;
+                launch_chain(h, CP, lds);
+            } else if (h->chain_on_stream2) {
+                HIPCHK(hipStreamWaitEvent(h->stream, h->ev_chain, 0));     // the chain ran next to the sweep
+            }
+            h->chain_on_stream2 = false;
+            if ((rc = launch_hist(h, &fh, 1))) return rc;
+            PickParams PP;
+            PP.counts = h->d_stats; PP.fgrid = h->d_stats + BOSSX_HIST_BINS; PP.ubar = h->d_stats + BOSSX_HIST_BINS * 3;
+            PP.limbs = nullptr; PP.ctrl = h->d_ctrl; PP.tc = up->tc; PP.gate = 1;
+            hipLaunchKernelGGL(threshold_pick_kernel, dim3(1), dim3(64), 0, h->stream, PP);
+            if ((rc = launch_mask(h, 1))) return rc;
+        }
+        HIPCHK(hipGetLastError());
+        // results
+        HIPCHK(hipMemcpyAsync(hc, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(herr, h->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(hon, h->d_contig_on, h->filt.size(), hipMemcpyDeviceToHost, h->stream));
+        if (counts) HIPCHK(hipMemcpyAsync(hst, h->d_stats, kStatWords * 8, hipMemcpyDeviceToHost, h->stream));
+        if (strat_all && have_strategy_inputs && (rc = copy_masks(h, strat_all, (up->flags & BOSSX_UPDATE_STRAT_BITS) != 0))) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (have_strategy_inputs && (hc->err & 4) && attempt == 0) {
+            // The concurrent chain gave up waiting for the sweep (kernels serialised by a profiler):
+            // rerun it after the sweep, and stay serial from now on.
+            const int32_t cleared = 0;      // also drops the pick kernel's 'empty' flag of the aborted attempt
+            HIPCHK(hipMemcpyAsync(&h->d_ctrl->err, &cleared, sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            h->overlap_ok = false;
+            chain_done = false;
+            continue;
+        }
+        break;
+    }
+    if (hc->any_on) h->host_armed = true;
     if (*herr) {
         HIPCHK(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
         return fail(h, BOSSX_E_RANGE, "a read contains a base other than A/C/G/T inside an aligned segment");
@@ -1344,6 +1414,7 @@ int bossx_synchronize(bossx_engine *h) {
     if (!h) return BOSSX_E_INVALID;
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->stream2) HIPCHK(hipStreamSynchronize(h->stream2));
     return BOSSX_OK;
 }
 

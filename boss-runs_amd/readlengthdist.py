@@ -14,6 +14,7 @@ class ReadlengthDist:
     def __init__(self, mu=400, sd=4000, lam=6000, eta=11):
         self.sd, self.lam, self.eta, self.mu = sd, lam, eta, mu
         self.read_lengths = np.zeros(int(1e6), dtype='uint16')
+        self._L = self._ccl = None
         x = np.arange(int(lam + 10 * sd), dtype='int')
         dens = np.exp(-((x - lam + 1) ** 2) / (2 * (sd ** 2))) / (sd * np.sqrt(2 * np.pi))
         # the reference normalises with Python's sequential sum(); cumsum adds in the same order
@@ -35,19 +36,75 @@ class ReadlengthDist:
             # repeated `+= 1` (readlengthdist.py:23,48)
             np.add.at(self.read_lengths, lens, np.uint16(1))
         # only lengths up to the longest one seen so far can be non-zero
-        observed = np.nonzero(self.read_lengths[:getattr(self, "_hi", 0) + 1])[0]
-        if observed.size == 0:
+        counts = self.read_lengths[:getattr(self, "_hi", 0) + 1].astype(np.int64)
+        total = int(counts.sum())
+        if total == 0:
             logging.info('Attempted update of read lengths before observing any reads')
             return
-        counts = self.read_lengths[observed].astype(np.int64)
-        self.lam = np.sum(observed * counts) / np.sum(self.read_lengths[observed])
-        self.longest_read = observed[-1]
-        dens = self.read_lengths[:self.longest_read + 1].astype('float64')
-        dens /= np.sum(dens)          # integer counts: any summation order is exact
-        self.L = dens
-        self.approx_ccl = self.ccl_approx_constant()
-        logging.info(f'rld: {self.approx_ccl}')
+        # uint16 wrap-around can zero the top counters: the reference takes the last non-zero one
+        hi = counts.size - 1
+        while counts[hi] == 0:
+            hi -= 1
+        counts = counts[:hi + 1]
+        self.longest_read = np.int64(hi)
+        self.lam = np.int64(np.dot(np.arange(hi + 1, dtype=np.int64), counts)) / np.uint64(total)
+        self._counts = counts
+        self._L = self._ccl = None                    # materialised on access
+        self.approx_ccl = self._approx_lean()
+        logging.info('rld: %s', self.approx_ccl)
         self.time_cost = self.lam - 400 - 300
+
+    # `L` (pmf) and `ccl` are attributes of the reference object (readlengthdist.py:60,84); here
+    # they are built from the integer histogram when somebody looks at them.
+    @property
+    def L(self):
+        if self._L is None:
+            dens = self._counts.astype('float64')
+            dens /= float(self._counts.sum())   # = the reference's sum(L): integer-valued, exact
+            self._L = dens
+        return self._L
+
+    @L.setter
+    def L(self, value):
+        self._L = value
+
+    @property
+    def ccl(self):
+        if self._ccl is None:
+            self.ccl_approx_constant()
+        return self._ccl
+
+    @ccl.setter
+    def ccl(self, value):
+        self._ccl = value
+
+    def _approx_lean(self):
+        """`ccl_approx_constant` without materialising `ccl`: the same float cumsum of L[1:]
+        (bit-identical partial sums), the crossing of each level located by bisection on the
+        monotone partial sums and settled with the reference's own expression `1 - cs > prob`.
+        The 1e-6 cut-off and the trailing-zero trim of the reference do not move any crossing:
+        ccl is non-increasing, so the first entry <= prob is the same before and after them."""
+        total = float(self._counts.sum())
+        n = self._counts.size - 1                     # len(L[1:])
+        probs = [1 - (part + 0.5) / (self.eta - 1) for part in range(self.eta - 1)]
+        # the last level (0.05) is crossed near the previous update's last index: sum that far
+        # first (a prefix of the cumsum is bit-identical to the cumsum's prefix), all of it if not
+        m = min(n, int(self.approx_ccl[-1] * 1.25) + 64)
+        while True:
+            cs = np.cumsum(self._counts[1:m + 1] / total)     # = L[1:m+1].cumsum()
+            if m == n or 1.0 - cs[-1] <= probs[-1]:
+                break
+            m = n
+        j = np.searchsorted(cs, 1.0 - np.array(probs), side='left')
+        out = np.empty(len(probs), dtype='int32')
+        for k, prob in enumerate(probs):
+            i = int(j[k])
+            while i > 0 and not (1.0 - cs[i - 1] > prob):
+                i -= 1
+            while i < cs.size and 1.0 - cs[i] > prob:
+                i += 1
+            out[k] = i + 1            # ccl[i + 1] = 1 - cs[i]; i == n is the appended final zero
+        return out
 
     def ccl_approx_constant(self):
         ccl = np.zeros(len(self.L) + 1)

@@ -271,3 +271,38 @@ def test_native_parser_errors_are_first_in_record_order():
         bad[300] = "\t".join(bad[300].split("\t")[:7])
         with pytest.raises(ValueError, match="PAF line 301"):
             host_parse(contigs, "\n".join(bad), batch["seqs"], n_threads=threads, expand=False)
+
+
+def test_readlength_fast_path_equals_float_scan():
+    """ReadlengthDist.update decides approx_ccl on the exact integer histogram; it must agree
+    with the reference's float cumsum scan (ccl_approx_constant) and with the oracle on every
+    distribution, including degenerate ones and uint16 wrap-around."""
+    from oracle.dists import OReadlengthDist
+    rng = np.random.default_rng(12)
+    cases = [np.array([5000]), np.array([5000] * 10), np.array([900, 60000]), np.array([801, 802, 803]),
+             np.array([1_500_000, 2000, 2000]), np.arange(801, 1801), np.array([100, 200])]
+    for _ in range(40):
+        n = int(rng.integers(1, 5000))
+        cases.append(np.clip(rng.gamma(2, rng.uniform(500, 6000), n), 1, 2_000_000).astype(np.int64))
+    p, o = ReadlengthDist(), OReadlengthDist()
+    for lens in cases:
+        p.update(lens)
+        o.update({"r%d" % i: int(v) for i, v in enumerate(lens)})
+        assert np.array_equal(p.approx_ccl, o.approx_ccl)
+        assert np.array_equal(p.approx_ccl, p.ccl_approx_constant())
+        if hasattr(o, "time_cost"):
+            assert p.lam == o.lam and p.time_cost == o.time_cost and p.longest_read == o.longest_read
+            assert np.array_equal(p.L, o.L) and np.array_equal(p.ccl, o.ccl)
+    # fresh objects on single batches (the first update matters: few reads, coarse steps)
+    for lens in cases:
+        p, o = ReadlengthDist(), OReadlengthDist()
+        p.update(lens)
+        o.update({"r%d" % i: int(v) for i, v in enumerate(lens)})
+        assert np.array_equal(p.approx_ccl, o.approx_ccl)
+        assert hasattr(p, "time_cost") == hasattr(o, "time_cost")
+    # 65536 reads of one length wrap its uint16 counter to zero (readlengthdist.py:23)
+    p, o = ReadlengthDist(), OReadlengthDist()
+    lens = np.concatenate([np.full(65536, 7000), np.full(10, 3000)])
+    p.update(lens)
+    o.update({"r%d" % i: int(v) for i, v in enumerate(lens)})
+    assert np.array_equal(p.approx_ccl, o.approx_ccl) and p.lam == o.lam and p.longest_read == o.longest_read == 3000

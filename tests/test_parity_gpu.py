@@ -511,3 +511,52 @@ def test_mask_bits_path_equals_npz(in_tmp):
             want = 0 if arr.shape[0] == 1 else (int(arr[:, rev, bc][pos // 100]) if pos // 100 < arr.shape[0] else 1)
             assert rd.check_coord(n, pos, rev, "barcode%02d" % (bc + 1)) == want
     assert 0 < sum(int(v.sum()) for v in got.values()) < sum(v.size for v in got.values())
+
+
+def _run_updates(in_tmp, name, n_batches, env=None):
+    """E2E-style run; returns per-update (threshold, benefit arrays, bin sums, masks)."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.runs import BossRuns
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        contigs = synth.make_reference([300_700, 123_400, 200_000], seed=31, names=["o1", "o2", "o3"])
+        strs = [(n, synth.codes_to_str(c)) for n, c in contigs]
+        args = BossConfig()
+        args.general.name = name
+        args.optional.bucket_threshold = 0
+        args.general.barcodes = ["barcode01", "barcode02"]
+        runs = BossRuns(args)
+        runs.init(contigs=strs)
+        out = []
+        for b in range(n_batches):
+            batch = synth.make_batch(contigs, 1200, seed=900 + b, mean_len=4000.0, nbarcodes=2)
+            runs.rl_dist.update(batch["read_lengths"])
+            runs.process_batch_paf(batch["paf"], batch["seqs"], barcodes=batch["barcodes"])
+            out.append((runs.threshold,
+                        [runs.contigs[n].additional_benefit.copy() for n in ("o1", "o2", "o3")],
+                        [runs.contigs[n].scores_ds.copy() for n in ("o1", "o2", "o3")],
+                        [runs.contigs[n].strat.copy() for n in ("o1", "o2", "o3")]))
+        return out, runs
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_chain_next_to_sweep_equals_serial(in_tmp):
+    """Once the strategy is on, the benefit chain runs on a second stream NEXT TO the sweep of the
+    same update (tile flags, agent-scope stores/loads).  Every update must be bit-identical to the
+    serial schedule, and the time-out fallback (chain gives up, host reruns it) as well."""
+    serial, r0 = _run_updates(in_tmp, "ov_serial", 8, env={"BOSSX_NO_OVERLAP": "1"})
+    live, r1 = _run_updates(in_tmp, "ov_live", 8, env={"BOSSX_OVERLAP": "1"})
+    fallback, r2 = _run_updates(in_tmp, "ov_fallback", 4, env={"BOSSX_OVERLAP": "1", "BOSSX_OVERLAP_SELFTEST": "1"})
+    for other in (live, fallback):
+        for k, (a, b) in enumerate(zip(serial, other)):
+            assert a[0] == b[0], k
+            for x, y in zip(a[1] + a[2] + a[3], b[1] + b[2] + b[3]):
+                assert np.array_equal(x, y), k
+    assert serial[-1][0] is not None
