@@ -55,6 +55,7 @@ struct bossx_engine {
     uint32_t *d_drop_count = nullptr;
     int64_t fhat_cap = 0;
     int32_t *d_err = nullptr;
+    uint8_t *d_result = nullptr; size_t result_bytes = 0;   // [Ctrl | err (16 B) | contig_on]: d_ctrl, d_err, d_contig_on point into it
     Ctrl *d_ctrl = nullptr;
     uint8_t *d_contig_on = nullptr;
     long long *d_limbs = nullptr;       // multi-GPU: SUM-reducible statistics
@@ -193,6 +194,7 @@ SweepParams sweep_params(bossx_engine *h) {
     P.score0 = h->score0; P.tiny = std::numeric_limits<double>::min();
     P.tile_done = h->d_tile_done; P.epoch = h->epoch;
     P.publish = (h->overlap_ok && h->host_armed) ? 1 : 0;
+    P.dense = 0;
     return P;
 }
 
@@ -287,8 +289,8 @@ void bossx_destroy(bossx_engine *h) {
     if (h->d_tile_done) hipFree(h->d_tile_done);
     void *ptrs[] = {h->d_cov, h->d_meta, h->d_touched, h->d_strat, h->d_bucket_on, h->d_entropy, h->d_ds,
                     h->d_benefit, h->d_lut_score, h->d_lut_ent, h->d_fhat, h->d_bucket_sums, h->d_drop_count,
-                    h->d_stats, h->d_err, h->d_tile_off, h->d_site_off, h->d_length, h->d_bin_off, h->d_row_off,
-                    h->d_strat_off, h->d_bucket_off, h->d_drop_thr, h->d_local, h->d_ctrl, h->d_contig_on, h->d_limbs, h->d_tails,
+                    h->d_stats, h->d_result, h->d_tile_off, h->d_site_off, h->d_length, h->d_bin_off, h->d_row_off,
+                    h->d_strat_off, h->d_bucket_off, h->d_drop_thr, h->d_local, h->d_limbs, h->d_tails,
                     h->d_strat_bits};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &st : h->slots) { if (st.d_ops) hipFree(st.d_ops); if (st.d_tiles) hipFree(st.d_tiles); if (st.d_blob) hipFree(st.d_blob); if (st.d_segs) hipFree(st.d_segs); if (st.d_tilerefs) hipFree(st.d_tilerefs); }
@@ -404,9 +406,15 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
     if ((rc = dev_alloc(h, &h->d_drop_count, size_t(h->n_tiles), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_tile_ref, size_t(h->n_tiles), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_stats, size_t(BOSSX_HIST_BINS * 3 + 4 + 128), true))) return rc;
-    if ((rc = dev_alloc(h, &h->d_err, 1, true))) return rc;
-    if ((rc = dev_alloc(h, &h->d_ctrl, 1, true))) return rc;
-    if ((rc = dev_alloc(h, &h->d_contig_on, h->filt.size(), true))) return rc;
+    // control block, error flag and per-contig switches share one allocation: one D2H copy per update
+    {
+        const size_t bytes = sizeof(Ctrl) + 16 + h->filt.size();
+        if ((rc = dev_alloc(h, &h->d_result, bytes, true))) return rc;
+        h->d_ctrl = reinterpret_cast<Ctrl *>(h->d_result);
+        h->d_err = reinterpret_cast<int32_t *>(h->d_result + sizeof(Ctrl));
+        h->d_contig_on = h->d_result + sizeof(Ctrl) + 16;
+        h->result_bytes = bytes;
+    }
     if ((rc = dev_alloc(h, &h->d_limbs, size_t(BOSSX_HIST_BINS + 1) * 5, true))) return rc;
     if ((rc = dev_alloc(h, &h->d_tails, h->filt.size() * h->filt.size() * 2 * size_t(nb), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_lut_score, size_t(BOSSX_NCOMP) * 4, true))) return rc;
@@ -671,17 +679,35 @@ int launch_sweep(bossx_engine *h) {
         const double mean = double(c.cov_total) / double(c.length * int64_t(h->nb));
         thr[k] = (!c.remote && mean > 5) ? int32_t(mean / 8) : -1;
     }
-    HIPCHK(hipMemcpyAsync(h->d_drop_thr, thr.data(), thr.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemsetAsync(h->d_bucket_sums, 0, size_t(h->nb * h->NBK) * sizeof(unsigned long long), h->stream));
-    HIPCHK(hipMemsetAsync(h->d_ds, 0, size_t(h->nb * h->B) * sizeof(double), h->stream));
+    {
+        // one small launch clears the bucket sums and installs the thresholds.  The bin sums need no
+        // clearing: every bin of a local contig is rewritten by every sweep, the others stay zero.
+        PrepParams PR;
+        PR.bucket_sums = h->d_bucket_sums; PR.n_sums = h->nb * h->NBK;
+        PR.drop_thr = h->d_drop_thr; PR.n_thr = 0;
+        if (thr.size() <= 32) {
+            PR.n_thr = int32_t(thr.size());
+            for (size_t k = 0; k < thr.size(); ++k) PR.thr[k] = thr[k];
+        } else {
+            HIPCHK(hipMemcpyAsync(h->d_drop_thr, thr.data(), thr.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        }
+        const int64_t blocks = std::min<int64_t>((PR.n_sums + 255) / 256, 256);
+        hipLaunchKernelGGL(sweep_prep_kernel, dim3(uint32_t(std::max<int64_t>(blocks, 1))), dim3(256), 0, h->stream, PR);
+    }
     ++h->epoch;                                  // stamps the tile flags of this sweep
     SweepParams P = sweep_params(h);
     time_begin(h, BOSSX_K_SWEEP);
-    if (h->n_tiles > 0)
-        hipLaunchKernelGGL(site_sweep_kernel<false>, dim3(uint32_t(h->n_tiles)), dim3(256), 0, h->stream, P);
-    if (h->pending_slot >= 0 && !h->slots[size_t(h->pending_slot)].pb.tiles.empty())
-        hipLaunchKernelGGL(site_sweep_kernel<true>, dim3(uint32_t(h->slots[size_t(h->pending_slot)].pb.tiles.size())),
-                           dim3(256), 0, h->stream, P);
+    const size_t n_touched = h->pending_slot >= 0 ? h->slots[size_t(h->pending_slot)].pb.tiles.size() : 0;
+    if (n_touched * 2 >= size_t(h->n_tiles) && n_touched > 0) {
+        // most tiles receive bases: one launch over all tiles, each block looks its tile up
+        P.dense = 1;
+        hipLaunchKernelGGL(site_sweep_kernel<true>, dim3(uint32_t(h->n_tiles)), dim3(256), 0, h->stream, P);
+    } else {
+        if (h->n_tiles > 0)
+            hipLaunchKernelGGL(site_sweep_kernel<false>, dim3(uint32_t(h->n_tiles)), dim3(256), 0, h->stream, P);
+        if (n_touched)
+            hipLaunchKernelGGL(site_sweep_kernel<true>, dim3(uint32_t(n_touched)), dim3(256), 0, h->stream, P);
+    }
     // algorithmic bytes: per site*barcode 10 B counters + 1 B state read; per 100-site bin 8 B
     // downsampled score write; per ingested base 1 B read base + 2 B counter write-back, per
     // emit run 16 B (entropy / state write-backs of changed sites are data dependent and not
@@ -771,6 +797,7 @@ int fill_chain_params(bossx_engine *h, const int32_t *windows, const double *mul
     P.ds = h->d_ds; P.benefit = h->d_benefit; P.ctrl = h->d_ctrl; P.ct = table_of(h);
     P.B = h->B; P.nb = h->nb; P.ring = ring; P.gate = 0;
     P.tile_done = nullptr; P.epoch = h->epoch; P.wait_ticks = 200000000ll;   // 2 s
+    P.zero_stats = nullptr; P.n_zero = 0;
     P.probe = getenv("BOSSX_CHAIN_PROBE") ? reinterpret_cast<long long *>(h->d_stats + kStatWords + 8) : nullptr;
     P.max_limit = std::min<int64_t>(h->B, h->n_sites_all / kWindow);
     lds = size_t(ring) * sizeof(double);
@@ -850,9 +877,9 @@ int upload_fhat(bossx_engine *h, const bossx_fhat_desc *fh) {
     return BOSSX_OK;
 }
 
-int launch_hist(bossx_engine *h, const bossx_fhat_desc *fh, int gate) {
+int launch_hist(bossx_engine *h, const bossx_fhat_desc *fh, int gate, bool clear = true) {
     const int64_t target = h->n_sites_all / kWindow;
-    HIPCHK(hipMemsetAsync(h->d_stats, 0, kStatWords * sizeof(unsigned long long), h->stream));
+    if (clear) HIPCHK(hipMemsetAsync(h->d_stats, 0, kStatWords * sizeof(unsigned long long), h->stream));
     HistParams P;
     P.benefit = h->d_benefit; P.fhat_c = h->d_fhat;
     P.counts = h->d_stats; P.fgrid = h->d_stats + BOSSX_HIST_BINS; P.ubar = h->d_stats + BOSSX_HIST_BINS * 3;
@@ -870,12 +897,14 @@ int launch_hist(bossx_engine *h, const bossx_fhat_desc *fh, int gate) {
     return BOSSX_OK;
 }
 
-int launch_mask(bossx_engine *h, int gate, bool with_tails = false) {
+int launch_mask(bossx_engine *h, int gate, bool with_tails = false, const PickParams *pick = nullptr) {
     MaskParams P;
+    P.do_pick = pick ? 1 : 0;
+    if (pick) P.pick = *pick; else P.pick = PickParams{};
     P.benefit = h->d_benefit; P.bucket_on = h->d_bucket_on; P.strat = h->d_strat; P.ct = table_of(h);
     P.B = h->B; P.NBK = h->NBK; P.rows = h->rows; P.nb = h->nb; P.gate = gate; P.ctrl = h->d_ctrl;
     P.tails = with_tails ? h->d_tails : nullptr; P.tail_k = int32_t(h->filt.size());
-    const int64_t blocks = std::min<int64_t>((h->rows + 255) / 256, 4096);
+    const int64_t blocks = std::min<int64_t>((h->rows + 255) / 256, pick ? 1024 : 4096);
     time_begin(h, BOSSX_K_MASK);
     hipLaunchKernelGGL(strategy_mask_kernel, dim3(uint32_t(std::max<int64_t>(blocks, 1))), dim3(256), 0, h->stream, P);
     // algorithmic bytes: both strands' benefit read once, one mask byte written per row*strand*barcode
@@ -1002,15 +1031,13 @@ int bossx_dist_finish(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, b
     HIPCHK(hipSetDevice(h->cfg.device));
     int rc = launch_mask(h, 1, true);
     if (rc) return rc;
-    const size_t need = sizeof(Ctrl) + sizeof(int32_t) + h->filt.size();
+    const size_t need = h->result_bytes;
     if ((rc = ensure_pin(h, need + 64))) return rc;
     char *pin = static_cast<char *>(h->h_pin);
     Ctrl *hc = reinterpret_cast<Ctrl *>(pin);
     int32_t *herr = reinterpret_cast<int32_t *>(pin + sizeof(Ctrl));
-    uint8_t *hon = reinterpret_cast<uint8_t *>(pin + sizeof(Ctrl) + sizeof(int32_t));
-    HIPCHK(hipMemcpyAsync(hc, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(herr, h->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(hon, h->d_contig_on, h->filt.size(), hipMemcpyDeviceToHost, h->stream));
+    uint8_t *hon = reinterpret_cast<uint8_t *>(pin + sizeof(Ctrl) + 16);
+    HIPCHK(hipMemcpyAsync(pin, h->d_result, h->result_bytes, hipMemcpyDeviceToHost, h->stream));
     if (strat_all && (rc = copy_masks(h, strat_all, false))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     if (*herr) {
@@ -1060,6 +1087,7 @@ int bossx_update_benefit(bossx_engine *h, const int32_t *windows, const double *
     int rc = fill_chain_params(h, windows, mult, CP, lds);
     if (rc) return rc;
     CP.gate = 1;
+    CP.zero_stats = h->d_stats; CP.n_zero = int32_t(kStatWords);    // for the histogram of bossx_update
     if (h->overlap_ok && h->host_armed && h->sweep_in_flight) {
         // The strategy is switched on (the gate is known to be open) and this update's sweep is in
         // flight on the main stream: run the chain NEXT TO it on stream2.  The sweep hands tiles
@@ -1102,36 +1130,35 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
         launch_buckets(h, up->bucket_threshold);
     }
     h->sweep_in_flight = false;
-    const size_t need = sizeof(Ctrl) + sizeof(int32_t) + h->filt.size() + (counts ? kStatWords * 8 : 0);
+    const size_t need = h->result_bytes + 16 + (counts ? kStatWords * 8 : 0);
     if ((rc = ensure_pin(h, need + 64))) return rc;
     char *pin = static_cast<char *>(h->h_pin);
     Ctrl *hc = reinterpret_cast<Ctrl *>(pin);
     int32_t *herr = reinterpret_cast<int32_t *>(pin + sizeof(Ctrl));
-    uint8_t *hon = reinterpret_cast<uint8_t *>(pin + sizeof(Ctrl) + sizeof(int32_t));
-    unsigned long long *hst = reinterpret_cast<unsigned long long *>(pin + ((sizeof(Ctrl) + sizeof(int32_t) + h->filt.size() + 15) & ~size_t(15)));
+    uint8_t *hon = reinterpret_cast<uint8_t *>(pin + sizeof(Ctrl) + 16);
+    unsigned long long *hst = reinterpret_cast<unsigned long long *>(pin + ((h->result_bytes + 15) & ~size_t(15)));
     bool chain_done = (up->flags & BOSSX_UPDATE_BENEFIT_DONE) != 0;
     for (int attempt = 0;; ++attempt) {
         if (have_strategy_inputs) {
             if (!chain_done) {
                 HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream));
                 CP.gate = 1;
+                CP.zero_stats = h->d_stats; CP.n_zero = int32_t(kStatWords);
                 launch_chain(h, CP, lds);
             } else if (h->chain_on_stream2) {
                 HIPCHK(hipStreamWaitEvent(h->stream, h->ev_chain, 0));     // the chain ran next to the sweep
             }
             h->chain_on_stream2 = false;
-            if ((rc = launch_hist(h, &fh, 1))) return rc;
+            // the chain kernel cleared the statistics; the mask kernel picks the threshold itself
+            if ((rc = launch_hist(h, &fh, 1, /*clear=*/false))) return rc;
             PickParams PP;
             PP.counts = h->d_stats; PP.fgrid = h->d_stats + BOSSX_HIST_BINS; PP.ubar = h->d_stats + BOSSX_HIST_BINS * 3;
             PP.limbs = nullptr; PP.ctrl = h->d_ctrl; PP.tc = up->tc; PP.gate = 1;
-            hipLaunchKernelGGL(threshold_pick_kernel, dim3(1), dim3(64), 0, h->stream, PP);
-            if ((rc = launch_mask(h, 1))) return rc;
+            if ((rc = launch_mask(h, 1, false, &PP))) return rc;
         }
         HIPCHK(hipGetLastError());
         // results
-        HIPCHK(hipMemcpyAsync(hc, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(herr, h->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(hon, h->d_contig_on, h->filt.size(), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(pin, h->d_result, h->result_bytes, hipMemcpyDeviceToHost, h->stream));
         if (counts) HIPCHK(hipMemcpyAsync(hst, h->d_stats, kStatWords * 8, hipMemcpyDeviceToHost, h->stream));
         if (strat_all && have_strategy_inputs && (rc = copy_masks(h, strat_all, (up->flags & BOSSX_UPDATE_STRAT_BITS) != 0))) return rc;
         HIPCHK(hipStreamSynchronize(h->stream));
