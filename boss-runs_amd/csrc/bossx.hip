@@ -29,6 +29,7 @@ struct bossx_engine {
     uint32_t epoch = 0;
     bool overlap_ok = false;           // decided at finalize (BOSSX_OVERLAP / BOSSX_NO_OVERLAP / size); cleared after a chain time-out
     bool host_armed = false;           // the host has seen ctrl.any_on set
+    bool max_bits_clear = false;       // the sweep's prep launch zeroed ctrl.max_bits and no chain has run since
     bool sweep_in_flight = false;      // update_begin enqueued a sweep that no update has consumed yet
     bool chain_on_stream2 = false;     // update_benefit put the chain on stream2 (ev_chain pending)
     bool finalized = false;
@@ -205,8 +206,6 @@ int flush_pending(bossx_engine *h) {
     if (h->pending_slot < 0) return BOSSX_OK;
     bossx_engine::Staged &st = h->slots[size_t(h->pending_slot)];
     ParsedBatch &pb = st.pb;
-    const uint32_t n = uint32_t(pb.tiles.size());
-    hipLaunchKernelGGL(tile_ref_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, st.d_tilerefs, n, h->d_tile_ref, 0);
     const uint32_t n_tiles = uint32_t((pb.total_emit + kEmitTile - 1) / kEmitTile);
     if (!st.emit_tiles_built) {                // emit-order tiling is only needed on this path
         if (size_t(n_tiles) + 1 > st.tiles_cap) {
@@ -649,10 +648,8 @@ int bossx_ingest_staged(bossx_engine *h) {
     const ParsedBatch &pb = st.pb;
     for (size_t i = 0; i < h->contigs.size(); ++i) h->contigs[i].cov_total += pb.emitted_per_contig[i];
     if (pb.total_emit == 0) return BOSSX_OK;
-    // the increments are applied by the next sweep, tile by tile (site_sweep_kernel prologue)
-    const uint32_t n = uint32_t(pb.tiles.size());
-    hipLaunchKernelGGL(tile_ref_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, st.d_tilerefs, n, h->d_tile_ref, 1);
-    HIPCHK(hipGetLastError());
+    // the increments are applied by the next sweep, tile by tile (site_sweep_kernel prologue);
+    // its prep launch marks the touched tiles
     h->pending_slot = h->slot;
     h->pending_emit = double(pb.total_emit);
     h->pending_ops = double(pb.n_ops);
@@ -685,14 +682,24 @@ int launch_sweep(bossx_engine *h) {
         PrepParams PR;
         PR.bucket_sums = h->d_bucket_sums; PR.n_sums = h->nb * h->NBK;
         PR.drop_thr = h->d_drop_thr; PR.n_thr = 0;
+        PR.max_bits = &h->d_ctrl->max_bits;
+        PR.tiles = nullptr; PR.n_tiles = 0; PR.tile_ref = h->d_tile_ref;
+        if (h->pending_slot >= 0) {
+            const bossx_engine::Staged &st = h->slots[size_t(h->pending_slot)];
+            PR.tiles = st.d_tilerefs; PR.n_tiles = uint32_t(st.pb.tiles.size());
+        }
         if (thr.size() <= 32) {
             PR.n_thr = int32_t(thr.size());
             for (size_t k = 0; k < thr.size(); ++k) PR.thr[k] = thr[k];
         } else {
             HIPCHK(hipMemcpyAsync(h->d_drop_thr, thr.data(), thr.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
         }
-        const int64_t blocks = std::min<int64_t>((PR.n_sums + 255) / 256, 256);
+        const int64_t blocks = std::min<int64_t>((std::max<int64_t>(PR.n_sums, int64_t(PR.n_tiles)) + 255) / 256, 1024);
+        h->max_bits_clear = true;
         hipLaunchKernelGGL(sweep_prep_kernel, dim3(uint32_t(std::max<int64_t>(blocks, 1))), dim3(256), 0, h->stream, PR);
+        // everything up to here precedes a chain that update_benefit may put on stream2 next to
+        // the sweep (it needs max_bits cleared, and the previous update's readers finished)
+        HIPCHK(hipEventRecord(h->ev_begin, h->stream));
     }
     ++h->epoch;                                  // stamps the tile flags of this sweep
     SweepParams P = sweep_params(h);
@@ -956,9 +963,7 @@ int bossx_update_begin(bossx_engine *h, double bucket_threshold) {
     if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "bad update_begin call");
     if (!h->lut_set) return fail(h, BOSSX_E_INVALID, "update before set_lut");
     HIPCHK(hipSetDevice(h->cfg.device));
-    // everything enqueued so far precedes a chain that update_benefit may put on stream2
-    HIPCHK(hipEventRecord(h->ev_begin, h->stream));
-    int rc = launch_sweep(h);
+    int rc = launch_sweep(h);      // records ev_begin between its prep launch and the sweep proper
     if (rc) return rc;
     launch_buckets(h, bucket_threshold);
     HIPCHK(hipGetLastError());
@@ -1094,16 +1099,17 @@ int bossx_update_benefit(bossx_engine *h, const int32_t *windows, const double *
         // out from both contig ends and publishes each tile's bin sums (tile_done == epoch); the
         // chain's prefetch wave waits for the tiles of a chunk before reading it.
         HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_begin, 0));
-        HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream2));
+        if (!h->max_bits_clear) HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream2));
         CP.tile_done = h->d_tile_done; CP.epoch = h->epoch;
         if (getenv("BOSSX_OVERLAP_SELFTEST")) { CP.epoch = h->epoch + 1; CP.wait_ticks = 500000; }   // never satisfied: exercises the time-out path
         launch_chain(h, CP, lds, h->stream2);
         HIPCHK(hipEventRecord(h->ev_chain, h->stream2));
         h->chain_on_stream2 = true;
     } else {
-        HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream));
+        if (!h->max_bits_clear) HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream));
         launch_chain(h, CP, lds);
     }
+    h->max_bits_clear = false;
     HIPCHK(hipGetLastError());
     return BOSSX_OK;
 }
@@ -1141,7 +1147,8 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
     for (int attempt = 0;; ++attempt) {
         if (have_strategy_inputs) {
             if (!chain_done) {
-                HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream));
+                if (!h->max_bits_clear) HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream));
+                h->max_bits_clear = false;
                 CP.gate = 1;
                 CP.zero_stats = h->d_stats; CP.n_zero = int32_t(kStatWords);
                 launch_chain(h, CP, lds);
