@@ -896,7 +896,9 @@ int launch_hist(bossx_engine *h, const bossx_fhat_desc *fh, int gate, bool clear
     P.nb = h->nb; P.all_local = h->all_local ? 1 : 0; P.gate = gate; P.ctrl = h->d_ctrl;
     if (P.d2 < 0) P.d2 = 0;   // trimmed instead of padded: indices unchanged
     if (P.d1 < 0) P.d1 = 0;
-    const int64_t blocks = std::min<int64_t>((target + 255) / 256, 2048);
+    P.run = target >= (int64_t(1) << 18) ? 16 : 2;
+    const int64_t span = int64_t(256) * P.run;
+    const int64_t blocks = std::min<int64_t>((target + span - 1) / span, 2048);
     time_begin(h, BOSSX_K_HIST);
     hipLaunchKernelGGL(threshold_hist_kernel, dim3(uint32_t(std::max<int64_t>(blocks, 1)), uint32_t(h->nb * 2)), dim3(256), 0, h->stream, P);
     time_end(h, BOSSX_K_HIST, double(target) * h->nb * 2 * 8.0);
