@@ -182,12 +182,12 @@ void time_collect(bossx_engine *h) {
 SweepParams sweep_params(bossx_engine *h) {
     SweepParams P;
     P.cov = h->d_cov; P.meta = h->d_meta; P.touched = h->d_touched; P.entropy = h->d_entropy;
-    P.tile_ref = h->d_tile_ref; P.tiles = nullptr; P.segs = nullptr; P.ops = nullptr; P.blob = nullptr;
+    P.tile_ref = h->d_tile_ref; P.tiles = nullptr; P.n_groups = 0; P.segs = nullptr; P.ops = nullptr; P.blob = nullptr;
     P.err_flag = h->d_err; P.use_touched = h->touched_dirty ? 1 : 0;
     P.probe = getenv("BOSSX_SWEEP_PROBE") ? h->d_stats + kStatWords + 80 : nullptr;
     if (h->pending_slot >= 0) {
         const bossx_engine::Staged &st = h->slots[size_t(h->pending_slot)];
-        P.tiles = st.d_tilerefs; P.segs = st.d_segs; P.ops = st.d_ops; P.blob = st.d_blob;
+        P.tiles = st.d_tilerefs; P.n_groups = uint32_t(st.pb.tiles.size()); P.segs = st.d_segs; P.ops = st.d_ops; P.blob = st.d_blob;
     }
     P.ds = h->d_ds; P.bucket_sums = h->d_bucket_sums; P.drop_count = h->d_drop_count;
     P.lut_score = h->d_lut_score; P.lut_ent = h->d_lut_ent; P.ct = table_of(h);
@@ -704,7 +704,8 @@ int launch_sweep(bossx_engine *h) {
     ++h->epoch;                                  // stamps the tile flags of this sweep
     SweepParams P = sweep_params(h);
     time_begin(h, BOSSX_K_SWEEP);
-    const size_t n_touched = h->pending_slot >= 0 ? h->slots[size_t(h->pending_slot)].pb.tiles.size() : 0;
+    const size_t n_groups = h->pending_slot >= 0 ? h->slots[size_t(h->pending_slot)].pb.tiles.size() : 0;
+    const size_t n_touched = h->pending_slot >= 0 ? h->slots[size_t(h->pending_slot)].pb.n_touched_tiles : 0;
     if (n_touched * 2 >= size_t(h->n_tiles) && n_touched > 0) {
         // most tiles receive bases: one launch over all tiles, each block looks its tile up
         P.dense = 1;
@@ -712,8 +713,8 @@ int launch_sweep(bossx_engine *h) {
     } else {
         if (h->n_tiles > 0)
             hipLaunchKernelGGL(site_sweep_kernel<false>, dim3(uint32_t(h->n_tiles)), dim3(256), 0, h->stream, P);
-        if (n_touched)
-            hipLaunchKernelGGL(site_sweep_kernel<true>, dim3(uint32_t(n_touched)), dim3(256), 0, h->stream, P);
+        if (n_groups)    // one block per (tile, barcode) group; the first group of a tile does the tile
+            hipLaunchKernelGGL(site_sweep_kernel<true>, dim3(uint32_t(n_groups)), dim3(256), 0, h->stream, P);
     }
     // algorithmic bytes: per site*barcode 10 B counters + 1 B state read; per 100-site bin 8 B
     // downsampled score write; per ingested base 1 B read base + 2 B counter write-back, per

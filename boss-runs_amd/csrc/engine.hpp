@@ -57,11 +57,12 @@ struct TileSeg {
     uint32_t e_lo, e_hi;      // emit-index range [e_lo, e_hi)
     uint32_t op_lo, op_hi;    // first and last (inclusive) emit run overlapping the range
 };
-// A sweep tile that receives bases from the batch, with its slice of the segment list.
+// The segments one barcode contributes to one sweep tile.  The groups of a tile are consecutive
+// (ascending barcode); a tile's first group is what tile_ref points at.
 struct TileRef {
     uint32_t tile;            // global sweep tile index
     uint32_t seg_lo, seg_hi;  // segments [seg_lo, seg_hi)
-    uint32_t pad;
+    uint32_t bc;              // barcode index of every segment of the group
 };
 
 // The emit runs are written by the parser's threads into the caller's buffer (ParseInput::
@@ -76,7 +77,8 @@ struct ParsedBatch {
     std::vector<OpsChunk> chunks;
     size_t n_ops = 0;
     std::vector<TileSeg> segs;             // grouped by tile; op_lo/op_hi are device indices
-    std::vector<TileRef> tiles;            // touched tiles, ascending
+    std::vector<TileRef> tiles;            // (tile, barcode) groups, ascending
+    size_t n_touched_tiles = 0;            // distinct tiles among them
     uint64_t total_emit = 0;
     std::vector<uint64_t> emitted_per_contig;   // indexed by contig add order
     int32_t n_rec = 0;

@@ -168,6 +168,7 @@ struct WalkOut {
     size_t n_ops = 0;                      // runs written, contiguous from `base`
     std::vector<TileSeg> segs;             // op_lo / op_hi relative to the thread's base
     std::vector<uint32_t> seg_tile;
+    std::vector<uint8_t> seg_bc;
     std::vector<uint64_t> emitted_per_contig;
     WalkError err;
 };
@@ -258,6 +259,7 @@ void walk_plans(const ParseInput &in, const std::vector<ContigInfo> &contigs, co
                     sg.op_hi = uint32_t(oh - base);
                     wo.segs.push_back(sg);
                     wo.seg_tile.push_back(uint32_t(t));
+                    wo.seg_bc.push_back(uint8_t(pl.bc));
                 }
             }
         }
@@ -439,7 +441,9 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
     size_t n_segs = 0, dev_off = 0;
     for (const WalkOut &wo : wos) n_segs += wo.segs.size();
     std::vector<uint32_t> tile_of, order, tmp;
+    std::vector<uint8_t> bc_of;
     tile_of.reserve(n_segs);
+    bc_of.reserve(n_segs);
     std::vector<const TileSeg *> seg_ptr;
     seg_ptr.reserve(n_segs);
     std::vector<uint32_t> seg_base;
@@ -449,6 +453,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         if (wo.n_ops) out.chunks.push_back(OpsChunk{wo.base, wo.n_ops, dev_off});
         for (size_t i = 0; i < wo.segs.size(); ++i) {
             tile_of.push_back(wo.seg_tile[i]);
+            bc_of.push_back(wo.seg_bc[i]);
             max_tile = std::max(max_tile, wo.seg_tile[i]);
             seg_ptr.push_back(&wo.segs[i]);
             seg_base.push_back(uint32_t(dev_off));
@@ -457,10 +462,18 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         dev_off += wo.n_ops;
     }
     out.n_ops = dev_off;
-    // stable LSD radix sort of the segment indices by tile id, 11 bits per pass
+    // stable LSD radix sort of the segment indices by (tile, barcode): barcode pass first, then the
+    // tile id 11 bits per pass
     order.resize(n_segs);
     for (size_t i = 0; i < n_segs; ++i) order[i] = uint32_t(i);
     tmp.resize(n_segs);
+    if (in.nbarcodes > 1) {
+        uint32_t count[257] = {0};
+        for (size_t i = 0; i < n_segs; ++i) ++count[uint32_t(bc_of[order[i]]) + 1];
+        for (int b = 0; b < 256; ++b) count[b + 1] += count[b];
+        for (size_t i = 0; i < n_segs; ++i) tmp[count[bc_of[order[i]]]++] = order[i];
+        order.swap(tmp);
+    }
     for (uint32_t shift = 0; shift < 32 && (max_tile >> shift) != 0; shift += 11) {
         uint32_t count[2049] = {0};
         for (size_t i = 0; i < n_segs; ++i) ++count[((tile_of[order[i]] >> shift) & 2047u) + 1];
@@ -468,11 +481,14 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         for (size_t i = 0; i < n_segs; ++i) tmp[count[(tile_of[order[i]] >> shift) & 2047u]++] = order[i];
         order.swap(tmp);
     }
+    // one TileRef per (tile, barcode) group; the groups of a tile are consecutive
     out.segs.reserve(n_segs);
+    out.n_touched_tiles = 0;
     for (uint32_t idx : order) {
-        const uint32_t t = tile_of[idx];
-        if (out.tiles.empty() || out.tiles.back().tile != t)
-            out.tiles.push_back(TileRef{t, uint32_t(out.segs.size()), uint32_t(out.segs.size()), 0});
+        const uint32_t t = tile_of[idx], bc = bc_of[idx];
+        if (out.tiles.empty() || out.tiles.back().tile != t) ++out.n_touched_tiles;
+        if (out.tiles.empty() || out.tiles.back().tile != t || out.tiles.back().bc != bc)
+            out.tiles.push_back(TileRef{t, uint32_t(out.segs.size()), uint32_t(out.segs.size()), bc});
         TileSeg sg = *seg_ptr[idx];
         sg.op_lo += seg_base[idx]; sg.op_hi += seg_base[idx];
         out.segs.push_back(sg);
@@ -559,10 +575,16 @@ extern "C" int bossx_host_parse(const char *const *contig_names, const int64_t *
             const uint64_t s0 = ((uint64_t(o.meta & 0xffu) << 32) | o.site_lo) + (sg.e_lo - o.emit_start);
             if (s0 / kTileSites != tr.tile || (s0 + (sg.e_hi - sg.e_lo) - 1) / kTileSites != tr.tile)
                 return fail(BOSSX_E_INVALID, "segment crosses its tile");
+            for (uint32_t o2 = sg.op_lo; o2 <= sg.op_hi; ++o2)
+                if (((ops[o2].meta >> 8) & 0xffu) != tr.bc) return fail(BOSSX_E_INVALID, "segment in the wrong barcode group");
             seg_total += sg.e_hi - sg.e_lo;
         }
     }
     if (seg_total != pb.total_emit) return fail(BOSSX_E_INVALID, "segments do not cover the batch");
+    for (size_t i = 1; i < pb.tiles.size(); ++i) {
+        const TileRef &a = pb.tiles[i - 1], &b = pb.tiles[i];
+        if (b.tile < a.tile || (b.tile == a.tile && b.bc <= a.bc)) return fail(BOSSX_E_INVALID, "tile groups out of order");
+    }
     if (!out_contig) return BOSSX_OK;
     if (out_cap < int64_t(pb.total_emit)) return fail(BOSSX_E_INVALID, "output arrays too small");
     for (size_t i = 0; i < ops.size(); ++i) {
