@@ -30,6 +30,7 @@ struct bossx_engine {
     bool overlap_ok = false;           // decided at finalize (BOSSX_OVERLAP / BOSSX_NO_OVERLAP / size); cleared after a chain time-out
     bool host_armed = false;           // the host has seen ctrl.any_on set
     bool max_bits_clear = false;       // the sweep's prep launch zeroed ctrl.max_bits and no chain has run since
+    bool sweep_published = false;      // the last sweep launch publishes its tiles (tile_done flags, agent-scope bin stores)
     bool sweep_in_flight = false;      // update_begin enqueued a sweep that no update has consumed yet
     bool chain_on_stream2 = false;     // update_benefit put the chain on stream2 (ev_chain pending)
     bool finalized = false;
@@ -194,7 +195,7 @@ SweepParams sweep_params(bossx_engine *h) {
     P.Gp = h->Gp; P.B = h->B; P.NBK = h->NBK; P.nb = h->nb;
     P.score0 = h->score0; P.tiny = std::numeric_limits<double>::min();
     P.tile_done = h->d_tile_done; P.epoch = h->epoch;
-    P.publish = (h->overlap_ok && h->host_armed) ? 1 : 0;
+    P.publish = h->sweep_published ? 1 : 0;
     P.dense = 0;
     return P;
 }
@@ -702,6 +703,7 @@ int launch_sweep(bossx_engine *h) {
         HIPCHK(hipEventRecord(h->ev_begin, h->stream));
     }
     ++h->epoch;                                  // stamps the tile flags of this sweep
+    h->sweep_published = h->overlap_ok && h->host_armed;   // tiles are published only if a chain may run next to this sweep
     SweepParams P = sweep_params(h);
     time_begin(h, BOSSX_K_SWEEP);
     const size_t n_groups = h->pending_slot >= 0 ? h->slots[size_t(h->pending_slot)].pb.tiles.size() : 0;
@@ -1096,7 +1098,7 @@ int bossx_update_benefit(bossx_engine *h, const int32_t *windows, const double *
     if (rc) return rc;
     CP.gate = 1;
     CP.zero_stats = h->d_stats; CP.n_zero = int32_t(kStatWords);    // for the histogram of bossx_update
-    if (h->overlap_ok && h->host_armed && h->sweep_in_flight) {
+    if (h->overlap_ok && h->sweep_published && h->sweep_in_flight) {
         // The strategy is switched on (the gate is known to be open) and this update's sweep is in
         // flight on the main stream: run the chain NEXT TO it on stream2.  The sweep hands tiles
         // out from both contig ends and publishes each tile's bin sums (tile_done == epoch); the
