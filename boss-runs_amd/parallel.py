@@ -93,10 +93,10 @@ class Comm:
         if self.world == 1 and not self.force:
             return arr[np.newaxis].copy()
         t = self._t(arr)
-        out = [self.torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(out, t)
+        out = self.torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        self.dist.all_gather(list(out.unbind(0)), t)     # views of one tensor: one copy back (gloo has no all_gather_into_tensor)
         self.n_collectives += 1
-        return np.stack([o.cpu().numpy() for o in out])
+        return out.cpu().numpy()
 
 
 def fx_to_limbs(fx):
@@ -208,19 +208,23 @@ class DistributedBossRuns(BossRuns):
             k, m = len(summ["contig_idx"]), len(read_lengths)
             if k > cap or m > cap:
                 raise ValueError("batch larger than READ_CAP")
-            buf = np.zeros((2 * cap + 1, 4), dtype=np.int64)
-            buf[0, :3] = (k, m, n_reads)
-            buf[1:1 + k, 0] = summ["contig_idx"]
-            buf[1:1 + k, 1] = summ["rev"]
-            buf[1:1 + k, 2] = summ["tstart"]
-            buf[1:1 + k, 3] = summ["tend"]
-            buf[1 + cap:1 + cap + m, 0] = read_lengths
+            # one int32 record: header (k, m, n_reads) + contig / strand / start / end columns of
+            # the k chosen mappings + the m read lengths (positions and lengths are < 2^31)
+            buf = np.zeros(4 + 5 * cap, dtype=np.int32)
+            buf[:3] = (k, m, n_reads)
+            buf[4:4 + k] = summ["contig_idx"]
+            buf[4 + cap:4 + cap + k] = summ["rev"]
+            buf[4 + 2 * cap:4 + 2 * cap + k] = summ["tstart"]
+            buf[4 + 3 * cap:4 + 3 * cap + k] = summ["tend"]
+            buf[4 + 4 * cap:4 + 4 * cap + m] = np.minimum(read_lengths, 2 ** 31 - 1)
             allb = self.comm.allgather(buf)
-            rec = np.concatenate([b[1:1 + int(b[0, 0])] for b in allb])
-            read_lengths = np.concatenate([b[1 + cap:1 + cap + int(b[0, 1]), 0] for b in allb])
-            n_reads = int(sum(int(b[0, 2]) for b in allb))
-            summ = dict(contig_idx=rec[:, 0], rev=rec[:, 1], tstart=rec[:, 2], tend=rec[:, 3])
+            ks = [int(b[0]) for b in allb]
+            col = lambda j: np.concatenate([b[4 + j * cap:4 + j * cap + kk] for b, kk in zip(allb, ks)]).astype(np.int64)
+            read_lengths = np.concatenate([b[4 + 4 * cap:4 + 4 * cap + int(b[1])] for b in allb]).astype(np.int64)
+            n_reads = int(sum(int(b[2]) for b in allb))
+            summ = dict(contig_idx=col(0), rev=col(1), tstart=col(2), tend=col(3))
         self.rl_dist.update(read_lengths)
+        self._launch_chain_early()          # the chain needs only the read-length windows
         self.total_reads += n_reads
         ci = np.asarray(summ["contig_idx"])
         for i, n in enumerate(np.bincount(ci[ci >= 0], minlength=len(self.contig_names))):
@@ -237,6 +241,23 @@ class DistributedBossRuns(BossRuns):
             self.engine.update_begin(self.args.optional.bucket_threshold)
             self._begun = True
 
+    def _launch_chain_early(self):
+        """In-stream protocol, sweep already enqueued: as soon as the global read-length windows
+        are known, exchange the "some strategy is on" flag (until it is) and enqueue the chain, so
+        that it runs while the host still counts read starts and builds f-hat."""
+        self._chain_early = False
+        if not (getattr(self, "instream", False) and self._begun and hasattr(self.rl_dist, "time_cost")
+                and getattr(self, "early_chain", True) and self.comm.dist is not None):
+            return
+        dist, torch = self.comm.dist, self.comm.torch
+        with torch.cuda.stream(self.tstream):
+            if not self.armed:
+                dist.all_reduce(self.t_armed, op=dist.ReduceOp.MAX)      # core.py:111 is a global decision
+                self.comm.n_collectives += 1
+            windows = np.concatenate(([400 // 100], self.rl_dist.approx_ccl // 100)).astype(np.int32)
+            self.engine.update_benefit(windows, MULT)                    # gated on the (now global) flag
+        self._chain_early = True
+
     def _update_instream(self) -> None:
         """The update with device-resident statistics: four in-stream RCCL all-reduces between
         asynchronous engine stages, one synchronisation at the end (bossx.h, bossx_device_ptr)."""
@@ -245,18 +266,23 @@ class DistributedBossRuns(BossRuns):
         self.begin_update()
         self._begun = False
         have_rl = hasattr(self.rl_dist, "time_cost")
+        early = getattr(self, "_chain_early", False)
+        self._chain_early = False
         with torch.cuda.stream(self.tstream):                    # collectives ordered on the engine's stream
-            dist.all_reduce(self.t_armed, op=MAXOP)              # core.py:111 is a global decision
+            if not early and not self.armed:                     # sticky: once on everywhere, no exchange
+                dist.all_reduce(self.t_armed, op=MAXOP)          # core.py:111 is a global decision
+                self.comm.n_collectives += 1
             if have_rl:
-                windows = np.concatenate(([400 // 100], self.rl_dist.approx_ccl // 100)).astype(np.int32)
-                eng.update_benefit(windows, MULT)                # gated on the (now global) flag
+                if not early:
+                    windows = np.concatenate(([400 // 100], self.rl_dist.approx_ccl // 100)).astype(np.int32)
+                    eng.update_benefit(windows, MULT)            # gated on the (now global) flag
                 dist.all_reduce(self.t_norm, op=MAXOP)
                 fhat_c, target_rs = self.read_starts.fhat_compact()
                 eng.dist_hist(fhat_c, target_rs, self.ref.n_sites // 100)
                 dist.all_reduce(self.t_limbs, op=SUMOP)
                 eng.dist_pick(self.rl_dist.time_cost // 100)
                 dist.all_reduce(self.t_tails, op=SUMOP)
-        self.comm.n_collectives += 4 if have_rl else 1
+                self.comm.n_collectives += 3
         res = eng.dist_finish()
         for cont in self.local_filt.values():
             if res["contig_on"][cont.index]:
