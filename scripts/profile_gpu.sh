@@ -11,6 +11,8 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--workload $W --no-cpu-baseline --no-large ${BENCH_ARGS}"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o "$W" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_trace.log" 2>&1
+# counter collection serialises kernels: keep the chain after the sweep (it would time out and fall back anyway)
+export BOSSX_NO_OVERLAP=1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o "$W" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o "$W" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_write.log" 2>&1
 tail -1 "$OUT/bench_trace.log" | cut -c1-300
