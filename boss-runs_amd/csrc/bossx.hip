@@ -196,7 +196,7 @@ SweepParams sweep_params(bossx_engine *h) {
     P.score0 = h->score0; P.tiny = std::numeric_limits<double>::min();
     P.tile_done = h->d_tile_done; P.epoch = h->epoch;
     P.publish = h->sweep_published ? 1 : 0;
-    P.dense = 0;
+    P.dense = 0; P.ingest_only = 0;
     return P;
 }
 
@@ -708,7 +708,18 @@ int launch_sweep(bossx_engine *h) {
     time_begin(h, BOSSX_K_SWEEP);
     const size_t n_groups = h->pending_slot >= 0 ? h->slots[size_t(h->pending_slot)].pb.tiles.size() : 0;
     const size_t n_touched = h->pending_slot >= 0 ? h->slots[size_t(h->pending_slot)].pb.n_touched_tiles : 0;
-    if (n_touched * 2 >= size_t(h->n_tiles) && n_touched > 0) {
+    // With several barcodes a touched tile costs nb scoring passes at the ingest variant's low
+    // occupancy (LDS staging, 4 blocks/CU): split the work instead — an ingest-only launch applies
+    // the increments and leaves `touched` flags, then the plain variant (8 waves/SIMD) scores
+    // every tile.  (With one barcode the fused form is faster: 0.17 vs 0.36 ms for E. coli.)
+    const char *split_env = getenv("BOSSX_SPLIT_INGEST");
+    const bool split = n_groups > 0 && (split_env ? atoi(split_env) != 0 : h->nb >= 3);
+    if (split) {
+        P.ingest_only = 1;
+        hipLaunchKernelGGL(site_sweep_kernel<true>, dim3(uint32_t(n_groups)), dim3(256), 0, h->stream, P);
+        P.ingest_only = 0; P.tiles = nullptr; P.n_groups = 0; P.use_touched = 1;
+        hipLaunchKernelGGL(site_sweep_kernel<false>, dim3(uint32_t(h->n_tiles)), dim3(256), 0, h->stream, P);
+    } else if (n_touched * 2 >= size_t(h->n_tiles) && n_touched > 0) {
         // most tiles receive bases: one launch over all tiles, each block looks its tile up
         P.dense = 1;
         hipLaunchKernelGGL(site_sweep_kernel<true>, dim3(uint32_t(h->n_tiles)), dim3(256), 0, h->stream, P);
@@ -725,7 +736,7 @@ int launch_sweep(bossx_engine *h) {
     double sites = 0;
     for (int32_t fi : h->filt) if (!h->contigs[size_t(fi)].remote) sites += double(h->contigs[size_t(fi)].length);
     double bytes = sites * h->nb * 11.0 + double(h->B) * h->nb * 8.0;
-    if (h->touched_dirty) bytes += sites;
+    if (h->touched_dirty || split) bytes += sites;
     if (h->pending_slot >= 0) bytes += 3.0 * h->pending_emit + 16.0 * h->pending_ops;
     time_end(h, BOSSX_K_SWEEP, bytes);
     HIPCHK(hipGetLastError());
