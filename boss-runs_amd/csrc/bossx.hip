@@ -528,10 +528,10 @@ int bossx_stage_batch(bossx_engine *h, const char *paf, size_t paf_len, const ch
         st.ops_cap = pb.n_ops * 9 / 8 + 1024;
         if ((rc = dev_alloc(h, &st.d_ops, st.ops_cap))) return rc;
     }
-    if (blob_bytes + 16 > st.blob_cap) {
+    if (blob_bytes + 1024 > st.blob_cap) {       // slack: the ingest prologue reads a 384-byte window that may start at the last base
         if (st.d_blob) HIPCHK(hipFree(st.d_blob));
         st.d_blob = nullptr;
-        st.blob_cap = (blob_bytes + 16) * 9 / 8;
+        st.blob_cap = (blob_bytes + 1024) * 9 / 8;
         if ((rc = dev_alloc(h, &st.d_blob, st.blob_cap))) return rc;
     }
     if (pb.segs.size() > st.segs_cap) {
