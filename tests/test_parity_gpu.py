@@ -560,3 +560,57 @@ def test_chain_next_to_sweep_equals_serial(in_tmp):
             for x, y in zip(a[1] + a[2] + a[3], b[1] + b[2] + b[3]):
                 assert np.array_equal(x, y), k
     assert serial[-1][0] is not None
+
+
+def test_default_schedule_at_40mb_equals_serial(in_tmp):
+    """At >= 32 Mb the chain runs next to the sweep by default (and with 4 barcodes the sweep is
+    the split ingest-only + plain form).  Five updates on a 36 Mb + 6 Mb reference with deep
+    preloaded coverage must give bit-identical bin sums, benefits, thresholds and masks to the
+    serial schedule (BOSSX_NO_OVERLAP=1) — the hand-off is exercised while the sweep is really
+    busy, and the chain's L1 is warm from the previous update."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.runs import BossRuns
+    nb = 4
+    contigs = synth.make_reference([36_000_300, 6_000_100], seed=77, names=["big", "mid"])
+    strs = [(n, synth.codes_to_str(c)) for n, c in contigs]
+    batches = [synth.make_batch(contigs, 3000, seed=300 + b, mean_len=6000.0, nbarcodes=nb) for b in range(5)]
+
+    def run(name, env):
+        old = {k: os.environ.get(k) for k in ("BOSSX_NO_OVERLAP", "BOSSX_OVERLAP")}
+        for k in old:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        try:
+            args = BossConfig()
+            args.general.name = name
+            args.optional.bucket_threshold = 0
+            args.general.barcodes = ["barcode%02d" % (i + 1) for i in range(nb)]
+            r = BossRuns(args)
+            r.init(contigs=strs)
+            r.write_masks = False
+            r.engine.preload_coverage(6.0, seed=5)
+            out = []
+            for b in batches:
+                r.rl_dist.update(b["read_lengths"])
+                r.process_batch_paf(b["paf"], b["seqs"], barcodes=b["barcodes"])
+                out.append((r.threshold, r.last_stats.get("normaliser"),
+                            r.engine.export(0, "scores_ds"), r.engine.export(0, "benefit"),
+                            r.contigs["big"].strat.copy(), r.contigs["mid"].strat.copy()))
+            r.engine.close()
+            return out
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None)
+                if v is not None:
+                    os.environ[k] = v
+    serial = run("sched_serial", {"BOSSX_NO_OVERLAP": "1"})
+    default = run("sched_default", {})
+    assert serial[-1][0] is not None
+    for k, (a, b) in enumerate(zip(serial, default)):
+        assert a[0] == b[0] and a[1] == b[1], k
+        for x, y in zip(a[2:], b[2:]):
+            assert np.array_equal(x, y), k
+    # some, not all, positions accepted
+    frac = serial[-1][4].mean()
+    assert 0.0 < frac < 1.0
