@@ -94,6 +94,7 @@ PROTOTYPES = {
     "bossx_device_ptr": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "bossx_dist_hist": (C.c_int, [C.c_void_p, C.POINTER(FhatDesc)]),
     "bossx_dist_pick": (C.c_int, [C.c_void_p, C.c_double]),
+    "bossx_dist_tails": (C.c_int, [C.c_void_p]),
     "bossx_dist_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(UpdateResult)]),
     "bossx_arm": (C.c_int, [C.c_void_p]),
     "bossx_get_max": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),

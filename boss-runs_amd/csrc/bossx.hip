@@ -61,7 +61,8 @@ struct bossx_engine {
     Ctrl *d_ctrl = nullptr;
     uint8_t *d_contig_on = nullptr;
     long long *d_limbs = nullptr;       // multi-GPU: SUM-reducible statistics
-    double *d_tails = nullptr;          // multi-GPU: last n_filt rows of every block
+    double *d_tails = nullptr;          // multi-GPU: last n_filt rows of every block, + 1 slot for the normaliser
+    bool norm_in_tails = false;         // bossx_dist_tails ran: dist_hist takes the (reduced) normaliser from that slot
     // contig tables (device)
     int64_t *d_tile_off = nullptr, *d_site_off = nullptr, *d_length = nullptr, *d_bin_off = nullptr,
             *d_row_off = nullptr, *d_strat_off = nullptr, *d_bucket_off = nullptr;
@@ -416,7 +417,8 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
         h->result_bytes = bytes;
     }
     if ((rc = dev_alloc(h, &h->d_limbs, size_t(BOSSX_HIST_BINS + 1) * 5, true))) return rc;
-    if ((rc = dev_alloc(h, &h->d_tails, h->filt.size() * h->filt.size() * 2 * size_t(nb), true))) return rc;
+    // + one slot: the normaliser rides with the tails in one MAX all-reduce (bossx_dist_tails)
+    if ((rc = dev_alloc(h, &h->d_tails, h->filt.size() * h->filt.size() * 2 * size_t(nb) + 1, true))) return rc;
     if ((rc = dev_alloc(h, &h->d_lut_score, size_t(BOSSX_NCOMP) * 4, true))) return rc;
     if ((rc = dev_alloc(h, &h->d_lut_ent, size_t(BOSSX_NCOMP) * 4, true))) return rc;
     if ((rc = upload_vec(h, &h->d_tile_off, tile_off))) return rc;
@@ -993,10 +995,19 @@ int bossx_device_ptr(bossx_engine *h, int32_t which, void **ptr, size_t *bytes) 
         case BOSSX_PTR_ARMED: *ptr = &h->d_ctrl->any_on; *bytes = sizeof(int32_t); break;
         case BOSSX_PTR_NORMALISER: *ptr = &h->d_ctrl->max_bits; *bytes = sizeof(unsigned long long); break;
         case BOSSX_PTR_LIMBS: *ptr = h->d_limbs; *bytes = size_t(BOSSX_HIST_BINS + 1) * 5 * sizeof(long long); break;
-        case BOSSX_PTR_TAILS: *ptr = h->d_tails; *bytes = h->filt.size() * h->filt.size() * 2 * size_t(h->nb) * sizeof(double); break;
+        case BOSSX_PTR_TAILS: *ptr = h->d_tails; *bytes = (h->filt.size() * h->filt.size() * 2 * size_t(h->nb) + 1) * sizeof(double); break;
         default: return fail(h, BOSSX_E_INVALID, "unknown device pointer selector");
     }
     return BOSSX_OK;
+}
+
+static void launch_tails(bossx_engine *h) {
+    MaskParams P;
+    P.benefit = h->d_benefit; P.bucket_on = h->d_bucket_on; P.strat = h->d_strat; P.ct = table_of(h);
+    P.B = h->B; P.NBK = h->NBK; P.rows = h->rows; P.nb = h->nb; P.gate = 1; P.ctrl = h->d_ctrl;
+    P.tails = nullptr; P.tail_k = int32_t(h->filt.size());
+    P.do_pick = 0; P.pick = PickParams{};
+    hipLaunchKernelGGL(export_tails_kernel, dim3(64), dim3(256), 0, h->stream, P, h->d_tails);
 }
 
 int bossx_dist_hist(bossx_engine *h, const bossx_fhat_desc *fh) {
@@ -1004,6 +1015,10 @@ int bossx_dist_hist(bossx_engine *h, const bossx_fhat_desc *fh) {
     HIPCHK(hipSetDevice(h->cfg.device));
     int rc = upload_fhat(h, fh);
     if (rc) return rc;
+    if (h->norm_in_tails) {      // the all-reduced maximum comes back from the tails buffer's last slot
+        const size_t n_t = h->filt.size() * h->filt.size() * 2 * size_t(h->nb);
+        HIPCHK(hipMemcpyAsync(&h->d_ctrl->max_bits, h->d_tails + n_t, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    }
     if ((rc = launch_hist(h, fh, 1))) return rc;
     hipLaunchKernelGGL(stats_to_limbs_kernel, dim3((BOSSX_HIST_BINS + 1 + 255) / 256), dim3(256), 0, h->stream, h->d_stats,
                        h->d_stats + BOSSX_HIST_BINS, h->d_stats + BOSSX_HIST_BINS * 3, h->d_limbs, h->d_ctrl, 1);
@@ -1018,11 +1033,19 @@ int bossx_dist_pick(bossx_engine *h, double tc) {
     PP.counts = h->d_stats; PP.fgrid = h->d_stats + BOSSX_HIST_BINS; PP.ubar = h->d_stats + BOSSX_HIST_BINS * 3;
     PP.limbs = h->d_limbs; PP.ctrl = h->d_ctrl; PP.tc = tc; PP.gate = 1;
     hipLaunchKernelGGL(threshold_pick_kernel, dim3(1), dim3(64), 0, h->stream, PP);
-    MaskParams P;
-    P.benefit = h->d_benefit; P.bucket_on = h->d_bucket_on; P.strat = h->d_strat; P.ct = table_of(h);
-    P.B = h->B; P.NBK = h->NBK; P.rows = h->rows; P.nb = h->nb; P.gate = 1; P.ctrl = h->d_ctrl;
-    P.tails = nullptr; P.tail_k = int32_t(h->filt.size());
-    hipLaunchKernelGGL(export_tails_kernel, dim3(64), dim3(256), 0, h->stream, P, h->d_tails);
+    if (!h->norm_in_tails) launch_tails(h);     // otherwise published (and reduced) together with the normaliser
+    h->norm_in_tails = false;
+    HIPCHK(hipGetLastError());
+    return BOSSX_OK;
+}
+
+int bossx_dist_tails(bossx_engine *h) {
+    if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "bad dist_tails call");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    launch_tails(h);
+    const size_t n_t = h->filt.size() * h->filt.size() * 2 * size_t(h->nb);
+    HIPCHK(hipMemcpyAsync(h->d_tails + n_t, &h->d_ctrl->max_bits, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    h->norm_in_tails = true;
     HIPCHK(hipGetLastError());
     return BOSSX_OK;
 }

@@ -252,6 +252,11 @@ class Engine:
         self._keep = f                       # the upload is asynchronous
         self._ck(self.lib.bossx_dist_hist(self.h, C.byref(desc)))
 
+    def dist_tails(self):
+        """Publish the block tails and put the normaliser into the tails buffer's last slot: one
+        MAX all-reduce over that buffer then replaces the normaliser and tails exchanges."""
+        self._ck(self.lib.bossx_dist_tails(self.h))
+
     def dist_pick(self, tc):
         self._ck(self.lib.bossx_dist_pick(self.h, float(tc)))
 

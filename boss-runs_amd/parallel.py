@@ -178,7 +178,7 @@ class DistributedBossRuns(BossRuns):
             self.t_armed = wrap(0, (1,), "<i4")
             self.t_norm = wrap(1, (1,), "<i8")            # bit pattern of a non-negative double
             self.t_limbs = wrap(2, ((_lib.HIST_BINS + 1) * 5,), "<i8")
-            self.t_tails = wrap(3, (nfilt * nfilt * 2 * nb,), "<f8")
+            self.t_tails = wrap(3, (nfilt * nfilt * 2 * nb + 1,), "<f8")     # + the normaliser slot
         self.local_filt = {n: c for n, c in self.contigs_filt.items() if not c.remote}
         self.armed = False
         self._begun = False
@@ -259,7 +259,8 @@ class DistributedBossRuns(BossRuns):
         self._chain_early = True
 
     def _update_instream(self) -> None:
-        """The update with device-resident statistics: four in-stream RCCL all-reduces between
+        """The update with device-resident statistics: two in-stream RCCL all-reduces (three until
+        some strategy is on) between
         asynchronous engine stages, one synchronisation at the end (bossx.h, bossx_device_ptr)."""
         eng, dist, torch = self.engine, self.comm.dist, self.comm.torch
         MAXOP, SUMOP = dist.ReduceOp.MAX, dist.ReduceOp.SUM
@@ -276,13 +277,13 @@ class DistributedBossRuns(BossRuns):
                 if not early:
                     windows = np.concatenate(([400 // 100], self.rl_dist.approx_ccl // 100)).astype(np.int32)
                     eng.update_benefit(windows, MULT)            # gated on the (now global) flag
-                dist.all_reduce(self.t_norm, op=MAXOP)
+                eng.dist_tails()                                 # halo rows + normaliser in one buffer
+                dist.all_reduce(self.t_tails, op=MAXOP)          # non-negative, one contributor each: exact
                 fhat_c, target_rs = self.read_starts.fhat_compact()
                 eng.dist_hist(fhat_c, target_rs, self.ref.n_sites // 100)
                 dist.all_reduce(self.t_limbs, op=SUMOP)
                 eng.dist_pick(self.rl_dist.time_cost // 100)
-                dist.all_reduce(self.t_tails, op=SUMOP)
-                self.comm.n_collectives += 3
+                self.comm.n_collectives += 2
         res = eng.dist_finish()
         for cont in self.local_filt.values():
             if res["contig_on"][cont.index]:

@@ -251,9 +251,14 @@ int bossx_update_benefit(bossx_engine *h, const int32_t *windows, const double *
  *     bossx_dist_hist                         histogram with the global normaliser -> LIMBS
  *     all-reduce SUM  LIMBS                   (int64[(BOSSX_HIST_BINS + 1) * 5], exact)
  *     bossx_dist_pick                         global threshold; publishes the block TAILS
- *     all-reduce SUM  TAILS                   (float64[n_filt * n_filt * 2 * nb], one non-zero
+ *     all-reduce SUM  TAILS                   (float64[n_filt * n_filt * 2 * nb + 1], one non-zero
  *                                              contributor per element: exact)
- *     bossx_dist_finish                       masks (halo rows from the tails), D2H, sync     */
+ *     bossx_dist_finish                       masks (halo rows from the tails), D2H, sync
+ * Shorter form (one collective fewer): after the chain, bossx_dist_tails publishes the TAILS
+ * (they do not depend on the threshold) and puts the normaliser into the TAILS buffer's extra last
+ * slot; ONE all-reduce MAX over that float64 buffer (every element is non-negative and has one
+ * non-zero contributor, so MAX is as exact as SUM) replaces the NORMALISER and TAILS exchanges;
+ * bossx_dist_hist then takes the normaliser from the slot and bossx_dist_pick only picks.      */
 #define BOSSX_PTR_ARMED      0
 #define BOSSX_PTR_NORMALISER 1
 #define BOSSX_PTR_LIMBS      2
@@ -261,6 +266,7 @@ int bossx_update_benefit(bossx_engine *h, const int32_t *windows, const double *
 int bossx_device_ptr(bossx_engine *h, int32_t which, void **ptr, size_t *bytes);
 int bossx_dist_hist(bossx_engine *h, const bossx_fhat_desc *fh);
 int bossx_dist_pick(bossx_engine *h, double tc);
+int bossx_dist_tails(bossx_engine *h);
 int bossx_dist_finish(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, bossx_update_result *res);
 int bossx_arm(bossx_engine *h);
 int bossx_get_max(bossx_engine *h, double *max_benefit);

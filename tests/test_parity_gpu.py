@@ -394,18 +394,25 @@ def test_two_rank_device_protocol_emulated_on_one_gpu(in_tmp):
             d.begin_update()
             d.account_batch(summ, batch["read_lengths"], len(batch["seqs"]))
             d._begun = False
+            d.early_chain = False
         reduce_pair("t_armed", "max")
         windows = np.concatenate(([4], ranks[0].rl_dist.approx_ccl // 100)).astype(np.int32)
         for d in ranks:
             d.engine.update_benefit(windows, MULT)
-        reduce_pair("t_norm", "max")
+        if b % 2 == 0:                       # short form: tails + normaliser in one MAX exchange
+            for d in ranks:
+                d.engine.dist_tails()
+            reduce_pair("t_tails", "max")
+        else:                                # long form: separate normaliser and tails exchanges
+            reduce_pair("t_norm", "max")
         for d in ranks:
             fh, trs = d.read_starts.fhat_compact()
             d.engine.dist_hist(fh, trs, d.ref.n_sites // 100)
         reduce_pair("t_limbs", "sum")
         for d in ranks:
             d.engine.dist_pick(d.rl_dist.time_cost // 100)
-        reduce_pair("t_tails", "sum")
+        if b % 2 == 1:
+            reduce_pair("t_tails", "sum")
         res = [d.engine.dist_finish() for d in ranks]
         if f.threshold is None:
             assert not res[0]["any_on"] and not res[1]["any_on"]
