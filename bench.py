@@ -265,7 +265,11 @@ def main():
             # matrix-op latency, not HBM — 52 cycles per 4 bins measured (scripts/mfma_f64_probe.hip)
             "chain_latency": {"kernel": "benefit_chain", "bound": "dependent-op latency",
                               "bins": int(eng.merged_bins), "ns_per_bin": 1e6 * kern["benefit_chain"]["avg_ms"] / max(int(eng.merged_bins), 1),
-                              "floor_cycles_per_bin": 13.0, "on_fp64_matrix_core": eng.matrix_chain},
+                              "floor_cycles_per_bin": 13.0, "on_fp64_matrix_core": eng.matrix_chain,
+                              "runs_next_to_sweep": not os.environ.get("BOSSX_NO_OVERLAP"),
+                              "note": "the kernel starts while the sweep of the same update is still running and "
+                                      "waits for tiles it has not published yet: its duration includes those "
+                                      "waits (0.316 ms = 6.8 ns/bin when it runs after the sweep)"},
             "host": {"stage_batch_ms_mean": 1e3 * float(np.mean(t_parse))},
             "move_sum_on_fp64_matrix_core": eng.matrix_chain,
         }

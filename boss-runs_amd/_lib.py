@@ -69,6 +69,9 @@ PROTOTYPES = {
                                          C.POINTER(C.c_int64)]),
     "bossx_paf_summary": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int32,
                                     C.c_int32, C.POINTER(BatchSummary), C.POINTER(C.c_int32)]),
+    "bossx_rl_update": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
+                                  C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                  C.c_void_p, C.POINTER(C.c_int32)]),
     "bossx_py_str_pointers": (C.c_int, [C.py_object, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bossx_host_parse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                    C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -398,10 +398,11 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
     if ((rc = dev_alloc(h, &h->d_strat, size_t(h->strat_bytes)))) return rc;
     HIPCHK(hipMemsetAsync(h->d_strat, 1, size_t(h->strat_bytes), h->stream));       // reference.py:118
     if ((rc = dev_alloc(h, &h->d_tile_done, size_t(h->n_tiles > 0 ? h->n_tiles : 1), true))) return rc;
-    // The chain of an update runs next to that update's sweep where the sweep is long enough to be
-    // worth hiding (measured: +2-3 % at 110-390 Mb, -3 % at 4.6 Mb where the host's own work
-    // already covers the sweep).  BOSSX_OVERLAP=1 / BOSSX_NO_OVERLAP=1 force it either way.
-    h->overlap_ok = getenv("BOSSX_NO_OVERLAP") ? false : (getenv("BOSSX_OVERLAP") ? true : h->Gp >= (int64_t(32) << 20));
+    // The chain of an update runs next to that update's sweep (measured: -5 % per update at 4.6 Mb
+    // now that the host's read-length step no longer covers the sweep, -2-3 % at 110-390 Mb where
+    // the chain is 5-10x longer than the sweep, -30 % at 50 Mb x 8 barcodes).
+    // BOSSX_NO_OVERLAP=1 keeps them back to back.
+    h->overlap_ok = getenv("BOSSX_NO_OVERLAP") == nullptr;
     if ((rc = dev_alloc(h, &h->d_bucket_on, size_t(nb * h->NBK), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_bucket_sums, size_t(nb * h->NBK), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_drop_count, size_t(h->n_tiles), true))) return rc;

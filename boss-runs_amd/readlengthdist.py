@@ -5,9 +5,25 @@ Same interface and results as /root/reference/boss/readlengthdist.py:8-97
 `longest_read`, `time_cost`), vectorised: the per-read Python loop becomes one bincount and the
 10-step `while` scan becomes searchsorted on the (monotone) complementary CDF.
 """
+import ctypes as C
 import logging
 
 import numpy as np
+
+
+def _native():
+    """libbossx.so if it is built (host-only entry point: no GPU needed), else None."""
+    global _LIB
+    if _LIB is False:
+        try:
+            from . import _lib
+            _LIB = _lib.load()
+        except Exception:
+            _LIB = None
+    return _LIB
+
+
+_LIB = False
 
 
 class ReadlengthDist:
@@ -23,11 +39,37 @@ class ReadlengthDist:
         self.approx_ccl = self.ccl_approx_constant()
 
     def update(self, read_lengths):
-        """`read_lengths`: {read id: length} (as the reference) or an integer array."""
+        """`read_lengths`: {read id: length} (as the reference) or an integer array.  Runs in the
+        native library (bossx_rl_update) when it is built — this step sits on the critical path
+        of an update — and in numpy otherwise; both give bit-identical results."""
         if isinstance(read_lengths, dict):
             lens = np.fromiter(read_lengths.values(), dtype=np.int64, count=len(read_lengths))
         else:
-            lens = np.asarray(read_lengths, dtype=np.int64)
+            lens = np.ascontiguousarray(read_lengths, dtype=np.int64)
+        lib = _native()
+        if lib is None:
+            return self._update_numpy(lens)
+        hi = C.c_int64(getattr(self, "_hi", 0))
+        lam, longest, observed = C.c_double(0.0), C.c_int64(0), C.c_int32(0)
+        approx = np.empty(self.eta - 1, dtype=np.int32)
+        rc = lib.bossx_rl_update(self.read_lengths.ctypes.data, self.read_lengths.size, lens.ctypes.data, lens.size,
+                                 int(self.mu * 2), int(self.eta), C.byref(hi), C.byref(lam), C.byref(longest),
+                                 approx.ctypes.data, C.byref(observed))
+        if rc:
+            raise ValueError("bossx_rl_update failed (%d)" % rc)
+        self._hi = hi.value
+        if not observed.value:
+            logging.info('Attempted update of read lengths before observing any reads')
+            return
+        self.longest_read = np.int64(longest.value)
+        self.lam = np.float64(lam.value)
+        self._counts = None                           # built from the histogram when L / ccl are asked for
+        self._L = self._ccl = None
+        self.approx_ccl = approx
+        logging.info('rld: %s', self.approx_ccl)
+        self.time_cost = self.lam - 400 - 300
+
+    def _update_numpy(self, lens):
         lens = lens[lens > self.mu * 2]
         if lens.size:
             lens = np.minimum(lens, int(1e6) - 1)
@@ -59,6 +101,8 @@ class ReadlengthDist:
     @property
     def L(self):
         if self._L is None:
+            if self._counts is None:
+                self._counts = self.read_lengths[:int(self.longest_read) + 1].astype(np.int64)
             dens = self._counts.astype('float64')
             dens /= float(self._counts.sum())   # = the reference's sum(L): integer-valued, exact
             self._L = dens

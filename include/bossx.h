@@ -121,6 +121,18 @@ int bossx_ingest_staged(bossx_engine *h);
 int bossx_paf_summary(bossx_engine *h, const char *paf, size_t paf_len,
                       const char *const *name_ptrs, const int64_t *name_lens, int32_t n_reads,
                       int32_t min_len, bossx_batch_summary *summary, int32_t *n_rec);
+/* ReadlengthDist.update + ccl_approx_constant (readlengthdist.py:36-97) on the host, natively: adds
+ * the `n_lens` new read lengths (> min_len_exclusive, clipped to hist_len - 1) to the uint16
+ * histogram `hist` (the caller's array of hist_len counters; wraps like the reference's), then
+ * returns lam (mean length), the longest observed length and the eta - 1 indices where the
+ * complementary cumulative length distribution falls to 0.95, 0.85, ... (approx_ccl), all
+ * bit-identical to the reference's numpy arithmetic.  `hi_inout` carries the largest index ever
+ * incremented between calls.  `observed` = 0 if the histogram is still empty (nothing else is
+ * written then).  No device, no engine: this is the host step the move_sum windows wait for.   */
+int bossx_rl_update(uint16_t *hist, int64_t hist_len, const int64_t *lens, int64_t n_lens,
+                    int64_t min_len_exclusive, int32_t eta, int64_t *hi_inout,
+                    double *lam, int64_t *longest_read, int32_t *approx_ccl, int32_t *observed);
+
 /* CPython binding helper: pointer + length of the UTF-8 buffer of each str in the Python list
  * `list` (a PyObject*), obtained through the addresses of the interpreter's PyList_GetItem and
  * PyUnicode_AsUTF8AndSize; lets the ctypes layer hand a dict of reads to

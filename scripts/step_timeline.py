@@ -17,7 +17,9 @@ for b in bs:
 def make(name, overlap):
     if overlap:
         os.environ.pop("BOSSX_NO_OVERLAP", None)
+        os.environ["BOSSX_OVERLAP"] = "1"
     else:
+        os.environ.pop("BOSSX_OVERLAP", None)
         os.environ["BOSSX_NO_OVERLAP"] = "1"
     a = BossConfig(); a.optional.bucket_threshold = 0; a.general.name = name
     r = BossRuns(a); r.log_fractions = False

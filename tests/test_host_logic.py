@@ -284,13 +284,16 @@ def test_readlength_fast_path_equals_float_scan():
     for _ in range(40):
         n = int(rng.integers(1, 5000))
         cases.append(np.clip(rng.gamma(2, rng.uniform(500, 6000), n), 1, 2_000_000).astype(np.int64))
-    p, o = ReadlengthDist(), OReadlengthDist()
+    p, o, q = ReadlengthDist(), OReadlengthDist(), ReadlengthDist()
     for lens in cases:
-        p.update(lens)
+        p.update(lens)                                   # native (bossx_rl_update) when the library is built
+        q._update_numpy(np.asarray(lens, dtype=np.int64))   # the numpy form of the same step
         o.update({"r%d" % i: int(v) for i, v in enumerate(lens)})
         assert np.array_equal(p.approx_ccl, o.approx_ccl)
+        assert np.array_equal(q.approx_ccl, o.approx_ccl)
         assert np.array_equal(p.approx_ccl, p.ccl_approx_constant())
         if hasattr(o, "time_cost"):
+            assert q.lam == o.lam and q.time_cost == o.time_cost and q.longest_read == o.longest_read
             assert p.lam == o.lam and p.time_cost == o.time_cost and p.longest_read == o.longest_read
             assert np.array_equal(p.L, o.L) and np.array_equal(p.ccl, o.ccl)
     # fresh objects on single batches (the first update matters: few reads, coarse steps)
