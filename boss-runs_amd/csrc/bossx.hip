@@ -30,6 +30,7 @@ struct bossx_engine {
     bool overlap_ok = false;           // decided at finalize (BOSSX_OVERLAP / BOSSX_NO_OVERLAP / size); cleared after a chain time-out
     bool host_armed = false;           // the host has seen ctrl.any_on set
     bool max_bits_clear = false;       // the sweep's prep launch zeroed ctrl.max_bits and no chain has run since
+    bool chain_lds_big = false;        // the live chain kernels were allowed 94 KB of dynamic LDS
     bool sweep_published = false;      // the last sweep launch publishes its tiles (tile_done flags, agent-scope bin stores)
     bool sweep_in_flight = false;      // update_begin enqueued a sweep that no update has consumed yet
     bool chain_on_stream2 = false;     // update_benefit put the chain on stream2 (ev_chain pending)
@@ -843,6 +844,19 @@ void launch_chain(bossx_engine *h, const ChainParams &P, size_t lds, hipStream_t
     time_begin(h, BOSSX_K_BENEFIT, stream);
     const dim3 grid(uint32_t(h->filt.size() * size_t(h->nb) * 2)), block(kChainThreads);
     const bool live = P.tile_done != nullptr;
+    if (live && grid.x <= 8 && lds < size_t(94) * 1024) {
+        // A few long chains next to a running sweep: ask for enough LDS that no sweep block fits on
+        // the chain's CU (65 KB static + 94 KB dynamic leave less than the smallest sweep block needs), otherwise the
+        // sweep's waves share the chain wave's SIMD and slow the recurrence by ~6 % while they run.
+        lds = size_t(94) * 1024;
+        if (!h->chain_lds_big) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_kernel<true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+            hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_kernel<false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+            h->chain_lds_big = true;
+        }
+    }
     if (h->matrix_chain) {
         if (live) hipLaunchKernelGGL((benefit_chain_kernel<true, true>), grid, block, lds, stream, P);
         else hipLaunchKernelGGL((benefit_chain_kernel<true, false>), grid, block, lds, stream, P);
