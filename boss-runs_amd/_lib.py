@@ -99,6 +99,7 @@ PROTOTYPES = {
     "bossx_dist_pick": (C.c_int, [C.c_void_p, C.c_double]),
     "bossx_dist_tails": (C.c_int, [C.c_void_p]),
     "bossx_dist_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(UpdateResult)]),
+    "bossx_set_overlap": (C.c_int, [C.c_void_p, C.c_int32]),
     "bossx_arm": (C.c_int, [C.c_void_p]),
     "bossx_get_max": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "bossx_update": (C.c_int, [C.c_void_p, C.POINTER(UpdateParams), C.c_void_p, C.c_void_p,

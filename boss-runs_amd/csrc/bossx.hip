@@ -153,6 +153,16 @@ ContigTable table_of(const bossx_engine *h) {
     return t;
 }
 
+// A chain that bossx_update_benefit put on the second stream must be ordered before anything on
+// the main stream that reads its results (benefit, running maximum).
+int join_chain(bossx_engine *h) {
+    if (h->chain_on_stream2) {
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_chain, 0));
+        h->chain_on_stream2 = false;
+    }
+    return BOSSX_OK;
+}
+
 void time_begin(bossx_engine *h, int k, hipStream_t stream = nullptr) {
     if (!h->timing) return;
     if (h->ev_pending[k]) {      // collect the previous launch before re-recording
@@ -764,6 +774,7 @@ int bossx_sweep(bossx_engine *h) {
     if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "sweep before finalize");
     if (!h->lut_set) return fail(h, BOSSX_E_INVALID, "sweep before set_lut");
     HIPCHK(hipSetDevice(h->cfg.device));
+    { int jrc = join_chain(h); if (jrc) return jrc; }
     return launch_sweep(h);
 }
 
@@ -873,6 +884,7 @@ void launch_chain(bossx_engine *h, const ChainParams &P, size_t lds, hipStream_t
 int bossx_benefit(bossx_engine *h, const int32_t *windows, const double *mult, double *max_benefit) {
     if (!h || !h->finalized || !windows || !mult) return fail(h, BOSSX_E_INVALID, "bad benefit call");
     HIPCHK(hipSetDevice(h->cfg.device));
+    { int jrc = join_chain(h); if (jrc) return jrc; }
     ChainParams P;
     size_t lds = 0;
     int rc = fill_chain_params(h, windows, mult, P, lds);
@@ -960,6 +972,7 @@ int bossx_histogram(bossx_engine *h, double normaliser, const bossx_fhat_desc *f
     if (!h || !h->finalized || !fh || !fh->fhat_c || !counts || !fgrid_fx || !ubar0_fx) return fail(h, BOSSX_E_INVALID, "bad histogram call");
     if (!(normaliser > 0)) return fail(h, BOSSX_E_EMPTY, "no non-zero benefit (np.max of an empty array)");
     HIPCHK(hipSetDevice(h->cfg.device));
+    { int jrc = join_chain(h); if (jrc) return jrc; }
     int rc = upload_fhat(h, fh);
     if (rc) return rc;
     unsigned long long bits;
@@ -978,6 +991,7 @@ int bossx_histogram(bossx_engine *h, double normaliser, const bossx_fhat_desc *f
 int bossx_apply_threshold(bossx_engine *h, double threshold) {
     if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "bad apply_threshold call");
     HIPCHK(hipSetDevice(h->cfg.device));
+    { int jrc = join_chain(h); if (jrc) return jrc; }
     HIPCHK(hipMemcpyAsync(&h->d_ctrl->threshold, &threshold, sizeof(double), hipMemcpyHostToDevice, h->stream));
     return launch_mask(h, 0);
 }
@@ -996,6 +1010,7 @@ int bossx_update_begin(bossx_engine *h, double bucket_threshold) {
     if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "bad update_begin call");
     if (!h->lut_set) return fail(h, BOSSX_E_INVALID, "update before set_lut");
     HIPCHK(hipSetDevice(h->cfg.device));
+    { int jrc = join_chain(h); if (jrc) return jrc; }
     int rc = launch_sweep(h);      // records ev_begin between its prep launch and the sweep proper
     if (rc) return rc;
     launch_buckets(h, bucket_threshold);
@@ -1028,6 +1043,7 @@ static void launch_tails(bossx_engine *h) {
 int bossx_dist_hist(bossx_engine *h, const bossx_fhat_desc *fh) {
     if (!h || !h->finalized || !fh || !fh->fhat_c) return fail(h, BOSSX_E_INVALID, "bad dist_hist call");
     HIPCHK(hipSetDevice(h->cfg.device));
+    { int jrc = join_chain(h); if (jrc) return jrc; }
     int rc = upload_fhat(h, fh);
     if (rc) return rc;
     if (h->norm_in_tails) {      // the all-reduced maximum comes back from the tails buffer's last slot
@@ -1044,6 +1060,7 @@ int bossx_dist_hist(bossx_engine *h, const bossx_fhat_desc *fh) {
 int bossx_dist_pick(bossx_engine *h, double tc) {
     if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "bad dist_pick call");
     HIPCHK(hipSetDevice(h->cfg.device));
+    { int jrc = join_chain(h); if (jrc) return jrc; }
     PickParams PP;
     PP.counts = h->d_stats; PP.fgrid = h->d_stats + BOSSX_HIST_BINS; PP.ubar = h->d_stats + BOSSX_HIST_BINS * 3;
     PP.limbs = h->d_limbs; PP.ctrl = h->d_ctrl; PP.tc = tc; PP.gate = 1;
@@ -1057,6 +1074,7 @@ int bossx_dist_pick(bossx_engine *h, double tc) {
 int bossx_dist_tails(bossx_engine *h) {
     if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "bad dist_tails call");
     HIPCHK(hipSetDevice(h->cfg.device));
+    { int jrc = join_chain(h); if (jrc) return jrc; }
     launch_tails(h);
     const size_t n_t = h->filt.size() * h->filt.size() * 2 * size_t(h->nb);
     HIPCHK(hipMemcpyAsync(h->d_tails + n_t, &h->d_ctrl->max_bits, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -1088,6 +1106,8 @@ static int copy_masks(bossx_engine *h, uint8_t *dst, bool bits) {
 int bossx_dist_finish(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, bossx_update_result *res) {
     if (!h || !h->finalized || !res) return fail(h, BOSSX_E_INVALID, "bad dist_finish call");
     HIPCHK(hipSetDevice(h->cfg.device));
+    { int jrc = join_chain(h); if (jrc) return jrc; }
+    h->sweep_in_flight = false;
     int rc = launch_mask(h, 1, true);
     if (rc) return rc;
     const size_t need = h->result_bytes;
@@ -1118,6 +1138,12 @@ int bossx_dist_finish(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, b
     return BOSSX_OK;
 }
 
+int bossx_set_overlap(bossx_engine *h, int32_t on) {
+    if (!h) return BOSSX_E_INVALID;
+    h->overlap_ok = on != 0 && getenv("BOSSX_NO_OVERLAP") == nullptr;
+    return BOSSX_OK;
+}
+
 int bossx_arm(bossx_engine *h) {
     if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "bad arm call");
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -1131,6 +1157,7 @@ int bossx_arm(bossx_engine *h) {
 int bossx_get_max(bossx_engine *h, double *max_benefit) {
     if (!h || !h->finalized || !max_benefit) return fail(h, BOSSX_E_INVALID, "bad get_max call");
     HIPCHK(hipSetDevice(h->cfg.device));
+    { int jrc = join_chain(h); if (jrc) return jrc; }
     unsigned long long bits = 0;
     HIPCHK(hipMemcpyAsync(&bits, &h->d_ctrl->max_bits, sizeof(bits), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1300,6 +1327,7 @@ int bossx_export(bossx_engine *h, int32_t contig, int32_t which, void *dst, size
     int rc = check_contig(h, contig, true);
     if (rc) return rc;
     HIPCHK(hipSetDevice(h->cfg.device));
+    { int jrc = join_chain(h); if (jrc) return jrc; }
     if (h->pending_slot >= 0 && (rc = flush_pending(h))) return rc;   // make staged increments visible
     const ContigInfo &c = h->contigs[size_t(contig)];
     const int64_t L = c.length, nb = h->nb, nbin = c.T + 1;

@@ -272,6 +272,10 @@ class Engine:
                     normaliser=res.normaliser, ubar0=res.ubar0, strat_size=res.strat_size,
                     n_bins=res.n_bins, contig_on=on.astype(bool))
 
+    def set_overlap(self, on):
+        """Allow / forbid the chain of update_benefit to run next to the sweep of update_begin."""
+        self._ck(self.lib.bossx_set_overlap(self.h, int(bool(on))))
+
     def arm(self):
         self._ck(self.lib.bossx_arm(self.h))
 

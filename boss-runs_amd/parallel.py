@@ -179,6 +179,10 @@ class DistributedBossRuns(BossRuns):
             self.t_norm = wrap(1, (1,), "<i8")            # bit pattern of a non-negative double
             self.t_limbs = wrap(2, ((_lib.HIST_BINS + 1) * 5,), "<i8")
             self.t_tails = wrap(3, (nfilt * nfilt * 2 * nb + 1,), "<f8")     # + the normaliser slot
+        if hasattr(self.engine, "set_overlap"):
+            # the protocol consumes the chain through the stage-wise entry points, which have no
+            # time-out fallback for a chain running next to the sweep: keep it after the sweep
+            self.engine.set_overlap(False)
         self.local_filt = {n: c for n, c in self.contigs_filt.items() if not c.remote}
         self.armed = False
         self._begun = False

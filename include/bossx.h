@@ -280,6 +280,10 @@ int bossx_dist_hist(bossx_engine *h, const bossx_fhat_desc *fh);
 int bossx_dist_pick(bossx_engine *h, double tc);
 int bossx_dist_tails(bossx_engine *h);
 int bossx_dist_finish(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, bossx_update_result *res);
+/* The concurrent chain (bossx_update_benefit next to the sweep of bossx_update_begin) falls back to
+ * the serial schedule inside bossx_update if it times out; callers that consume the chain through
+ * the stage-wise / multi-GPU entry points instead switch it off.                               */
+int bossx_set_overlap(bossx_engine *h, int32_t on);
 int bossx_arm(bossx_engine *h);
 int bossx_get_max(bossx_engine *h, double *max_benefit);
 int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all,
