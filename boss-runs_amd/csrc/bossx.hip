@@ -26,6 +26,7 @@ struct bossx_engine {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_begin = nullptr, ev_chain = nullptr;
     uint32_t *d_tile_done = nullptr;   // [n_tiles] sweep -> chain hand-off flags (epoch stamped)
+    uint32_t *d_tile_order = nullptr;  // [n_tiles] block -> tile for publishing launches: every contig's two ends first
     uint32_t epoch = 0;
     bool overlap_ok = false;           // decided at finalize (BOSSX_OVERLAP / BOSSX_NO_OVERLAP / size); cleared after a chain time-out
     bool host_armed = false;           // the host has seen ctrl.any_on set
@@ -208,7 +209,8 @@ SweepParams sweep_params(bossx_engine *h) {
     P.score0 = h->score0; P.tiny = std::numeric_limits<double>::min();
     P.tile_done = h->d_tile_done; P.epoch = h->epoch;
     P.publish = h->sweep_published ? 1 : 0;
-    P.dense = 0; P.ingest_only = 0;
+    P.dense = 0; P.ingest_only = 0; P.ingest_first = 0;
+    P.order = h->d_tile_order;
     return P;
 }
 
@@ -299,6 +301,7 @@ void bossx_destroy(bossx_engine *h) {
     if (h->ev_begin) hipEventDestroy(h->ev_begin);
     if (h->ev_chain) hipEventDestroy(h->ev_chain);
     if (h->d_tile_done) hipFree(h->d_tile_done);
+    if (h->d_tile_order) hipFree(h->d_tile_order);
     void *ptrs[] = {h->d_cov, h->d_meta, h->d_touched, h->d_strat, h->d_bucket_on, h->d_entropy, h->d_ds,
                     h->d_benefit, h->d_lut_score, h->d_lut_ent, h->d_fhat, h->d_bucket_sums, h->d_drop_count,
                     h->d_stats, h->d_result, h->d_tile_off, h->d_site_off, h->d_length, h->d_bin_off, h->d_row_off,
@@ -409,6 +412,24 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
     if ((rc = dev_alloc(h, &h->d_strat, size_t(h->strat_bytes)))) return rc;
     HIPCHK(hipMemsetAsync(h->d_strat, 1, size_t(h->strat_bytes), h->stream));       // reference.py:118
     if ((rc = dev_alloc(h, &h->d_tile_done, size_t(h->n_tiles > 0 ? h->n_tiles : 1), true))) return rc;
+    {
+        // Sweep order for launches that a chain runs next to: the k-th tile from the start and the
+        // k-th tile from the end of EVERY contig come before any (k+1)-th one — each contig has a
+        // forward and a reverse strand walk waiting for exactly those tiles.
+        std::vector<std::pair<int64_t, uint32_t>> key;
+        key.reserve(size_t(h->n_tiles));
+        for (int32_t fi : h->filt) {
+            const ContigInfo &c = h->contigs[size_t(fi)];
+            for (int64_t t = 0; t < c.n_tiles; ++t)
+                key.emplace_back(std::min(t, c.n_tiles - 1 - t), uint32_t(c.tile_off + t));
+        }
+        std::sort(key.begin(), key.end());
+        std::vector<uint32_t> order(key.size());
+        for (size_t i = 0; i < key.size(); ++i) order[i] = key[i].second;
+        if ((rc = dev_alloc(h, &h->d_tile_order, order.size() ? order.size() : 1))) return rc;
+        if (!order.empty())
+            HIPCHK(hipMemcpy(h->d_tile_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     // The chain of an update runs next to that update's sweep (measured: -5 % per update at 4.6 Mb
     // now that the host's read-length step no longer covers the sweep, -2-3 % at 110-390 Mb where
     // the chain is 5-10x longer than the sweep, -30 % at 50 Mb x 8 barcodes).
@@ -737,6 +758,12 @@ int launch_sweep(bossx_engine *h) {
         // most tiles receive bases: one launch over all tiles, each block looks its tile up
         P.dense = 1;
         hipLaunchKernelGGL(site_sweep_kernel<true>, dim3(uint32_t(h->n_tiles)), dim3(256), 0, h->stream, P);
+    } else if (P.publish && n_groups) {
+        // a chain is waiting for tiles in walk order: the touched ones are scattered along it, so
+        // they go first (DONE marks keep the plain launch off them), then everything else in order
+        P.ingest_first = 1;
+        hipLaunchKernelGGL(site_sweep_kernel<true>, dim3(uint32_t(n_groups)), dim3(256), 0, h->stream, P);
+        hipLaunchKernelGGL(site_sweep_kernel<false>, dim3(uint32_t(h->n_tiles)), dim3(256), 0, h->stream, P);
     } else {
         if (h->n_tiles > 0)
             hipLaunchKernelGGL(site_sweep_kernel<false>, dim3(uint32_t(h->n_tiles)), dim3(256), 0, h->stream, P);
