@@ -99,6 +99,8 @@ PROTOTYPES = {
     "bossx_dist_pick": (C.c_int, [C.c_void_p, C.c_double]),
     "bossx_dist_tails": (C.c_int, [C.c_void_p]),
     "bossx_dist_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(UpdateResult)]),
+    "bossx_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "bossx_host_free": (C.c_int, [C.c_void_p]),
     "bossx_set_overlap": (C.c_int, [C.c_void_p, C.c_int32]),
     "bossx_arm": (C.c_int, [C.c_void_p]),
     "bossx_get_max": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),

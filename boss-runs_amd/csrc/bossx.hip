@@ -1165,6 +1165,17 @@ int bossx_dist_finish(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, b
     return BOSSX_OK;
 }
 
+int bossx_host_alloc(bossx_engine *h, size_t bytes, void **ptr) {
+    if (!h || !ptr) return fail(h, BOSSX_E_INVALID, "bad host_alloc call");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return BOSSX_OK;
+}
+
+int bossx_host_free(void *ptr) {
+    return (!ptr || hipHostFree(ptr) == hipSuccess) ? BOSSX_OK : BOSSX_E_HIP;
+}
+
 int bossx_set_overlap(bossx_engine *h, int32_t on) {
     if (!h) return BOSSX_E_INVALID;
     h->overlap_ok = on != 0 && getenv("BOSSX_NO_OVERLAP") == nullptr;

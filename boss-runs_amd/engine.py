@@ -9,6 +9,21 @@ EXPORT = dict(coverage=0, scores=1, entropy=2, scores_ds=3, benefit=4, state=5, 
               bucket_switches=7, benefit_tail=8)
 
 
+class _PinnedBlock:
+    """Owner of one hipHostMalloc block, exposed to numpy through the array interface: arrays and
+    views made from it keep it alive, and the block frees itself with the last of them."""
+
+    def __init__(self, lib, ptr, nbytes):
+        self._lib, self._ptr = lib, ptr
+        self.__array_interface__ = {"data": (ptr, False), "shape": (nbytes,), "typestr": "|u1", "version": 3}
+
+    def __del__(self):
+        try:
+            self._lib.bossx_host_free(self._ptr)
+        except Exception:
+            pass
+
+
 class Engine:
     def __init__(self, nbarcodes=1, device=0, track_entropy=True, stream=None):
         self.lib = _lib.load()
@@ -26,6 +41,19 @@ class Engine:
         self.lengths = []
         self.rejected = []
         self.remote = []
+
+    def _host_buffer(self, nbytes, fill):
+        """uint8 array over page-locked host memory (direct DMA target of the mask copies).  The
+        memory belongs to the array: it is released when the last view of it is gone, which may be
+        after the engine."""
+        try:
+            ptr = C.c_void_p()
+            self._ck(self.lib.bossx_host_alloc(self.h, int(nbytes), C.byref(ptr)))
+            arr = np.asarray(_PinnedBlock(self.lib, ptr.value, int(nbytes)))
+        except Exception:          # pinning is an optimisation only
+            arr = np.empty(int(nbytes), dtype=np.uint8)
+        arr[:] = fill
+        return arr
 
     def close(self):
         if getattr(self, "h", None):
@@ -262,7 +290,7 @@ class Engine:
 
     def dist_finish(self):
         if getattr(self, "strat_all", None) is None:
-            self.strat_all = np.ones(max(int(self.lib.bossx_strat_bytes(self.h)), 1), dtype=np.uint8)
+            self.strat_all = self._host_buffer(max(int(self.lib.bossx_strat_bytes(self.h)), 1), 1)
         on = np.zeros(len(self.names), dtype=np.uint8)
         res = _lib.UpdateResult()
         self._ck(self.lib.bossx_dist_finish(self.h, self.strat_all.ctypes.data, on.ctypes.data, C.byref(res)))
@@ -316,11 +344,11 @@ class Engine:
         if bits:
             up.flags |= 4
             if getattr(self, "strat_bits", None) is None:
-                self.strat_bits = np.full(max(int(self.lib.bossx_strat_bits_bytes(self.h)), 1), 0xFF, dtype=np.uint8)
+                self.strat_bits = self._host_buffer(max(int(self.lib.bossx_strat_bits_bytes(self.h)), 1), 0xFF)
             masks = self.strat_bits
         else:
             if getattr(self, "strat_all", None) is None:
-                self.strat_all = np.ones(max(int(self.lib.bossx_strat_bytes(self.h)), 1), dtype=np.uint8)
+                self.strat_all = self._host_buffer(max(int(self.lib.bossx_strat_bytes(self.h)), 1), 1)
             masks = self.strat_all
         on = np.zeros(len(self.names), dtype=np.uint8)
         res = _lib.UpdateResult()
