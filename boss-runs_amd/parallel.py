@@ -92,11 +92,32 @@ class Comm:
         arr = np.ascontiguousarray(arr)
         if self.world == 1 and not self.force:
             return arr[np.newaxis].copy()
-        t = self._t(arr)
-        out = self.torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        self.dist.all_gather(list(out.unbind(0)), t)     # views of one tensor: one copy back (gloo has no all_gather_into_tensor)
+        torch = self.torch
+        if self.device == "cpu":
+            t = torch.from_numpy(arr)
+            out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype)
+            self.dist.all_gather(list(out.unbind(0)), t)  # views of one tensor (gloo has no all_gather_into_tensor)
+            self.n_collectives += 1
+            return out.numpy()
+        # device path: page-locked staging on both sides, asynchronous copies, ONE synchronisation
+        key = (arr.shape, arr.dtype.str)
+        buf = getattr(self, "_stage", {}).get(key)
+        if buf is None:
+            tin = torch.from_numpy(arr.copy()).pin_memory()
+            tout = torch.empty((self.world,) + tuple(tin.shape), dtype=tin.dtype).pin_memory()
+            din = torch.empty_like(tin, device=self.device)
+            dout = torch.empty((self.world,) + tuple(tin.shape), dtype=tin.dtype, device=self.device)
+            buf = (tin, tout, din, dout)
+            self._stage = getattr(self, "_stage", {})
+            self._stage[key] = buf
+        tin, tout, din, dout = buf
+        tin.numpy()[...] = arr
+        din.copy_(tin, non_blocking=True)
+        self.dist.all_gather(list(dout.unbind(0)), din)
+        tout.copy_(dout, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
         self.n_collectives += 1
-        return out.cpu().numpy()
+        return tout.numpy().copy()
 
 
 def fx_to_limbs(fx):
