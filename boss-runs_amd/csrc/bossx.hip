@@ -304,8 +304,8 @@ void bossx_destroy(bossx_engine *h) {
     if (h->d_tile_order) hipFree(h->d_tile_order);
     void *ptrs[] = {h->d_cov, h->d_meta, h->d_touched, h->d_strat, h->d_bucket_on, h->d_entropy, h->d_ds,
                     h->d_benefit, h->d_lut_score, h->d_lut_ent, h->d_fhat, h->d_bucket_sums, h->d_drop_count,
-                    h->d_stats, h->d_result, h->d_tile_off, h->d_site_off, h->d_length, h->d_bin_off, h->d_row_off,
-                    h->d_strat_off, h->d_bucket_off, h->d_drop_thr, h->d_local, h->d_limbs, h->d_tails,
+                    h->d_stats, h->d_tails /* base of the tails + result block */, h->d_tile_off, h->d_site_off, h->d_length, h->d_bin_off, h->d_row_off,
+                    h->d_strat_off, h->d_bucket_off, h->d_drop_thr, h->d_local, h->d_limbs,
                     h->d_strat_bits};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &st : h->slots) { if (st.d_ops) hipFree(st.d_ops); if (st.d_tiles) hipFree(st.d_tiles); if (st.d_blob) hipFree(st.d_blob); if (st.d_segs) hipFree(st.d_segs); if (st.d_tilerefs) hipFree(st.d_tilerefs); }
@@ -440,18 +440,23 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
     if ((rc = dev_alloc(h, &h->d_drop_count, size_t(h->n_tiles), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_tile_ref, size_t(h->n_tiles), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_stats, size_t(BOSSX_HIST_BINS * 3 + 4 + 128), true))) return rc;
-    // control block, error flag and per-contig switches share one allocation: one D2H copy per update
+    // One allocation: [halo tails | control block | error flag | per-contig switches].  The tails sit
+    // right before the control block, whose first field is the running maximum: the multi-GPU MAX
+    // all-reduce over "tails + 1 double" reduces the normaliser in place.  The part from the
+    // control block on is what an update copies back (one D2H copy).
     {
+        const size_t n_t = h->filt.size() * h->filt.size() * 2 * size_t(nb);
         const size_t bytes = sizeof(Ctrl) + 16 + h->filt.size();
-        if ((rc = dev_alloc(h, &h->d_result, bytes, true))) return rc;
+        uint8_t *base = nullptr;
+        if ((rc = dev_alloc(h, &base, n_t * sizeof(double) + bytes, true))) return rc;
+        h->d_tails = reinterpret_cast<double *>(base);
+        h->d_result = base + n_t * sizeof(double);
         h->d_ctrl = reinterpret_cast<Ctrl *>(h->d_result);
         h->d_err = reinterpret_cast<int32_t *>(h->d_result + sizeof(Ctrl));
         h->d_contig_on = h->d_result + sizeof(Ctrl) + 16;
         h->result_bytes = bytes;
     }
     if ((rc = dev_alloc(h, &h->d_limbs, size_t(BOSSX_HIST_BINS + 1) * 5, true))) return rc;
-    // + one slot: the normaliser rides with the tails in one MAX all-reduce (bossx_dist_tails)
-    if ((rc = dev_alloc(h, &h->d_tails, h->filt.size() * h->filt.size() * 2 * size_t(nb) + 1, true))) return rc;
     if ((rc = dev_alloc(h, &h->d_lut_score, size_t(BOSSX_NCOMP) * 4, true))) return rc;
     if ((rc = dev_alloc(h, &h->d_lut_ent, size_t(BOSSX_NCOMP) * 4, true))) return rc;
     if ((rc = upload_vec(h, &h->d_tile_off, tile_off))) return rc;
@@ -1073,10 +1078,6 @@ int bossx_dist_hist(bossx_engine *h, const bossx_fhat_desc *fh) {
     { int jrc = join_chain(h); if (jrc) return jrc; }
     int rc = upload_fhat(h, fh);
     if (rc) return rc;
-    if (h->norm_in_tails) {      // the all-reduced maximum comes back from the tails buffer's last slot
-        const size_t n_t = h->filt.size() * h->filt.size() * 2 * size_t(h->nb);
-        HIPCHK(hipMemcpyAsync(&h->d_ctrl->max_bits, h->d_tails + n_t, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    }
     if ((rc = launch_hist(h, fh, 1))) return rc;
     hipLaunchKernelGGL(stats_to_limbs_kernel, dim3((BOSSX_HIST_BINS + 1 + 255) / 256), dim3(256), 0, h->stream, h->d_stats,
                        h->d_stats + BOSSX_HIST_BINS, h->d_stats + BOSSX_HIST_BINS * 3, h->d_limbs, h->d_ctrl, 1);
@@ -1102,9 +1103,7 @@ int bossx_dist_tails(bossx_engine *h) {
     if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "bad dist_tails call");
     HIPCHK(hipSetDevice(h->cfg.device));
     { int jrc = join_chain(h); if (jrc) return jrc; }
-    launch_tails(h);
-    const size_t n_t = h->filt.size() * h->filt.size() * 2 * size_t(h->nb);
-    HIPCHK(hipMemcpyAsync(h->d_tails + n_t, &h->d_ctrl->max_bits, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    launch_tails(h);          // the normaliser already sits behind the tails (ctrl.max_bits)
     h->norm_in_tails = true;
     HIPCHK(hipGetLastError());
     return BOSSX_OK;

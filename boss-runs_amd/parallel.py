@@ -199,7 +199,9 @@ class DistributedBossRuns(BossRuns):
             self.t_armed = wrap(0, (1,), "<i4")
             self.t_norm = wrap(1, (1,), "<i8")            # bit pattern of a non-negative double
             self.t_limbs = wrap(2, ((_lib.HIST_BINS + 1) * 5,), "<i8")
-            self.t_tails = wrap(3, (nfilt * nfilt * 2 * nb + 1,), "<f8")     # + the normaliser slot
+            # halo rows + the normaliser (ctrl.max_bits lies right behind them): ONE MAX all-reduce
+            self.t_tails = wrap(3, (nfilt * nfilt * 2 * nb + 1,), "<f8")
+            self.t_tails_only = self.t_tails[:-1]          # long form: SUM over the rows alone
         if hasattr(self.engine, "set_overlap"):
             # the protocol consumes the chain through the stage-wise entry points, which have no
             # time-out fallback for a chain running next to the sweep: keep it after the sweep
@@ -235,7 +237,9 @@ class DistributedBossRuns(BossRuns):
                 raise ValueError("batch larger than READ_CAP")
             # one int32 record: header (k, m, n_reads) + contig / strand / start / end columns of
             # the k chosen mappings + the m read lengths (positions and lengths are < 2^31)
-            buf = np.zeros(4 + 5 * cap, dtype=np.int32)
+            buf = getattr(self, "_xbuf", None)
+            if buf is None:
+                buf = self._xbuf = np.zeros(4 + 5 * cap, dtype=np.int32)
             buf[:3] = (k, m, n_reads)
             buf[4:4 + k] = summ["contig_idx"]
             buf[4 + cap:4 + cap + k] = summ["rev"]
@@ -243,13 +247,17 @@ class DistributedBossRuns(BossRuns):
             buf[4 + 3 * cap:4 + 3 * cap + k] = summ["tend"]
             buf[4 + 4 * cap:4 + 4 * cap + m] = np.minimum(read_lengths, 2 ** 31 - 1)
             allb = self.comm.allgather(buf)
+            # the read lengths first: the move_sum windows (and with them the chain) wait for them
+            read_lengths = np.concatenate([b[4 + 4 * cap:4 + 4 * cap + int(b[1])] for b in allb]).astype(np.int64)
+            self.rl_dist.update(read_lengths)
+            self._launch_chain_early()
             ks = [int(b[0]) for b in allb]
             col = lambda j: np.concatenate([b[4 + j * cap:4 + j * cap + kk] for b, kk in zip(allb, ks)]).astype(np.int64)
-            read_lengths = np.concatenate([b[4 + 4 * cap:4 + 4 * cap + int(b[1])] for b in allb]).astype(np.int64)
             n_reads = int(sum(int(b[2]) for b in allb))
             summ = dict(contig_idx=col(0), rev=col(1), tstart=col(2), tend=col(3))
-        self.rl_dist.update(read_lengths)
-        self._launch_chain_early()          # the chain needs only the read-length windows
+        else:
+            self.rl_dist.update(read_lengths)
+            self._launch_chain_early()          # the chain needs only the read-length windows
         self.total_reads += n_reads
         ci = np.asarray(summ["contig_idx"])
         for i, n in enumerate(np.bincount(ci[ci >= 0], minlength=len(self.contig_names))):

@@ -263,14 +263,15 @@ int bossx_update_benefit(bossx_engine *h, const int32_t *windows, const double *
  *     bossx_dist_hist                         histogram with the global normaliser -> LIMBS
  *     all-reduce SUM  LIMBS                   (int64[(BOSSX_HIST_BINS + 1) * 5], exact)
  *     bossx_dist_pick                         global threshold; publishes the block TAILS
- *     all-reduce SUM  TAILS                   (float64[n_filt * n_filt * 2 * nb + 1], one non-zero
+ *     all-reduce SUM  TAILS                   (the first n_filt * n_filt * 2 * nb float64, one non-zero
  *                                              contributor per element: exact)
  *     bossx_dist_finish                       masks (halo rows from the tails), D2H, sync
  * Shorter form (one collective fewer): after the chain, bossx_dist_tails publishes the TAILS
- * (they do not depend on the threshold) and puts the normaliser into the TAILS buffer's extra last
- * slot; ONE all-reduce MAX over that float64 buffer (every element is non-negative and has one
- * non-zero contributor, so MAX is as exact as SUM) replaces the NORMALISER and TAILS exchanges;
- * bossx_dist_hist then takes the normaliser from the slot and bossx_dist_pick only picks.      */
+ * (they do not depend on the threshold).  The TAILS buffer is followed in memory by the running
+ * maximum (BOSSX_PTR_TAILS reports n_filt * n_filt * 2 * nb + 1 doubles): ONE all-reduce MAX over
+ * it (every element is non-negative and has one non-zero contributor, so MAX is as exact as SUM)
+ * replaces the NORMALISER and TAILS exchanges, reducing the normaliser in place; bossx_dist_pick
+ * then only picks.                                                                            */
 #define BOSSX_PTR_ARMED      0
 #define BOSSX_PTR_NORMALISER 1
 #define BOSSX_PTR_LIMBS      2

@@ -412,7 +412,7 @@ def test_two_rank_device_protocol_emulated_on_one_gpu(in_tmp):
         for d in ranks:
             d.engine.dist_pick(d.rl_dist.time_cost // 100)
         if b % 2 == 1:
-            reduce_pair("t_tails", "sum")
+            reduce_pair("t_tails_only", "sum")
         res = [d.engine.dist_finish() for d in ranks]
         if f.threshold is None:
             assert not res[0]["any_on"] and not res[1]["any_on"]
