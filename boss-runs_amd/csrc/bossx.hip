@@ -64,6 +64,7 @@ struct bossx_engine {
     uint8_t *d_contig_on = nullptr;
     long long *d_limbs = nullptr;       // multi-GPU: SUM-reducible statistics
     double *d_tails = nullptr;          // multi-GPU: last n_filt rows of every block, + 1 slot for the normaliser
+    double dist_tc = 0.0; bool dist_pick_fused = false;   // short form: dist_finish's mask kernel picks the threshold
     bool norm_in_tails = false;         // bossx_dist_tails ran: dist_hist takes the (reduced) normaliser from that slot
     // contig tables (device)
     int64_t *d_tile_off = nullptr, *d_site_off = nullptr, *d_length = nullptr, *d_bin_off = nullptr,
@@ -1089,12 +1090,19 @@ int bossx_dist_pick(bossx_engine *h, double tc) {
     if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "bad dist_pick call");
     HIPCHK(hipSetDevice(h->cfg.device));
     { int jrc = join_chain(h); if (jrc) return jrc; }
+    if (h->norm_in_tails) {
+        // short form: the halo rows are already exchanged, so nothing separates the threshold choice
+        // from the masks — bossx_dist_finish's mask kernel picks it itself (one launch fewer)
+        h->dist_tc = tc;
+        h->dist_pick_fused = true;
+        h->norm_in_tails = false;
+        return BOSSX_OK;
+    }
     PickParams PP;
     PP.counts = h->d_stats; PP.fgrid = h->d_stats + BOSSX_HIST_BINS; PP.ubar = h->d_stats + BOSSX_HIST_BINS * 3;
     PP.limbs = h->d_limbs; PP.ctrl = h->d_ctrl; PP.tc = tc; PP.gate = 1;
     hipLaunchKernelGGL(threshold_pick_kernel, dim3(1), dim3(64), 0, h->stream, PP);
-    if (!h->norm_in_tails) launch_tails(h);     // otherwise published (and reduced) together with the normaliser
-    h->norm_in_tails = false;
+    launch_tails(h);
     HIPCHK(hipGetLastError());
     return BOSSX_OK;
 }
@@ -1134,7 +1142,16 @@ int bossx_dist_finish(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, b
     HIPCHK(hipSetDevice(h->cfg.device));
     { int jrc = join_chain(h); if (jrc) return jrc; }
     h->sweep_in_flight = false;
-    int rc = launch_mask(h, 1, true);
+    int rc;
+    if (h->dist_pick_fused) {
+        PickParams PP;
+        PP.counts = h->d_stats; PP.fgrid = h->d_stats + BOSSX_HIST_BINS; PP.ubar = h->d_stats + BOSSX_HIST_BINS * 3;
+        PP.limbs = h->d_limbs; PP.ctrl = h->d_ctrl; PP.tc = h->dist_tc; PP.gate = 1;
+        rc = launch_mask(h, 1, true, &PP);
+        h->dist_pick_fused = false;
+    } else {
+        rc = launch_mask(h, 1, true);
+    }
     if (rc) return rc;
     const size_t need = h->result_bytes;
     if ((rc = ensure_pin(h, need + 64))) return rc;
