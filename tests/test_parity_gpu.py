@@ -621,3 +621,50 @@ def test_default_schedule_at_40mb_equals_serial(in_tmp):
     # some, not all, positions accepted
     frac = serial[-1][4].mean()
     assert 0.0 < frac < 1.0
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+def test_random_scenarios_vs_oracle(in_tmp, seed):
+    """Seeded random scenarios — contig count and lengths, barcodes (fused, ingest-first and split
+    sweep forms), ploidy, bucket threshold, batch size, read length — against the oracle: coverage,
+    scores, bucket switches, bin sums, benefits, threshold and masks bit for bit, every update."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.runs import BossRuns
+    from oracle.pipeline import OracleRuns
+    rng = np.random.default_rng(seed)
+    n_contigs = int(rng.integers(1, 5))
+    lens = [int(rng.integers(100_000, 330_000)) for _ in range(n_contigs)]
+    nb = int(rng.choice([1, 1, 2, 3, 5]))
+    ploidy = int(rng.choice([1, 2]))
+    thr = int(rng.choice([0, 0, 1, 3]))
+    n_reads = int(rng.integers(300, 1500))
+    mean_len = float(rng.choice([1500.0, 4000.0, 9000.0]))
+    names = ["rc%d" % i for i in range(n_contigs)]
+    contigs = synth.make_reference(lens, seed=seed, names=names)
+    strs = [(n, synth.codes_to_str(c)) for n, c in contigs]
+    args = BossConfig()
+    args.general.name = "rnd%d" % seed
+    args.optional.ploidy = ploidy
+    args.optional.bucket_threshold = thr
+    if nb > 1:
+        args.general.barcodes = ["barcode%02d" % (i + 1) for i in range(nb)]
+    runs = BossRuns(args)
+    runs.init(contigs=strs)
+    o = OracleRuns(strs, ploidy=ploidy, nbarcodes=nb, bucket_threshold=thr)
+    for b in range(4):
+        batch = synth.make_batch(contigs, n_reads, seed=seed * 100 + b, mean_len=mean_len, nbarcodes=nb)
+        bcs = batch["barcodes"] if nb > 1 else None
+        o.process_batch(batch["paf"], batch["seqs"], read_lengths=batch["read_lengths"], barcodes=bcs)
+        runs.rl_dist.update(batch["read_lengths"])
+        runs.process_batch_paf(batch["paf"], batch["seqs"], barcodes=bcs)
+        assert runs.threshold == o.threshold, (seed, b)
+        for n, oc in o.contigs.items():
+            pc = runs.contigs[n]
+            assert np.array_equal(pc.coverage, oc.coverage), (seed, b, n)
+            assert np.array_equal(pc.scores, oc.scores), (seed, b, n)
+            assert np.array_equal(pc.bucket_switches, oc.bucket_switches), (seed, b, n)
+            assert np.array_equal(pc.strat, oc.strat), (seed, b, n)
+            if o.threshold is not None:
+                assert np.array_equal(pc.scores_ds, oc.scores_ds), (seed, b, n)
+                assert np.array_equal(pc.additional_benefit, oc.additional_benefit), (seed, b, n)
