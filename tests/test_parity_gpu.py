@@ -668,3 +668,22 @@ def test_random_scenarios_vs_oracle(in_tmp, seed):
             if o.threshold is not None:
                 assert np.array_equal(pc.scores_ds, oc.scores_ds), (seed, b, n)
                 assert np.array_equal(pc.additional_benefit, oc.additional_benefit), (seed, b, n)
+
+
+def test_mask_views_outlive_the_engine(in_tmp):
+    """Contig.strat views point into page-locked memory that owns itself: they stay readable
+    after the engine is closed and collected."""
+    import gc
+    runs = _product(1, 1, in_tmp)
+    contigs = e2e_reference()
+    for b in range(3):
+        batch = e2e_batch(contigs, b, 1)
+        runs.rl_dist.update(batch["read_lengths"])
+        runs.process_batch_paf(batch["paf"], batch["seqs"])
+    views = {n: c.strat for n, c in runs.contigs_filt.items()}
+    copies = {n: v.copy() for n, v in views.items()}
+    runs.engine.close()
+    del runs
+    gc.collect()
+    for n, v in views.items():
+        assert np.array_equal(v, copies[n])
