@@ -209,12 +209,16 @@ def main():
         step(i)
     eng.enable_timing(True)
     base = eng.kernel_stats()
+    import gc
+    gc.collect()
+    gc.disable()                 # no collector pause inside the timed region
     barrier()
     t0 = time.perf_counter()
     for i in range(a.warmup, n_b):
         step(i)
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     stats = eng.kernel_stats()
     eng.enable_timing(False)
     # PCIe-inclusive path, reported beside (never as) `value`: PAF text + reads in host memory ->
