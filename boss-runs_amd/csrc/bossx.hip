@@ -923,6 +923,7 @@ int bossx_benefit(bossx_engine *h, const int32_t *windows, const double *mult, d
     int rc = fill_chain_params(h, windows, mult, P, lds);
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream));
+    h->max_bits_clear = false;
     launch_chain(h, P, lds);
     HIPCHK(hipGetLastError());
     unsigned long long bits = 0;
@@ -1011,6 +1012,7 @@ int bossx_histogram(bossx_engine *h, double normaliser, const bossx_fhat_desc *f
     unsigned long long bits;
     memcpy(&bits, &normaliser, sizeof(bits));
     HIPCHK(hipMemcpyAsync(&h->d_ctrl->max_bits, &bits, sizeof(bits), hipMemcpyHostToDevice, h->stream));
+    h->max_bits_clear = false;
     if ((rc = launch_hist(h, fh, 0))) return rc;
     std::vector<unsigned long long> host(kStatWords);
     HIPCHK(hipMemcpyAsync(host.data(), h->d_stats, kStatWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
