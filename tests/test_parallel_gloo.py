@@ -80,8 +80,10 @@ def _worker(rank, world, port, tmp, nb, ploidy, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nb,ploidy", [(1, 1), (2, 2)])
-def test_two_ranks_equal_single_process_oracle(nb, ploidy, tmp_path):
+@pytest.mark.parametrize("nb,ploidy,world", [(1, 1, 2), (2, 2, 2), (1, 1, 3)])
+def test_two_ranks_equal_single_process_oracle(nb, ploidy, world, tmp_path):
+    """2 ranks (each owns one contig) and 3 ranks (the third owns nothing: it still takes part in
+    every collective and ends with the same global threshold and masks)."""
     from oracle.pipeline import OracleRuns
     contigs = e2e_reference()
     o = OracleRuns(e2e_contig_strings(contigs), ploidy=ploidy, reject_refs={E2E_REJECT}, nbarcodes=nb)
@@ -97,9 +99,9 @@ def test_two_ranks_equal_single_process_oracle(nb, ploidy, tmp_path):
     mgr = mp.Manager()
     ret = mgr.dict()
     port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, str(tmp_path), nb, ploidy, ret), nprocs=2, join=True)
-    assert set(ret.keys()) == {0, 1}
-    for rank in (0, 1):
+    mp.spawn(_worker, args=(world, port, str(tmp_path), nb, ploidy, ret), nprocs=world, join=True)
+    assert set(ret.keys()) == set(range(world))
+    for rank in range(world):
         for b in range(3):
             got, exp = ret[rank][b], expected[b]
             assert np.array_equal(got["approx_ccl"], exp["approx_ccl"])
