@@ -343,12 +343,14 @@ def test_simulation_decisions(in_tmp):
     assert got == want and any(want.values()) and not all(want.values())
 
 
-def test_two_rank_device_protocol_emulated_on_one_gpu(in_tmp):
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_rank_device_protocol_emulated_on_one_gpu(in_tmp, world):
     """Cross-rank logic of the device-resident multi-GPU update without a second GPU: two
     engines on cuda:0 own different contigs; the four in-stream all-reduces are emulated by
     reducing the two engines' aliased statistics tensors.  Exercises remote-contig geometry in
     every kernel, the exact limb sums, and the halo rows served from the published tails.
-    Result must equal the single-engine fused update."""
+    Result must equal the single-engine fused update.  With world = 3 the third engine owns no
+    contig at all (every contig remote) and still has to follow the protocol."""
     import torch
     from boss_runs_amd.config import BossConfig
     from boss_runs_amd.parallel import DistributedBossRuns
@@ -357,14 +359,14 @@ def test_two_rank_device_protocol_emulated_on_one_gpu(in_tmp):
     class FakeComm:
         def __init__(self, rank):
             self.torch, self.dist, self.on, self.force = torch, None, True, False
-            self.rank, self.world, self.n_collectives = rank, 2, 0
+            self.rank, self.world, self.n_collectives = rank, world, 0
             self.device = torch.device("cuda", 0)
 
     nb = 2
     contigs = e2e_reference()
     torch.cuda.set_device(0)
     ranks = []
-    for r in range(2):
+    for r in range(world):
         args = BossConfig()
         args.general.name = "emu%d" % r
         args.optional.ploidy = 2
@@ -380,7 +382,9 @@ def test_two_rank_device_protocol_emulated_on_one_gpu(in_tmp):
     def reduce_pair(name, op):
         ts = [getattr(d, name) for d in ranks]
         torch.cuda.synchronize()
-        red = torch.maximum(ts[0], ts[1]) if op == "max" else ts[0] + ts[1]
+        red = ts[0].clone()
+        for t in ts[1:]:
+            red = torch.maximum(red, t) if op == "max" else red + t
         for t in ts:
             t.copy_(red)
         torch.cuda.synchronize()
@@ -415,7 +419,7 @@ def test_two_rank_device_protocol_emulated_on_one_gpu(in_tmp):
             reduce_pair("t_tails_only", "sum")
         res = [d.engine.dist_finish() for d in ranks]
         if f.threshold is None:
-            assert not res[0]["any_on"] and not res[1]["any_on"]
+            assert not any(r_["any_on"] for r_ in res)
             continue
         for r, d in enumerate(ranks):
             assert res[r]["any_on"] and res[r]["threshold"] == f.threshold, (b, r)
