@@ -24,7 +24,7 @@ struct bossx_engine {
     bool own_stream = false;
     // second stream: the benefit chain of an update runs next to that update's sweep
     hipStream_t stream2 = nullptr;
-    hipEvent_t ev_begin = nullptr, ev_chain = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_chain = nullptr, ev_sweep = nullptr;
     uint32_t *d_tile_done = nullptr;   // [n_tiles] sweep -> chain hand-off flags (epoch stamped)
     uint32_t *d_tile_order = nullptr;  // [n_tiles] block -> tile for publishing launches: every contig's two ends first
     uint32_t epoch = 0;
@@ -289,7 +289,8 @@ int bossx_create(const bossx_config *cfg, bossx_engine **out) {
     }
     if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_begin, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming) != hipSuccess) return BOSSX_E_HIP;
+        hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_sweep, hipEventDisableTiming) != hipSuccess) return BOSSX_E_HIP;
     *out = e.release();
     return BOSSX_OK;
 }
@@ -301,6 +302,7 @@ void bossx_destroy(bossx_engine *h) {
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
     if (h->ev_begin) hipEventDestroy(h->ev_begin);
     if (h->ev_chain) hipEventDestroy(h->ev_chain);
+    if (h->ev_sweep) hipEventDestroy(h->ev_sweep);
     if (h->d_tile_done) hipFree(h->d_tile_done);
     if (h->d_tile_order) hipFree(h->d_tile_order);
     void *ptrs[] = {h->d_cov, h->d_meta, h->d_touched, h->d_strat, h->d_bucket_on, h->d_entropy, h->d_ds,
@@ -1049,6 +1051,7 @@ int bossx_update_begin(bossx_engine *h, double bucket_threshold) {
     int rc = launch_sweep(h);      // records ev_begin between its prep launch and the sweep proper
     if (rc) return rc;
     launch_buckets(h, bucket_threshold);
+    HIPCHK(hipEventRecord(h->ev_sweep, h->stream));     // sweep + bucket switches of this update are behind this
     HIPCHK(hipGetLastError());
     h->sweep_in_flight = true;
     return BOSSX_OK;
@@ -1266,7 +1269,6 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
     const bool have_strategy_inputs = up->fhat_c != nullptr;
     if (have_strategy_inputs) {
         if ((rc = fill_chain_params(h, up->windows, up->mult, CP, lds))) return rc;
-        if ((rc = upload_fhat(h, &fh))) return rc;
     }
     if (!(up->flags & BOSSX_UPDATE_SWEEP_DONE)) {
         if ((rc = launch_sweep(h))) return rc;
@@ -1281,6 +1283,17 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
     uint8_t *hon = reinterpret_cast<uint8_t *>(pin + sizeof(Ctrl) + 16);
     unsigned long long *hst = reinterpret_cast<unsigned long long *>(pin + ((h->result_bytes + 15) & ~size_t(15)));
     bool chain_done = (up->flags & BOSSX_UPDATE_BENEFIT_DONE) != 0;
+    // A chain that ran next to the sweep lives on stream2: the rest of the update follows it IN THAT
+    // QUEUE (no cross-queue signal between the chain and the histogram); the sweep and the bucket
+    // switches it also depends on finished long ago (ev_sweep).
+    hipStream_t const main_stream = h->stream;
+    struct Restore { bossx_engine *h; hipStream_t s; ~Restore() { h->stream = s; } } restore{h, main_stream};
+    if (have_strategy_inputs && chain_done && h->chain_on_stream2 && (up->flags & BOSSX_UPDATE_SWEEP_DONE)) {
+        HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_sweep, 0));
+        h->stream = h->stream2;
+        h->chain_on_stream2 = false;        // same queue now: ordered behind the chain
+    }
+    if (have_strategy_inputs && (rc = upload_fhat(h, &fh))) return rc;
     for (int attempt = 0;; ++attempt) {
         if (have_strategy_inputs) {
             if (!chain_done) {
@@ -1314,6 +1327,8 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
             HIPCHK(hipStreamSynchronize(h->stream));
             h->overlap_ok = false;
             chain_done = false;
+            HIPCHK(hipStreamSynchronize(main_stream));
+            h->stream = main_stream;       // rerun on the main stream, after the sweep
             continue;
         }
         break;
