@@ -12,65 +12,83 @@ import numpy as np
 from scipy.special import betaln
 
 
+def _sum(a):
+    """Sum in extended precision, rounded once (what an exact sum gives in all but pathological
+    cases; a C loop instead of math.fsum's Python-level iteration)."""
+    return float(np.sum(a, dtype=np.longdouble))
+
+
 class ReadStartDist:
     def __init__(self, contigs, window_size=2000, alpha=1.0, p0=0.1):
         """`contigs`: {name: object with .length}, the non-rejected contigs in merge order."""
         self.alpha, self.p0, self.window_size = alpha, p0, window_size
-        self.read_starts = {n: np.zeros((int(c.length / window_size), 2)) for n, c in contigs.items()}
+        # one merged array (merge order) with per-contig views, so that a batch is counted with ONE
+        # bincount and merge() is free
+        sizes = [int(c.length / window_size) for c in contigs.values()]
+        self._offs = np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)
+        self._merged = np.zeros((int(self._offs[-1]), 2))
+        self.read_starts = {n: self._merged[self._offs[i]:self._offs[i + 1]] for i, n in enumerate(contigs)}
+        self._order = {n: i for i, n in enumerate(contigs)}
+        self._lookup = (None, None, None)
         self.total_len = int(np.sum([a.shape[0] for a in self.read_starts.values()]))
         self.target_size = int(np.sum([c.length for c in contigs.values()]) // 100)
         self.on_target = 1
 
     def merge(self):
-        return np.concatenate(list(self.read_starts.values()))
+        return self._merged
 
     def count_starts(self, names, contig_idx, rev, tstart, tend):
         """readstartdist.py:43-82 on arrays: forward reads count at tstart, reverse at tend, in
         2-kb windows with np.histogram's closed last edge and out-of-range drop."""
-        contig_idx = np.asarray(contig_idx)
-        pos = np.where(np.asarray(rev) != 0, tend, tstart)
-        for ci in np.unique(contig_idx):
-            if ci < 0 or names[ci] not in self.read_starts:
-                continue
-            arr = self.read_starts[names[ci]]
-            n = arr.shape[0]
-            sel = contig_idx == ci
-            for strand in (0, 1):
-                x = pos[sel & ((np.asarray(rev) != 0) == bool(strand))]
-                if x.size == 0 or n == 0:
-                    continue
-                arr[:, strand] += np.histogram(x, bins=n, range=(0, self.window_size * n))[0].astype('float')
+        if self._lookup[0] is not names:        # contig index (add order) -> window offset / count
+            off = np.full(len(names) + 1, -1, dtype=np.int64)
+            cnt = np.zeros(len(names) + 1, dtype=np.int64)
+            for i, nm in enumerate(names):
+                k = self._order.get(nm)
+                if k is not None:
+                    off[i], cnt[i] = self._offs[k], self._offs[k + 1] - self._offs[k]
+            self._lookup = (names, off, cnt)
+        _, off, cnt = self._lookup
+        ci = np.asarray(contig_idx, dtype=np.int64)
+        rev = np.asarray(rev) != 0
+        x = np.where(rev, tend, tstart).astype(np.int64)
+        ws = self.window_size
+        n = cnt[ci]                              # ci == -1 picks the sentinel (count 0)
+        # np.histogram(x, bins=n, range=(0, ws * n)) per contig and strand: windows [k*ws, (k+1)*ws),
+        # the last one closed on the right, anything outside dropped
+        keep = (n > 0) & (x >= 0) & (x <= ws * n)
+        if not keep.any():
+            return
+        w = np.minimum(x[keep] // ws, n[keep] - 1)
+        key = (off[ci[keep]] + w) * 2 + rev[keep]
+        self._merged += np.bincount(key, minlength=2 * self._merged.shape[0]).reshape(-1, 2)
 
     def fhat_compact(self):
         """-> (fhat_c float64[n_windows, 2] already multiplied by the on-target normaliser,
         target_size).  readstartdist.py:86-152."""
         merged = self.merge()
         n = merged.shape[0]
-        fhat = np.zeros(merged.shape)
-        nzi = np.nonzero(merged)
-        nz = merged[nzi]
-        csum = np.sum(nz)
-        fhat[nzi] = np.divide(np.add(self.alpha, nz), 2 * n * self.alpha + csum)
+        nzmask = merged != 0
+        csum = np.sum(merged)                    # counts are integers: the zeros add nothing, any order is exact
         rhs = (self.alpha / (2 * n * self.alpha + csum))
         beta_num = np.exp(betaln(self.alpha, ((2 * n - 1) * self.alpha + csum)))
         beta_denom = np.exp(betaln(self.alpha, ((2 * n - 1) * self.alpha))) or 1e-20
         p0_bit = self.p0 / (self.p0 + (1 - self.p0))
         expected = (1 - p0_bit * (beta_num / beta_denom)) * rhs
-        zero = np.ones(fhat.shape, dtype="bool")
-        zero[nzi] = 0
-        fhat[zero] = expected
+        # (alpha + C) / (2 N alpha + sum C) where reads started, the point-mass expectation elsewhere
+        fhat = np.where(nzmask, np.divide(np.add(self.alpha, merged), 2 * n * self.alpha + csum), expected)
         # sum of the expanded array without building it: 20 copies of every row, plus the
         # re-appended tail (or minus the trimmed tail) of _expand_fhat
         rep = int(self.window_size // 100)
         d = self.target_size - rep * n
         assert d < self.window_size
-        total = rep * math.fsum(fhat.reshape(-1))
+        total = rep * _sum(fhat)
         if d != 0:
             k = abs(d)
             full, part = divmod(k, rep)            # tail rows of the expanded array
-            tail = rep * math.fsum(fhat[n - full:].reshape(-1)) if full else 0.0
+            tail = rep * _sum(fhat[n - full:]) if full else 0.0
             if part:
-                tail += part * math.fsum(fhat[n - full - 1])
+                tail += part * _sum(fhat[n - full - 1])
             total = total + tail if d > 0 else total - tail
         if total != 0:
             fhat = np.multiply(fhat, self.on_target / total)
