@@ -24,7 +24,8 @@ struct bossx_engine {
     bool own_stream = false;
     // second stream: the benefit chain of an update runs next to that update's sweep
     hipStream_t stream2 = nullptr;
-    hipEvent_t ev_begin = nullptr, ev_chain = nullptr, ev_sweep = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_chain = nullptr, ev_sweep = nullptr, ev_fhat = nullptr;
+    double *h_fhat_pin = nullptr;      // page-locked staging of the compact f-hat
     uint32_t *d_tile_done = nullptr;   // [n_tiles] sweep -> chain hand-off flags (epoch stamped)
     uint32_t *d_tile_order = nullptr;  // [n_tiles] block -> tile for publishing launches: every contig's two ends first
     uint32_t epoch = 0;
@@ -290,7 +291,8 @@ int bossx_create(const bossx_config *cfg, bossx_engine **out) {
     if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_begin, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_sweep, hipEventDisableTiming) != hipSuccess) return BOSSX_E_HIP;
+        hipEventCreateWithFlags(&h->ev_sweep, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fhat, hipEventDisableTiming) != hipSuccess) return BOSSX_E_HIP;
     *out = e.release();
     return BOSSX_OK;
 }
@@ -303,6 +305,8 @@ void bossx_destroy(bossx_engine *h) {
     if (h->ev_begin) hipEventDestroy(h->ev_begin);
     if (h->ev_chain) hipEventDestroy(h->ev_chain);
     if (h->ev_sweep) hipEventDestroy(h->ev_sweep);
+    if (h->ev_fhat) hipEventDestroy(h->ev_fhat);
+    if (h->h_fhat_pin) hipHostFree(h->h_fhat_pin);
     if (h->d_tile_done) hipFree(h->d_tile_done);
     if (h->d_tile_order) hipFree(h->d_tile_order);
     void *ptrs[] = {h->d_cov, h->d_meta, h->d_touched, h->d_strat, h->d_bucket_on, h->d_entropy, h->d_ds,
@@ -956,10 +960,19 @@ int upload_fhat(bossx_engine *h, const bossx_fhat_desc *fh) {
     if (fh->n_windows * 2 > h->fhat_cap) {
         HIPCHK(hipStreamSynchronize(h->stream));
         if (h->d_fhat) HIPCHK(hipFree(h->d_fhat));
+        if (h->h_fhat_pin) HIPCHK(hipHostFree(h->h_fhat_pin));
+        h->h_fhat_pin = nullptr;
         h->fhat_cap = fh->n_windows * 2 + 64;
         if ((rc = dev_alloc(h, &h->d_fhat, size_t(h->fhat_cap)))) return rc;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->h_fhat_pin), size_t(h->fhat_cap) * sizeof(double), hipHostMallocDefault));
     }
-    HIPCHK(hipMemcpyAsync(h->d_fhat, fh->fhat_c, size_t(fh->n_windows) * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    // through page-locked staging: a copy from pageable memory is serviced by the host when the
+    // stream reaches it (45 us after the chain ended, measured); this one is a plain DMA
+    const size_t bytes = size_t(fh->n_windows) * 2 * sizeof(double);
+    HIPCHK(hipEventSynchronize(h->ev_fhat));        // the previous upload has left the staging buffer
+    memcpy(h->h_fhat_pin, fh->fhat_c, bytes);
+    HIPCHK(hipMemcpyAsync(h->d_fhat, h->h_fhat_pin, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipEventRecord(h->ev_fhat, h->stream));
     return BOSSX_OK;
 }
 
@@ -1288,12 +1301,14 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
     // switches it also depends on finished long ago (ev_sweep).
     hipStream_t const main_stream = h->stream;
     struct Restore { bossx_engine *h; hipStream_t s; ~Restore() { h->stream = s; } } restore{h, main_stream};
+    // f-hat goes up on the (idle) main stream right away, while the chain still runs
+    if (have_strategy_inputs && (rc = upload_fhat(h, &fh))) return rc;
     if (have_strategy_inputs && chain_done && h->chain_on_stream2 && (up->flags & BOSSX_UPDATE_SWEEP_DONE)) {
         HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_sweep, 0));
+        HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fhat, 0));
         h->stream = h->stream2;
         h->chain_on_stream2 = false;        // same queue now: ordered behind the chain
     }
-    if (have_strategy_inputs && (rc = upload_fhat(h, &fh))) return rc;
     for (int attempt = 0;; ++attempt) {
         if (have_strategy_inputs) {
             if (!chain_done) {
