@@ -107,6 +107,7 @@ struct bossx_engine {
 namespace {
 
 constexpr size_t kStatWords = size_t(BOSSX_HIST_BINS) * 3 + 2;
+constexpr int32_t kNoResult = 0x7fffffff;    // sentinel in the pinned result block's error field
 
 int fail(bossx_engine *h, int code, const std::string &msg) {
     if (h) h->err = msg;
@@ -453,7 +454,7 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
     // control block on is what an update copies back (one D2H copy).
     {
         const size_t n_t = h->filt.size() * h->filt.size() * 2 * size_t(nb);
-        const size_t bytes = sizeof(Ctrl) + 16 + h->filt.size();
+        const size_t bytes = (sizeof(Ctrl) + 16 + h->filt.size() + 7) & ~size_t(7);   // whole 8-byte words
         uint8_t *base = nullptr;
         if ((rc = dev_alloc(h, &base, n_t * sizeof(double) + bytes, true))) return rc;
         h->d_tails = reinterpret_cast<double *>(base);
@@ -998,10 +999,13 @@ int launch_hist(bossx_engine *h, const bossx_fhat_desc *fh, int gate, bool clear
     return BOSSX_OK;
 }
 
-int launch_mask(bossx_engine *h, int gate, bool with_tails = false, const PickParams *pick = nullptr) {
+int launch_mask(bossx_engine *h, int gate, bool with_tails = false, const PickParams *pick = nullptr,
+                unsigned long long *host_result = nullptr) {
     MaskParams P;
     P.do_pick = pick ? 1 : 0;
     if (pick) P.pick = *pick; else P.pick = PickParams{};
+    P.host_result = host_result; P.dev_result = reinterpret_cast<const unsigned long long *>(h->d_result);
+    P.result_words = int32_t(h->result_bytes / 8);
     P.benefit = h->d_benefit; P.bucket_on = h->d_bucket_on; P.strat = h->d_strat; P.ct = table_of(h);
     P.B = h->B; P.NBK = h->NBK; P.rows = h->rows; P.nb = h->nb; P.gate = gate; P.ctrl = h->d_ctrl;
     P.tails = with_tails ? h->d_tails : nullptr; P.tail_k = int32_t(h->filt.size());
@@ -1088,6 +1092,7 @@ static void launch_tails(bossx_engine *h) {
     P.B = h->B; P.NBK = h->NBK; P.rows = h->rows; P.nb = h->nb; P.gate = 1; P.ctrl = h->d_ctrl;
     P.tails = nullptr; P.tail_k = int32_t(h->filt.size());
     P.do_pick = 0; P.pick = PickParams{};
+    P.host_result = nullptr; P.dev_result = nullptr; P.result_words = 0;
     hipLaunchKernelGGL(export_tails_kernel, dim3(64), dim3(256), 0, h->stream, P, h->d_tails);
 }
 
@@ -1326,14 +1331,22 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
             PickParams PP;
             PP.counts = h->d_stats; PP.fgrid = h->d_stats + BOSSX_HIST_BINS; PP.ubar = h->d_stats + BOSSX_HIST_BINS * 3;
             PP.limbs = nullptr; PP.ctrl = h->d_ctrl; PP.tc = up->tc; PP.gate = 1;
-            if ((rc = launch_mask(h, 1, false, &PP))) return rc;
+            // the mask kernel's block 0 writes the result block into the pinned buffer itself; the
+            // sentinel tells whether it got that far (it returns early while nothing is switched on)
+            *herr = kNoResult;
+            if ((rc = launch_mask(h, 1, false, &PP, reinterpret_cast<unsigned long long *>(pin)))) return rc;
         }
         HIPCHK(hipGetLastError());
         // results
-        HIPCHK(hipMemcpyAsync(pin, h->d_result, h->result_bytes, hipMemcpyDeviceToHost, h->stream));
+        if (!have_strategy_inputs)
+            HIPCHK(hipMemcpyAsync(pin, h->d_result, h->result_bytes, hipMemcpyDeviceToHost, h->stream));
         if (counts) HIPCHK(hipMemcpyAsync(hst, h->d_stats, kStatWords * 8, hipMemcpyDeviceToHost, h->stream));
         if (strat_all && have_strategy_inputs && (rc = copy_masks(h, strat_all, (up->flags & BOSSX_UPDATE_STRAT_BITS) != 0))) return rc;
         HIPCHK(hipStreamSynchronize(h->stream));
+        if (have_strategy_inputs && *herr == kNoResult) {      // the kernel left early: fetch the block the ordinary way
+            HIPCHK(hipMemcpyAsync(pin, h->d_result, h->result_bytes, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
         if (have_strategy_inputs && (hc->err & 4) && attempt == 0) {
             // The concurrent chain gave up waiting for the sweep (kernels serialised by a profiler):
             // rerun it after the sweep, and stay serial from now on.
