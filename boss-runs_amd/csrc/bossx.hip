@@ -9,6 +9,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 
@@ -107,6 +108,10 @@ struct bossx_engine {
 namespace {
 
 constexpr size_t kStatWords = size_t(BOSSX_HIST_BINS) * 3 + 2;
+// page-locked blocks handed out by bossx_host_alloc: device-writable host memory (process-wide:
+// bossx_host_free has no engine)
+std::mutex g_host_mutex;
+std::vector<std::pair<uint8_t *, size_t>> g_host_blocks;
 constexpr int32_t kNoResult = 0x7fffffff;    // sentinel in the pinned result block's error field
 
 int fail(bossx_engine *h, int code, const std::string &msg) {
@@ -1000,12 +1005,13 @@ int launch_hist(bossx_engine *h, const bossx_fhat_desc *fh, int gate, bool clear
 }
 
 int launch_mask(bossx_engine *h, int gate, bool with_tails = false, const PickParams *pick = nullptr,
-                unsigned long long *host_result = nullptr) {
+                unsigned long long *host_result = nullptr, uint8_t *host_strat = nullptr) {
     MaskParams P;
     P.do_pick = pick ? 1 : 0;
     if (pick) P.pick = *pick; else P.pick = PickParams{};
     P.host_result = host_result; P.dev_result = reinterpret_cast<const unsigned long long *>(h->d_result);
     P.result_words = int32_t(h->result_bytes / 8);
+    P.host_strat = host_strat;
     P.benefit = h->d_benefit; P.bucket_on = h->d_bucket_on; P.strat = h->d_strat; P.ct = table_of(h);
     P.B = h->B; P.NBK = h->NBK; P.rows = h->rows; P.nb = h->nb; P.gate = gate; P.ctrl = h->d_ctrl;
     P.tails = with_tails ? h->d_tails : nullptr; P.tail_k = int32_t(h->filt.size());
@@ -1092,7 +1098,7 @@ static void launch_tails(bossx_engine *h) {
     P.B = h->B; P.NBK = h->NBK; P.rows = h->rows; P.nb = h->nb; P.gate = 1; P.ctrl = h->d_ctrl;
     P.tails = nullptr; P.tail_k = int32_t(h->filt.size());
     P.do_pick = 0; P.pick = PickParams{};
-    P.host_result = nullptr; P.dev_result = nullptr; P.result_words = 0;
+    P.host_result = nullptr; P.dev_result = nullptr; P.result_words = 0; P.host_strat = nullptr;
     hipLaunchKernelGGL(export_tails_kernel, dim3(64), dim3(256), 0, h->stream, P, h->d_tails);
 }
 
@@ -1208,11 +1214,21 @@ int bossx_host_alloc(bossx_engine *h, size_t bytes, void **ptr) {
     if (!h || !ptr) return fail(h, BOSSX_E_INVALID, "bad host_alloc call");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    {
+        std::lock_guard<std::mutex> lock(g_host_mutex);
+        g_host_blocks.emplace_back(static_cast<uint8_t *>(*ptr), bytes);
+    }
     return BOSSX_OK;
 }
 
 int bossx_host_free(void *ptr) {
-    return (!ptr || hipHostFree(ptr) == hipSuccess) ? BOSSX_OK : BOSSX_E_HIP;
+    if (!ptr) return BOSSX_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_host_mutex);
+        for (size_t i = 0; i < g_host_blocks.size(); ++i)
+            if (g_host_blocks[i].first == ptr) { g_host_blocks.erase(g_host_blocks.begin() + long(i)); break; }
+    }
+    return hipHostFree(ptr) == hipSuccess ? BOSSX_OK : BOSSX_E_HIP;
 }
 
 int bossx_set_overlap(bossx_engine *h, int32_t on) {
@@ -1301,6 +1317,7 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
     uint8_t *hon = reinterpret_cast<uint8_t *>(pin + sizeof(Ctrl) + 16);
     unsigned long long *hst = reinterpret_cast<unsigned long long *>(pin + ((h->result_bytes + 15) & ~size_t(15)));
     bool chain_done = (up->flags & BOSSX_UPDATE_BENEFIT_DONE) != 0;
+    bool mirrored = false;
     // A chain that ran next to the sweep lives on stream2: the rest of the update follows it IN THAT
     // QUEUE (no cross-queue signal between the chain and the histogram); the sweep and the bucket
     // switches it also depends on finished long ago (ev_sweep).
@@ -1334,14 +1351,23 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
             // the mask kernel's block 0 writes the result block into the pinned buffer itself; the
             // sentinel tells whether it got that far (it returns early while nothing is switched on)
             *herr = kNoResult;
-            if ((rc = launch_mask(h, 1, false, &PP, reinterpret_cast<unsigned long long *>(pin)))) return rc;
+            // small references: the kernel mirrors its mask bytes into the caller's buffer when that is
+            // device-writable (from bossx_host_alloc) and holds the byte form — no copy afterwards
+            uint8_t *mirror = nullptr;
+            if (strat_all && !(up->flags & BOSSX_UPDATE_STRAT_BITS) && h->strat_bytes <= (int64_t(1) << 20)) {
+                std::lock_guard<std::mutex> lock(g_host_mutex);
+                for (const auto &blk : g_host_blocks)
+                    if (strat_all >= blk.first && strat_all + h->strat_bytes <= blk.first + blk.second) mirror = strat_all;
+            }
+            mirrored = mirror != nullptr;
+            if ((rc = launch_mask(h, 1, false, &PP, reinterpret_cast<unsigned long long *>(pin), mirror))) return rc;
         }
         HIPCHK(hipGetLastError());
         // results
         if (!have_strategy_inputs)
             HIPCHK(hipMemcpyAsync(pin, h->d_result, h->result_bytes, hipMemcpyDeviceToHost, h->stream));
         if (counts) HIPCHK(hipMemcpyAsync(hst, h->d_stats, kStatWords * 8, hipMemcpyDeviceToHost, h->stream));
-        if (strat_all && have_strategy_inputs && (rc = copy_masks(h, strat_all, (up->flags & BOSSX_UPDATE_STRAT_BITS) != 0))) return rc;
+        if (strat_all && have_strategy_inputs && !mirrored && (rc = copy_masks(h, strat_all, (up->flags & BOSSX_UPDATE_STRAT_BITS) != 0))) return rc;
         HIPCHK(hipStreamSynchronize(h->stream));
         if (have_strategy_inputs && *herr == kNoResult) {      // the kernel left early: fetch the block the ordinary way
             HIPCHK(hipMemcpyAsync(pin, h->d_result, h->result_bytes, hipMemcpyDeviceToHost, h->stream));
