@@ -1326,7 +1326,8 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
     // f-hat goes up on the (idle) main stream right away, while the chain still runs
     if (have_strategy_inputs && (rc = upload_fhat(h, &fh))) return rc;
     if (have_strategy_inputs && chain_done && h->chain_on_stream2 && (up->flags & BOSSX_UPDATE_SWEEP_DONE)) {
-        HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_sweep, 0));
+        // ev_fhat was recorded on the main stream behind the sweep and the bucket switches of this
+        // update, so it covers them as well: one (long signalled) cross-queue dependency
         HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fhat, 0));
         h->stream = h->stream2;
         h->chain_on_stream2 = false;        // same queue now: ordered behind the chain
