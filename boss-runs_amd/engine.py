@@ -369,10 +369,18 @@ class Engine:
         return out
 
     def strat_view(self, contig):
-        """Zero-copy bool view [T,2,nb] of one contig's mask inside `strat_all`."""
-        off = int(self.lib.bossx_strat_offset(self.h, contig))
-        T = self.lengths[contig] // 100
-        return self.strat_all[off: off + T * 2 * self.nb].view(np.bool_).reshape(T, 2, self.nb)
+        """Zero-copy bool view [T,2,nb] of one contig's mask inside `strat_all` (the same object
+        every time: the buffer lives as long as the engine)."""
+        cache = self.__dict__.setdefault("_strat_views", {})
+        v = cache.get(contig)
+        if v is None or v.base is None or self.strat_all is not cache.get("_buf"):
+            if self.strat_all is not cache.get("_buf"):
+                cache.clear()
+                cache["_buf"] = self.strat_all
+            off = int(self.lib.bossx_strat_offset(self.h, contig))
+            T = self.lengths[contig] // 100
+            v = cache[contig] = self.strat_all[off: off + T * 2 * self.nb].view(np.bool_).reshape(T, 2, self.nb)
+        return v
 
     def strat_offset(self, contig):
         return int(self.lib.bossx_strat_offset(self.h, contig))
