@@ -2,14 +2,20 @@
 """Benchmark of the BOSS-RUNS decision update on MI355X (BASELINE.json metric:
 "decision-update wall-clock (ms) + Mbp scored/sec, 4000-read batch").
 
-One step = one decision update on one resident 4000-read batch: coverage-scatter of the
-batch (inputs already parsed and uploaded to HBM), the fused per-site sweep, bucket switches,
-exact move_sum benefit chain, threshold statistics, threshold choice on the host, mask
-kernel and the device-to-host copy of every contig's mask.  `value` = reference positions
-whose score state is brought up to date per second (G * nbarcodes / t_update), summed over
-ranks; `ms_per_step` is the decision-update wall-clock.
+One step = ONE decision update as SURVEY.md §8(d) defines it: from "PAF batch text + read
+sequences in host memory" to "all contig masks in host memory" — the read-length step
+(`rl_dist.update`, boss/core.py:106) and `BossRuns.process_batch_paf` (= process_batch_runs
+minus the mapper call, boss/runs/core.py:214-224) on a FRESH 4000-read batch every step: native
+PAF/CIGAR front end, upload, fused per-site sweep with coverage ingestion, bucket switches, exact
+move_sum benefit chain, threshold statistics and choice, masks, device-to-host copy.  The npz
+write is not part of the step (SURVEY §8d reports it separately).
 
-    python bench.py                               # N=1, E. coli 4.6 Mb (BASELINE configs[1])
+`value` = reference positions whose score state is brought up to date per second
+(G * nbarcodes / t_update), summed over ranks; `ms_per_step` = t_update.  The same K updates on
+batches already parsed and resident in HBM are reported beside it as `kernels_only_ms`.
+
+    python bench.py                               # N=1, chr20+chr21 110 Mb ploidy 2 (BASELINE configs[2])
+    python bench.py --workload ecoli|barcoded|shard390|grch38
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
 """
 import argparse
@@ -25,6 +31,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+GPU_CLOCK_GHZ = 2.4         # MI355X_MICROARCH.md: peak engine clock
+CHAIN_FLOOR_CYCLES = 13.0   # one dependent FP64 matrix op (52 cycles) per 4 recurrence steps: scripts/mfma_f64_probe.hip
 
 WORKLOADS = {
     # name: (contig lengths, names, ploidy, nbarcodes, reject, preload depth)
@@ -38,18 +46,50 @@ WORKLOADS = {
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="ecoli", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS) + ["grch38"])
     ap.add_argument("--reads", type=int, default=4000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-updates", type=int, default=3)
     ap.add_argument("--no-large", action="store_true",
                     help="skip the extra sweep-kernel measurement on a 200 Mb contig (HBM-sized working set)")
+    ap.add_argument("--no-others", action="store_true",
+                    help="skip the short runs of the other single-GPU workloads (`workloads` object)")
+    ap.add_argument("--track-entropy", action="store_true",
+                    help="keep the reference's per-site entropy array current (dead state on the strategy path)")
     return ap.parse_args()
 
 
-def make_runs(workload, rank, world, device):
+# ---- synthetic inputs (generated before the GPU is touched: worker processes are forked) -------
+_GEN = {}
+
+
+def _gen_one(job):
+    from boss_runs_amd import synth
+    key, seed, n_reads, nb = job
+    b = synth.make_batch(_GEN[key], n_reads, seed=seed, nbarcodes=nb, extras=False)
+    b["read_lengths_arr"] = np.fromiter(b["read_lengths"].values(), dtype=np.int64, count=len(b["read_lengths"]))
+    del b["read_lengths"]
+    return b
+
+
+def generate_batches(jobs):
+    """jobs: list of (reference key, seed, n_reads, nbarcodes) -> list of batches, in order."""
+    import multiprocessing as mp
+    n = min(len(jobs), max(1, min(32, (os.cpu_count() or 1))))
+    if n <= 1:
+        return [_gen_one(j) for j in jobs]
+    with mp.get_context("fork").Pool(n) as pool:
+        return pool.map(_gen_one, jobs, chunksize=1)
+
+
+def make_reference(workload, rank):
+    from boss_runs_amd import synth
+    lens, names = WORKLOADS[workload][0], WORKLOADS[workload][1]
+    return synth.make_reference(lens, seed=1 + rank, names=["%s_r%d" % (n, rank) for n in names])
+
+
+def make_runs(workload, mine, rank, world, device, track_entropy):
     """N=1: the fused single-GPU `BossRuns`.  N>1: `DistributedBossRuns`; the global reference is
     the per-GPU contig set repeated once per rank (weak scaling), contig-partitioned so that
     every rank owns its own copy, with ONE global threshold per update (the collectives of
@@ -59,12 +99,12 @@ def make_runs(workload, rank, world, device):
     from boss_runs_amd.runs import BossRuns
     from boss_runs_amd.parallel import DistributedBossRuns
     lens, names, ploidy, nb, reject, preload = WORKLOADS[workload]
-    mine = synth.make_reference(lens, seed=1 + rank, names=["%s_r%d" % (n, rank) for n in names])
     args = BossConfig()
-    args.general.name = "bench_r%d" % rank
+    args.general.name = "bench_%s_r%d" % (workload, rank)
     args.optional.ploidy = ploidy
     args.optional.bucket_threshold = 0        # strategies on from the first update
     args.gpu.device = device
+    args.gpu.track_entropy = bool(track_entropy)
     if nb > 1:
         args.general.barcodes = ["barcode%02d" % (i + 1) for i in range(nb)]
     if world == 1 and not os.environ.get("BOSSX_FORCE_COLLECTIVES"):
@@ -85,24 +125,39 @@ def make_runs(workload, rank, world, device):
     runs.log_fractions = False
     if preload > 0:
         runs.engine.preload_coverage(preload, seed=7 + rank)
-    return runs, mine, nb
+    return runs, nb
 
 
 def pmc_traffic(workload, kernel_substr):
     """HBM bytes per launch of `kernel_substr` from the newest committed rocprofv3 PMC summary
     of this workload (profiles/rNN_<workload>_rocprof_summary.json: FETCH_SIZE and WRITE_SIZE
-    from separate --pmc passes, in KB; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM)."""
+    from separate --pmc passes, in KB; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).
+    Returns (bytes, file name, commit the profile was taken at)."""
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_%s_rocprof_summary.json" % workload)))
     if not files:
-        return None, None
+        return None, None, None
     d = json.load(open(files[-1]))
     tot, found = 0.0, False
     for name, v in d.get("kernels", {}).items():
         if kernel_substr in name and "FETCH_SIZE_avg_per_launch" in v and "WRITE_SIZE_avg_per_launch" in v:
-            tot += (2.0 * v["FETCH_SIZE_avg_per_launch"] + v["WRITE_SIZE_avg_per_launch"]) * 1024.0
+            # launches of the variants per update differ (plain + ingest): weight by launches per update
+            per_update = v.get("launches_per_update", 1.0)
+            tot += (2.0 * v["FETCH_SIZE_avg_per_launch"] + v["WRITE_SIZE_avg_per_launch"]) * 1024.0 * per_update
             found = True
-    return (tot if found else None), os.path.basename(files[-1])
+    return (tot if found else None), os.path.basename(files[-1]), d.get("commit")
+
+
+def current_commit():
+    p = os.path.join(REPO, ".bossx_commit")       # written before a gpurun call (the GPU box has no .git)
+    if os.path.exists(p):
+        return open(p).read().strip()
+    try:
+        import subprocess
+        return subprocess.run(["git", "-C", REPO, "rev-parse", "--short=12", "HEAD"], capture_output=True,
+                              text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        return None
 
 
 def large_sweep(device, L=200_000_000, reps=5, depth=8.0):
@@ -112,7 +167,7 @@ def large_sweep(device, L=200_000_000, reps=5, depth=8.0):
     from boss_runs_amd.scoring import SiteScoring
     rng = np.random.default_rng(1)
     seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=L, dtype=np.uint8)].tobytes()
-    e = Engine(nbarcodes=1, device=device, track_entropy=True)
+    e = Engine(nbarcodes=1, device=device, track_entropy=False)
     e.add_contig("big", seq)
     del seq
     hap = SiteScoring(1)
@@ -136,17 +191,131 @@ def large_sweep(device, L=200_000_000, reps=5, depth=8.0):
     return out
 
 
-def cpu_baseline(contigs, batches, n_updates):
-    """The oracle (structure-faithful numpy port of the reference) on the host cores."""
+def kernel_table(stats, base):
+    kern = {}
+    for k, v in stats.items():
+        n = v["launches"] - base[k]["launches"]
+        ms = (v["ms_total"] - base[k]["ms_total"]) / max(n, 1)
+        kern[k] = dict(avg_ms=ms, launches=n, bytes=v["bytes_last"],
+                       gbs=(v["bytes_last"] / 1e9) / (ms / 1e3) if ms > 0 else None)
+    return kern
+
+
+class Runner:
+    """One workload on this rank: end-to-end steps on fresh batches, and the same updates on
+    resident batches."""
+
+    def __init__(self, workload, runs, nb, batches, distributed):
+        self.w, self.runs, self.nb, self.batches, self.dist = workload, runs, nb, batches, distributed
+        self.eng = runs.engine
+
+    def step_e2e(self, b):
+        bcs = b["barcodes"] if self.nb > 1 else None
+        if self.dist:
+            self.runs.process_batch_paf(b["paf"], b["seqs"], barcodes=bcs, read_lengths=b["read_lengths_arr"])
+        else:
+            self.runs.rl_dist.update(b["read_lengths_arr"])        # boss/core.py:106
+            self.runs.process_batch_paf(b["paf"], b["seqs"], barcodes=bcs)
+
+    def stage(self, batches):
+        """Parse + upload into numbered slots (untimed): inputs resident in HBM."""
+        summ, t = [], []
+        for i, b in enumerate(batches):
+            self.eng.select_batch(i)
+            t0 = time.perf_counter()
+            summ.append(self.eng.stage_batch(b["paf"], b["seqs"], barcodes=b["barcodes"] if self.nb > 1 else None))
+            t.append(time.perf_counter() - t0)
+        return summ, t
+
+    def step_resident(self, i, b, summ):
+        runs, eng = self.runs, self.eng
+        eng.ingest_staged(slot=i)
+        if self.dist:          # sweep starts now; the exchange / host bookkeeping overlap with it
+            runs.begin_update()
+            runs.account_batch(summ, b["read_lengths_arr"], len(b["seqs"]))
+        else:
+            eng.update_begin(runs.args.optional.bucket_threshold)
+            runs.rl_dist.update(b["read_lengths_arr"])
+            runs.launch_benefit()    # the chain needs only the read-length windows
+            runs._account_reads(summ, len(b["seqs"]))
+        runs.update_wrapper()
+
+
+def timed(fn_barrier, steps_fn):
+    import gc
+    gc.collect()
+    gc.disable()                 # no collector pause inside the timed region
+    fn_barrier()
+    t0 = time.perf_counter()
+    steps_fn()
+    fn_barrier()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    return dt
+
+
+def cpu_baseline_like_for_like(runs, contigs, workload, batch):
+    """ONE update of the oracle (structure-faithful numpy port of the reference, oracle/) on the
+    host, starting from exactly the state the GPU engine holds (coverage, scores, switches, masks,
+    read-start counts and the read-length histogram are exported from it), on the same fresh batch
+    the GPU then processes — so the two time the same work and their results can be compared."""
     from boss_runs_amd import synth
     from oracle.pipeline import OracleRuns
-    o = OracleRuns([(n, synth.codes_to_str(c)) for n, c in contigs], bucket_threshold=0)
-    times = []
-    for b in batches[:n_updates]:
-        t0 = time.perf_counter()
-        o.process_batch(b["paf"], b["seqs"], read_lengths=b["read_lengths"])
-        times.append(time.perf_counter() - t0)
-    return o, times
+    lens, names, ploidy, nb, reject, preload = WORKLOADS[workload]
+    o = OracleRuns([(n, synth.codes_to_str(c)) for n, c in contigs], ploidy=ploidy, nbarcodes=nb, bucket_threshold=0)
+    for name, oc in o.contigs_filt.items():
+        pc = runs.contigs[name]
+        oc.coverage[:] = pc.coverage
+        oc.scores[:] = pc.scores
+        oc.bucket_switches[:] = pc.bucket_switches
+        oc.switched_on[:] = pc.switched_on
+        oc.strat[:] = pc.strat
+        o.read_starts.read_starts[name][:] = runs.read_starts.read_starts[name]
+    o.rl_dist.read_lengths[:] = runs.rl_dist.read_lengths
+    o.timings = {}
+    rl = dict(zip(batch["seqs"].keys(), batch["read_lengths_arr"].tolist()))
+    t0 = time.perf_counter()
+    o.process_batch(batch["paf"], batch["seqs"], read_lengths=rl, barcodes=batch["barcodes"] if nb > 1 else None)
+    t_cpu = time.perf_counter() - t0
+    # the GPU on the same batch from the same state
+    t0 = time.perf_counter()
+    runs.rl_dist.update(batch["read_lengths_arr"])
+    runs.process_batch_paf(batch["paf"], batch["seqs"], barcodes=batch["barcodes"] if nb > 1 else None)
+    t_gpu = time.perf_counter() - t0
+    same = runs.threshold == o.threshold
+    for name, oc in o.contigs_filt.items():
+        same = same and bool(np.array_equal(runs.contigs[name].strat, oc.strat))
+    return o, t_cpu, t_gpu, bool(same)
+
+
+def other_workload(name, device, batches, steps, warmup, track_entropy):
+    """Short run of another single-GPU workload: end-to-end and resident-batch update times."""
+    contigs = _GEN[name]
+    runs, nb = make_runs(name, contigs, 0, 1, device, track_entropy)
+    R = Runner(name, runs, nb, batches, False)
+    eng = runs.engine
+    G = sum(c.length for c in runs.contigs_filt.values())
+    for b in batches[:warmup]:
+        R.step_e2e(b)
+    eng.enable_timing(True)
+    base = eng.kernel_stats()
+    sel = batches[warmup:warmup + steps]
+    dt = timed(eng.synchronize, lambda: [R.step_e2e(b) for b in sel])
+    kern = kernel_table(eng.kernel_stats(), base)
+    summ, _ = R.stage(sel)
+    dtr = timed(eng.synchronize, lambda: [R.step_resident(i, b, s) for i, (b, s) in enumerate(zip(sel, summ))])
+    eng.enable_timing(False)
+    ms = 1e3 * dt / len(sel)
+    out = {"workload": "%s: %s bp, ploidy %d, nbarcodes %d" % (name, "+".join(str(x) for x in WORKLOADS[name][0][:3]) +
+                                                              ("+..." if len(WORKLOADS[name][0]) > 3 else ""),
+                                                              WORKLOADS[name][2], nb),
+           "steps": len(sel), "ms_per_step": ms, "kernels_only_ms": 1e3 * dtr / len(sel),
+           "value_mbp_per_s": G * nb / 1e6 / (dt / len(sel)),
+           "site_sweep": {"avg_ms": kern["site_sweep"]["avg_ms"], "frac_of_hbm_peak": (kern["site_sweep"]["gbs"] or 0.0) / HBM_PEAK_GBS},
+           "benefit_chain_ms": kern["benefit_chain"]["avg_ms"],
+           "chain_floor_ms": max(c.length // 100 + 1 for c in runs.contigs_filt.values()) * CHAIN_FLOOR_CYCLES / GPU_CLOCK_GHZ * 1e-6}
+    eng.close()
+    return out
 
 
 def main():
@@ -154,6 +323,32 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    workload = a.workload or "chr20_21"
+    if workload == "grch38":
+        raise SystemExit("--workload grch38 is not wired up yet")
+    from boss_runs_amd import synth
+
+    # ---- inputs: reference + W+K (+1) distinct synthetic batches, before the GPU is initialised ----
+    n_b = a.warmup + a.steps
+    _GEN[workload] = make_reference(workload, rank)
+    nb_main = WORKLOADS[workload][3]
+    jobs = [(workload, 1000 * (rank + 1) + i, a.reads, nb_main) for i in range(n_b + 1)]
+    others = []
+    if world == 1 and not a.no_others:
+        others = [w for w in ("ecoli", "barcoded", "shard390") if w != workload]
+        for w in others:
+            _GEN[w] = make_reference(w, 0)
+            jobs += [(w, 5000 + i, a.reads, WORKLOADS[w][3]) for i in range(2 + 5)]
+    t0 = time.perf_counter()
+    allb = generate_batches(jobs)
+    t_gen = time.perf_counter() - t0
+    batches, extra = allb[:n_b], allb[n_b]
+    other_batches, off = {}, n_b + 1
+    for w in others:
+        other_batches[w] = allb[off:off + 7]
+        off += 7
+    del allb
+
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -162,42 +357,14 @@ def main():
     if world > 1 or (os.environ.get("BOSSX_FORCE_COLLECTIVES") and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    from boss_runs_amd import synth
 
     os.chdir(tempfile.mkdtemp(prefix="bossx_bench_"))
-    runs, contigs, nb = make_runs(a.workload, rank, world, local_rank)
+    contigs = _GEN[workload]
+    runs, nb = make_runs(workload, contigs, rank, world, local_rank, a.track_entropy)
     distributed = hasattr(runs, "account_batch")
     eng = runs.engine
+    R = Runner(workload, runs, nb, batches, distributed)
     G = sum(c.length for c in runs.contigs_filt.values() if not getattr(c, "remote", False))
-
-    # ---- inputs: W+K distinct synthetic batches, parsed and resident in HBM before timing ----
-    n_b = a.warmup + a.steps
-    batches, summaries = [], []
-    t_parse = []
-    for i in range(n_b):
-        b = synth.make_batch(contigs, a.reads, seed=1000 * (rank + 1) + i, nbarcodes=nb, extras=False)
-        eng.select_batch(i)
-        t0 = time.perf_counter()
-        s = eng.stage_batch(b["paf"], b["seqs"], barcodes=b["barcodes"] if nb > 1 else None)
-        t_parse.append(time.perf_counter() - t0)
-        b["read_lengths_arr"] = np.fromiter(b["read_lengths"].values(), dtype=np.int64, count=len(b["read_lengths"]))
-        batches.append(b)
-        summaries.append(s)
-    aligned = float(np.mean([s["aligned"] for s in summaries]))
-
-    def step(i):
-        eng.ingest_staged(slot=i)
-        if distributed:          # sweep starts now; the exchange / host bookkeeping overlap with it
-            runs.begin_update()
-        else:
-            eng.update_begin(runs.args.optional.bucket_threshold)
-        if distributed:
-            runs.account_batch(summaries[i], batches[i]["read_lengths_arr"], len(batches[i]["seqs"]))
-        else:
-            runs.rl_dist.update(batches[i]["read_lengths_arr"])
-            runs.launch_benefit()    # the chain needs only the read-length windows
-            runs._account_reads(summaries[i], len(batches[i]["seqs"]))
-        runs.update_wrapper()
 
     def barrier():
         if world > 1:
@@ -205,38 +372,29 @@ def main():
         torch.cuda.synchronize()
         eng.synchronize()
 
-    for i in range(a.warmup):
-        step(i)
-    eng.enable_timing(True)
+    # ---- the timed region: K end-to-end updates on fresh batches ---------------------------------
+    for b in batches[:a.warmup]:
+        R.step_e2e(b)
+    eng.enable_timing(True)          # HIP events on the engine's own streams, collected after the region
     base = eng.kernel_stats()
-    import gc
-    gc.collect()
-    gc.disable()                 # no collector pause inside the timed region
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(a.warmup, n_b):
-        step(i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
+    sel = batches[a.warmup:]
+    elapsed = timed(barrier, lambda: [R.step_e2e(b) for b in sel])
     stats = eng.kernel_stats()
+    kern = kernel_table(stats, base)
+    # ---- the same updates with the inputs already resident in HBM (parse + upload outside) --------
+    summ, t_stage = R.stage(sel)
+    base2 = eng.kernel_stats()
+    elapsed_res = timed(barrier, lambda: [R.step_resident(i, b, s) for i, (b, s) in enumerate(zip(sel, summ))])
+    kern_res = kernel_table(eng.kernel_stats(), base2)
     eng.enable_timing(False)
-    # PCIe-inclusive path, reported beside (never as) `value`: PAF text + reads in host memory ->
-    # masks in host memory, i.e. stage (parse + upload) + update, on three further batches
-    t_e2e = []
-    if not distributed:
-        for i in range(3):
-            b = synth.make_batch(contigs, a.reads, seed=777000 + 1000 * rank + i, nbarcodes=nb, extras=False)
-            rl = np.fromiter(b["read_lengths"].values(), dtype=np.int64, count=len(b["read_lengths"]))
-            eng.select_batch(0)
-            t0 = time.perf_counter()
-            runs.rl_dist.update(rl)
-            runs.process_batch_paf(b["paf"], b["seqs"], barcodes=b["barcodes"] if nb > 1 else None)
-            t_e2e.append(time.perf_counter() - t0)
+    # event overhead check: the resident loop once more without events
+    elapsed_res_noev = timed(barrier, lambda: [R.step_resident(i, b, s) for i, (b, s) in enumerate(zip(sel, summ))])
+    aligned = float(np.mean([s["aligned"] for s in summ]))
+
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, elapsed_res], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, elapsed_res = float(t[0].item()), float(t[1].item())
         gt = torch.tensor([float(G * nb)], dtype=torch.float64, device="cuda")
         dist.all_reduce(gt, op=dist.ReduceOp.SUM)
         total_sites = float(gt.item())
@@ -246,64 +404,81 @@ def main():
     value = total_sites / 1e6 / (elapsed / a.steps)
 
     if rank == 0:
-        kern = {}
-        for k, v in stats.items():
-            n = v["launches"] - base[k]["launches"]
-            ms = (v["ms_total"] - base[k]["ms_total"]) / max(n, 1)
-            kern[k] = dict(avg_ms=ms, launches=n, bytes=v["bytes_last"],
-                           gbs=(v["bytes_last"] / 1e9) / (ms / 1e3) if ms > 0 else None)
         dom = max(kern, key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"])
         roof_k = "site_sweep"    # the HBM-streaming kernel the roofline is quoted on
         achieved = kern[roof_k]["gbs"] or 0.0
-        traffic, traffic_src = pmc_traffic(a.workload, "site_sweep_kernel")
+        traffic, traffic_src, traffic_commit = pmc_traffic(workload, "site_sweep_kernel")
+        commit = current_commit()
+        longest_bins = max(c.length // 100 + 1 for c in runs.contigs_filt.values())
         out = {
             "metric": "decision-update wall-clock (ms) + Mbp scored/sec, 4000-read batch",
             "value": value, "unit": "Mbp/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u16+f64", "data": "synthetic",
-            "config": {"workload": "%s: %s, ploidy %d, nbarcodes %d, %d-read PAF batches (mean 6 kb), per GPU"
-                       % (a.workload, "+".join("%d" % c[1].shape[0] for c in contigs),
-                          WORKLOADS[a.workload][2], nb, a.reads),
+            "config": {"workload": "%s: %s bp, ploidy %d, nbarcodes %d, %d-read PAF batches (mean 6 kb), per GPU; "
+                                   "step = PAF text + reads in host memory -> masks in host memory"
+                       % (workload, "+".join("%d" % c[1].shape[0] for c in contigs),
+                          WORKLOADS[workload][2], nb, a.reads),
                        "sites_per_gpu": G, "aligned_bases_per_batch": aligned,
+                       "track_entropy": bool(a.track_entropy),
                        "parallelism": "contig-sharded x%d, one global threshold" % world,
-                       "collectives_per_update": (runs.comm.n_collectives / max(n_b, 1)) if distributed else 0},
+                       "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
+                       "collectives_per_update": (runs.comm.n_collectives / max(n_b + 2 * a.steps, 1)) if distributed else 0},
+            "commit": commit,
+            "timed_region_s": elapsed,
+            "kernels_only_ms": 1e3 * elapsed_res / a.steps,
+            "kernels_only_note": "the same K updates with every batch already parsed and resident in HBM "
+                                 "(ingest + sweep + buckets + chain + histogram + masks + D2H); "
+                                 "without the per-kernel HIP events: %.3f ms" % (1e3 * elapsed_res_noev / a.steps),
             "roofline": {"kernel": roof_k, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_src,
+                         "traffic_source": traffic_src, "traffic_commit": traffic_commit,
+                         "traffic_same_commit": bool(commit and traffic_commit and commit[:12] == str(traffic_commit)[:12]),
                          "algorithmic_bytes": kern[roof_k]["bytes"], "avg_launch_ms": kern[roof_k]["avg_ms"],
-                         "note": "site_sweep = sweep<false> + sweep<true> launches (fused CIGAR expansion + "
-                                 "coverage increment + scoring + bin sums); at this size the working set is "
-                                 "cache resident and the kernel is latency bound; see roofline_large"},
+                         "note": "site_sweep = the sweep launches of one update (fused CIGAR expansion + coverage "
+                                 "increment + scoring + bin sums); HIP events on the engine stream over the timed region; "
+                                 "roofline_large = the same kernel on an HBM-sized working set"},
             "metric_note": "value = Mbp scored/s (reference positions brought up to date per second); "
-                           "ms_per_step = decision-update wall-clock",
-            "kernels": kern, "dominant_kernel_by_time": dom,
+                           "ms_per_step = decision-update wall-clock, PAF text in host memory -> masks in host memory",
+            "kernels": kern, "kernels_resident_loop": kern_res, "dominant_kernel_by_time": dom,
             # the chain is a serial FP64 recurrence (1 % of the data): its bound is the dependent
             # matrix-op latency, not HBM — 52 cycles per 4 bins measured (scripts/mfma_f64_probe.hip)
             "chain_latency": {"kernel": "benefit_chain", "bound": "dependent-op latency",
-                              "bins": int(eng.merged_bins), "ns_per_bin": 1e6 * kern["benefit_chain"]["avg_ms"] / max(int(eng.merged_bins), 1),
-                              "floor_cycles_per_bin": 13.0, "on_fp64_matrix_core": eng.matrix_chain,
+                              "bins_total": int(eng.merged_bins), "bins_longest_contig": int(longest_bins),
+                              "ns_per_bin_longest": 1e6 * kern["benefit_chain"]["avg_ms"] / max(longest_bins, 1),
+                              "floor_cycles_per_bin": CHAIN_FLOOR_CYCLES,
+                              "chain_floor_ms": longest_bins * CHAIN_FLOOR_CYCLES / GPU_CLOCK_GHZ * 1e-6,
+                              "on_fp64_matrix_core": eng.matrix_chain,
                               "runs_next_to_sweep": not os.environ.get("BOSSX_NO_OVERLAP"),
-                              "note": "the kernel starts while the sweep of the same update is still running and "
-                                      "waits for tiles it has not published yet: its duration includes those "
-                                      "waits (0.316 ms = 6.8 ns/bin when it runs after the sweep)"},
-            "host": {"stage_batch_ms_mean": 1e3 * float(np.mean(t_parse)),
-                     "pcie_inclusive_update_ms": (1e3 * float(np.median(t_e2e))) if t_e2e else None,
-                     "pcie_inclusive_note": "PAF text + read strings in host memory -> masks in host memory "
-                                            "(threaded parse, upload, update); not the headline value"},
+                              "note": "exact serial recurrence (bottleneck.move_sum): an update cannot be shorter than "
+                                      "chain_floor_ms = bins of the longest contig x 13 cycles / 2.4 GHz on any GPU count"},
+            "host": {"stage_batch_ms_mean": 1e3 * float(np.mean(t_stage)),
+                     "batch_generation_s": t_gen,
+                     "note": "stage_batch = native PAF/CIGAR parse + upload of one batch (inside ms_per_step)"},
             "move_sum_on_fp64_matrix_core": eng.matrix_chain,
         }
-        if not a.no_large and world == 1:
-            del runs, eng
-            out["roofline_large"] = large_sweep(local_rank)
-        if not a.no_cpu_baseline and world == 1:
-            _, times = cpu_baseline(contigs, batches, a.cpu_updates)
-            t_med = float(np.median(times))
+        if world == 1 and not a.no_cpu_baseline:
+            o, t_cpu, t_gpu, same = cpu_baseline_like_for_like(runs, contigs, workload, extra)
             out["cpu_baseline"] = {
-                "value": G * nb / 1e6 / t_med, "unit": "Mbp/s", "cores": 1, "kind": "port",
-                "sample": "%d full updates of the same workload through oracle/ (numpy port of the reference; "
-                          "median %.2f s per update, PAF parse included)" % (a.cpu_updates, t_med),
-                "ms_per_update": 1e3 * t_med, "host_cores_available": os.cpu_count()}
-            out["speedup_vs_cpu_port"] = (1e3 * t_med) / ms_per_step
+                "value": G * nb / 1e6 / t_cpu, "unit": "Mbp/s", "cores": 1, "kind": "port",
+                "sample": "1 full update of the same workload (%s, %d sites) through oracle/ (numpy port of the "
+                          "reference) from the engine's exported state, same region: PAF text -> masks" % (workload, G),
+                "ms_per_update": 1e3 * t_cpu, "host_cores_available": os.cpu_count(),
+                "stages_ms": {k: 1e3 * v for k, v in o.timings.items()},
+                "gpu_ms_same_batch": 1e3 * t_gpu, "masks_and_threshold_equal_to_gpu": same}
+            out["speedup_vs_cpu_port"] = (1e3 * t_cpu) / ms_per_step
+            del o
+        if world == 1 and not a.no_large:
+            out["roofline_large"] = large_sweep(local_rank)
+        runs.engine.close()
+        del runs, eng, R
+        if others:
+            out["workloads"] = {}
+            for w in others:
+                try:
+                    out["workloads"][w] = other_workload(w, local_rank, other_batches[w], 5, 2, a.track_entropy)
+                except Exception as e:      # a side measurement must not lose the main line
+                    out["workloads"][w] = {"error": repr(e)}
         print(json.dumps(out))
     if dist.is_initialized():
         dist.barrier()

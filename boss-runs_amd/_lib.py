@@ -69,6 +69,8 @@ PROTOTYPES = {
                                          C.POINTER(C.c_int64)]),
     "bossx_paf_summary": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int32,
                                     C.c_int32, C.POINTER(BatchSummary), C.POINTER(C.c_int32)]),
+    "bossx_paf_select_lines": (C.c_int, [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                         C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "bossx_rl_update": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
                                   C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                   C.c_void_p, C.POINTER(C.c_int32)]),
@@ -136,8 +138,11 @@ def load():
     if not os.path.exists(LIB_PATH) and os.path.exists("/opt/rocm/bin/hipcc") and not os.environ.get("BOSSX_NO_AUTOBUILD"):
         # a clean checkout: build the HIP extension in-tree (same as __graft_entry__.build())
         import subprocess
-        subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "ARCH=gfx950"], check=False,
-                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "ARCH=gfx950"], check=False,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0 or not os.path.exists(LIB_PATH):
+            raise BossxError("building the HIP extension failed (make -C %s, exit %d):\n%s\nThere is no CPU "
+                             "fallback." % (os.path.join(_HERE, "csrc"), r.returncode, (r.stdout or "")[-4000:]))
     if not os.path.exists(LIB_PATH):
         raise BossxError(
             "HIP extension not built: %s is missing. Run `python -c 'import __graft_entry__ as g; "

@@ -22,6 +22,29 @@ class OptionalConfig:
 
 
 @dataclass
+class LiveConfig:
+    """boss/config.py:33-37 (read by Boss.launch_live_components / _init_live: out of scope here,
+    kept so that reference-shaped callers find the section)."""
+    device: Optional[str] = None
+    host: str = 'localhost'
+    port: int = 9502
+    data_wait: int = 100
+
+
+@dataclass
+class SimulationConfig:
+    """boss/config.py:54-62."""
+    fq: Optional[str] = None
+    batchsize: int = 4000
+    maxb: int = 400
+    binit: int = 5
+    dumptime: int = 200000000
+    paf_full: Optional[str] = None
+    paf_trunc: Optional[str] = None
+    accept_unmapped: bool = False
+
+
+@dataclass
 class GpuConfig:
     """Additions of this build (no reference counterpart)."""
     device: int = 0
@@ -34,5 +57,7 @@ class GpuConfig:
 @dataclass
 class BossConfig:
     general: GeneralConfig = field(default_factory=GeneralConfig)
+    live: LiveConfig = field(default_factory=LiveConfig)
     optional: OptionalConfig = field(default_factory=OptionalConfig)
+    simulation: SimulationConfig = field(default_factory=SimulationConfig)
     gpu: GpuConfig = field(default_factory=GpuConfig)

@@ -557,6 +557,7 @@ int bossx_stage_batch(bossx_engine *h, const char *paf, size_t paf_len, const ch
     }
     ParseInput in{paf ? paf : "", paf ? paf_len : 0, names, name_off, seq_off, barcodes, n_reads, min_len, h->nb};
     in.ops_buf = h->h_ops_pin; in.ops_cap = h->ops_pin_cap;
+    in.seqs = seqs;
     ParsedBatch pb;
     std::string err;
     int rc = parse_paf_batch(in, h->contigs, h->index, summary, pb, err);

@@ -93,6 +93,7 @@ struct ParseInput {
     int32_t min_len;
     int32_t nbarcodes;
     bool summary_only = false;   // choose mappings and fill the summary, no CIGAR walk
+    const char *seqs = nullptr;  // the read blob seq_off indexes (null: read bases are not validated)
     EmitOp *ops_buf = nullptr;   // storage for the emit runs: ops_capacity_for(paf_len) entries
     size_t ops_cap = 0;
     int32_t n_threads = 0;       // 0: parse_threads()

@@ -85,6 +85,18 @@ struct CigarTable {
 };
 constexpr CigarTable kCigarOp{};
 
+// True if every byte of [p, p + n) is one of 'A', 'C', 'G', 'T' (the reference's base2int table,
+// sequences.py:666-667; anything else becomes an out-of-range column index in np.add.at).
+// Branch-free byte loop: vectorised by the compiler (this file is built with -O3).
+bool all_acgt(const char *p, size_t n) {
+    unsigned bad = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned char c = static_cast<unsigned char>(p[i]);
+        bad |= unsigned(!((c == 'A') | (c == 'C') | (c == 'G') | (c == 'T')));
+    }
+    return bad == 0;
+}
+
 }  // namespace
 
 namespace {
@@ -170,7 +182,8 @@ struct WalkOut {
     std::vector<uint32_t> seg_tile;
     std::vector<uint8_t> seg_bc;
     std::vector<uint64_t> emitted_per_contig;
-    WalkError err;
+    WalkError err;          // first ValueError / AssertionError / KeyError class failure (stops the walk)
+    WalkError range_err;    // first IndexError class failure (raised later in the reference: the walk goes on)
 };
 
 // CIGAR walk of plans [p0, p1): emit runs written densely from `base`, tile segments collected.
@@ -184,6 +197,12 @@ void walk_plans(const ParseInput &in, const std::vector<ContigInfo> &contigs, co
         if (pl.cidx < 0) continue;           // ignored contig (pre-pass marks it)
         const Rec &r = *pl.rec;
         auto fail = [&](int code, std::string msg) { wo.err.group = int64_t(pi); wo.err.code = code; wo.err.msg = std::move(msg); };
+        // IndexError class (np.add.at inside Contig.increment_coverage, reference.py:138): the
+        // reference raises it after convert_records has gone through every read, so it never hides
+        // a parse error of a later read — noted, and the walk continues
+        auto range_fail = [&](std::string msg) {
+            if (!wo.range_err.code) { wo.range_err.group = int64_t(pi); wo.range_err.code = BOSSX_E_RANGE; wo.range_err.msg = std::move(msg); }
+        };
         const ContigInfo &c = contigs[size_t(pl.cidx)];
         const int64_t seq_b = in.seq_off[pl.read], seq_len = in.seq_off[pl.read + 1] - seq_b;
         const int64_t tlo = r.tstart < r.tend ? r.tstart : r.tend;
@@ -193,6 +212,15 @@ void walk_plans(const ParseInput &in, const std::vector<ContigInfo> &contigs, co
         int64_t q = r.rev ? (seq_len - 1 - (r.qlen - r.qend)) : r.qstart;
         const int64_t qstep = r.rev ? -1 : 1;
         const int64_t q_need = r.qend - r.qstart;
+        // quick look at the whole aligned stretch of the read; only a read that holds something
+        // other than A/C/G/T there gets the per-run check below (insertions may hold anything)
+        bool check_bases = false;
+        if (in.seqs && q_need > 0) {
+            int64_t lo = r.rev ? q - (q_need - 1) : q, hi = r.rev ? q : q + (q_need - 1);
+            if (lo < 0) lo = 0;
+            if (hi >= seq_len) hi = seq_len - 1;
+            if (hi >= lo) check_bases = !all_acgt(in.seqs + seq_b + lo, size_t(hi - lo + 1));
+        }
         int64_t consumed = 0, ref_pos = tlo;
         uint64_t cur_emit = pl.emit0;
         EmitOp *const first = w;
@@ -216,9 +244,11 @@ void walk_plans(const ParseInput &in, const std::vector<ContigInfo> &contigs, co
                 const int64_t q_last = q + qstep * (len - 1);
                 if (q < 0 || q >= seq_len || q_last < 0 || q_last >= seq_len)
                     return fail(BOSSX_E_PARSE, "read '" + r.qname + "': CIGAR walks outside the read");   // shape mismatch in cig_rep[notdel] = int_seq[start:end]
+                if (check_bases && !all_acgt(in.seqs + seq_b + (r.rev ? q_last : q), size_t(len)))
+                    range_fail("read '" + r.qname + "': base other than A/C/G/T inside an aligned segment");
             }
             if (ref_pos + len > c.length)
-                return fail(BOSSX_E_RANGE, "read '" + r.qname + "': mapping extends past the end of " + c.name);
+                range_fail("read '" + r.qname + "': mapping extends past the end of " + c.name);
             const uint64_t site = uint64_t(c.site_off + ref_pos);
             w->emit_start = uint32_t(cur_emit);
             w->site_lo = uint32_t(site & 0xffffffffu);
@@ -349,7 +379,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
     // raises inside its per-record loop, sequences.py:700-735).
     std::vector<Plan> plans;
     plans.reserve(groups.size());
-    WalkError pre_err;
+    WalkError pre_err, pre_range;
     uint64_t cur_emit = 0;
     size_t ops_at = 0;
     int32_t n_rec = 0;
@@ -385,8 +415,8 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         } else {
             pl.bc = in.barcodes ? in.barcodes[read] : 0;
             if (pl.bc < 0 || pl.bc >= in.nbarcodes) {
-                pre_fail(BOSSX_E_RANGE, "read '" + r.qname + "': barcode index out of range");
-                break;
+                if (!pre_range.code) { pre_range.group = int64_t(gi); pre_range.code = BOSSX_E_RANGE; pre_range.msg = "read '" + r.qname + "': barcode index out of range"; }
+                pl.bc = 0;
             }
             const int64_t span = r.tstart < r.tend ? r.tend - r.tstart : r.tstart - r.tend;
             cur_emit += uint64_t(span);
@@ -427,10 +457,16 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         for (auto &th : pool) th.join();
     }
     PT(T3);
-    // first failure in record order
+    // first failure in record order; the IndexError class only if nothing else failed (the
+    // reference raises those in _effect_increments, after convert_records has seen every read)
     const WalkError *first_err = pre_err.code ? &pre_err : nullptr;
     for (const WalkOut &wo : wos)
         if (wo.err.code && (!first_err || wo.err.group < first_err->group)) first_err = &wo.err;
+    if (!first_err) {
+        if (pre_range.code) first_err = &pre_range;
+        for (const WalkOut &wo : wos)
+            if (wo.range_err.code && (!first_err || wo.range_err.group < first_err->group)) first_err = &wo.range_err;
+    }
     if (first_err) { err = first_err->msg; return first_err->code; }
     if (cur_emit >= (1ull << 32) - kEmitTile) {
         err = "batch too large: more than 2^32 aligned bases";
@@ -549,6 +585,7 @@ extern "C" int bossx_host_parse(const char *const *contig_names, const int64_t *
     std::vector<EmitOp> buf(ops_capacity_for(paf ? paf_len : 0));
     ParseInput in{paf ? paf : "", paf ? paf_len : 0, names.data(), name_off.data(), seq_off.data(), barcodes, n_reads, min_len, nbarcodes};
     in.ops_buf = buf.data(); in.ops_cap = buf.size(); in.n_threads = n_threads;
+    in.seqs = blob.data();
     ParsedBatch pb;
     std::string err;
     int rc = parse_paf_batch(in, contigs, index, summary, pb, err);
@@ -611,6 +648,45 @@ extern "C" int bossx_host_parse(const char *const *contig_names, const int64_t *
             out_barcode[e] = uint8_t((o.meta >> 8) & 0xffu);
         }
     }
+    return BOSSX_OK;
+}
+
+// Lines of a PAF text whose query name (column 1, normalised as PafLine does) is a read of the
+// batch with keep[read] != 0, copied to `out` in file order, '\n' separated.
+extern "C" int bossx_paf_select_lines(const char *paf, size_t paf_len, const char *const *name_ptrs,
+                                      const int64_t *name_lens, int32_t n_reads, const uint8_t *keep,
+                                      char *out, size_t out_cap, size_t *out_len) {
+    using namespace bossx;
+    if (!out_len || n_reads < 0 || (n_reads > 0 && (!name_ptrs || !name_lens || !keep)) || (paf_len && (!paf || !out)))
+        return BOSSX_E_INVALID;
+    std::unordered_map<std::string_view, int32_t> read_index;
+    read_index.reserve(size_t(n_reads) * 2 + 1);
+    for (int32_t i = 0; i < n_reads; ++i) read_index[std::string_view(name_ptrs[i], size_t(name_lens[i]))] = i;
+    size_t w = 0;
+    const char *p = paf, *end = paf + paf_len;
+    while (p < end) {
+        const char *nl = static_cast<const char *>(memchr(p, '\n', size_t(end - p)));
+        const char *le = nl ? nl : end;
+        std::string_view line = strip(std::string_view(p, size_t(le - p)));
+        p = nl ? nl + 1 : end;
+        if (line.empty()) continue;
+        const size_t t = line.find('\t');
+        const std::string_view q = line.substr(0, t);
+        auto it = read_index.find(q);
+        if (it == read_index.end()) {
+            int64_t v;
+            if (!parse_int(q, v)) continue;
+            const std::string norm = std::to_string(v);         // "007" is stored as "7" (paf.py:55-56)
+            it = read_index.find(std::string_view(norm));
+            if (it == read_index.end()) continue;
+        }
+        if (!keep[it->second]) continue;
+        if (w + line.size() + 1 > out_cap) return BOSSX_E_INVALID;
+        if (w) out[w++] = '\n';
+        memcpy(out + w, line.data(), line.size());
+        w += line.size();
+    }
+    *out_len = w;
     return BOSSX_OK;
 }
 

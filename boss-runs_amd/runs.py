@@ -9,6 +9,7 @@ hold the PAF text (simulations, tests, benchmarks).  Without the HIP extension o
 class raises at `init()`; there is no numpy fallback.
 """
 import logging
+import time
 from pathlib import Path
 
 import numpy as np
@@ -63,23 +64,51 @@ class Boss:
         (Path(self.out_dir) / "masks").mkdir(parents=True, exist_ok=True)
         self.rl_dist = ReadlengthDist()
 
+    data_source = None      # callable() -> (reads {id: seq}, quals {id: qual}); stands in for the FASTQ scan
+
     def _get_new_data(self):
-        raise NotImplementedError("live FASTQ scanning is outside the decision-update path")
+        """boss/core.py:89-107.  Discovering and reading new FASTQ files (LiveRun.scan_dir,
+        FastqBatch) is outside the decision-update path: the caller plugs a `data_source` in.  What
+        belongs to the path is kept: the global read-length distribution is updated here, before
+        the batch function runs (core.py:106)."""
+        if self.data_source is None:
+            raise NotImplementedError("live FASTQ scanning is outside the decision-update path: set "
+                                      "`data_source` to a callable returning (reads, quals)")
+        reads, quals = self.data_source()
+        if not reads:
+            logging.info("no new files, deferring update ")
+            return {}, {}
+        self.rl_dist.update(read_lengths={rid: len(seq) for rid, seq in reads.items()})
+        return reads, quals
 
     def process_batch(self, main_processing_func):
-        """boss/core.py:137-157 without the sleep bookkeeping."""
+        """boss/core.py:137-157: returns the seconds to wait until the next update."""
+        logging.info(f"Next batch ---------------------------- # {self.batch}")
+        tic = time.time()
         new_reads, new_quals = self._get_new_data()
         if not new_reads:
             return self.args.general.wait
         main_processing_func(new_reads=new_reads, new_quals=new_quals)
+        next_update = int(self.args.general.wait - (time.time() - tic))
         self.batch += 1
-        return 0
+        return next_update
+
+    def process_batch_sim(self, main_processing_func):
+        """boss/core.py:160-176."""
+        logging.info(f"Next batch ---------------------------- # {self.batch}")
+        tic = time.time()
+        main_processing_func()
+        next_update = int(self.args.general.wait - (time.time() - tic))
+        self.batch += 1
+        return next_update
 
 
 class BossRuns(Boss):
-    def init(self, contigs=None, engine=None, is_local=None) -> None:
+    def init(self, contigs=None, engine=None, is_local=None, mapper=None) -> None:
         """boss/runs/core.py:23-55.  `contigs` optionally replaces the FASTA with an iterable
-        of (name, sequence)."""
+        of (name, sequence).  `mapper`: a reference-shaped mapper (boss/mapper.py:27: `mu`,
+        `_mappy_batch` / `map_sequences`); without one, the reference's own construction
+        `Mapper(ref=self.ref.mmi)` (core.py:41-42) is attempted when an index is configured."""
         a = self.args
         if not a.general.barcodes:
             self.barcodes_index = {"": 0}
@@ -94,7 +123,13 @@ class BossRuns(Boss):
         self.contigs = self.ref.contigs
         self.contigs_filt = {n: c for n, c in self.contigs.items() if not c.rej}
         self.contig_names = list(self.contigs.keys())
-        self.mapper = None                     # set by the caller when reads must be mapped
+        self.mapper = mapper
+        if mapper is None and a.general.mmi:
+            try:
+                from .mapper import Mapper
+                self.mapper = Mapper(ref=self.ref.mmi)
+            except ImportError as e:           # mappy not installed: PAF text has to be supplied
+                logging.info("no mapper: %s", e)
         self.read_counts = {n: 0 for n in self.contigs}          # AbundanceTracker
         self.total_reads = 0
         self.read_starts = ReadStartDist(contigs=self.contigs_filt)
@@ -140,13 +175,28 @@ class BossRuns(Boss):
             write_mask_bits(f'{self.out_dir}/masks/boss.bits', self._mask_entries(), bits, self.nbarcodes)
 
     # ---- batch entry points ---------------------------------------------------------------
-    def process_batch_runs(self, new_reads, new_quals) -> None:
-        """boss/runs/core.py:202-224.  `self.mapper` must provide
-        `map_batch_paf(sequences) -> str` (PAF text, mapper.py:68-108)."""
-        if self.mapper is None:
-            raise RuntimeError("no mapper attached: use process_batch_paf(paf_text, new_reads)")
-        paf_text = self.mapper.map_batch_paf(sequences=new_reads)
-        self.process_batch_paf(paf_text, new_reads)
+    def process_batch_runs(self, new_reads, new_quals=None) -> None:
+        """boss/runs/core.py:202-224 with the reference's own `Mapper` (boss/mapper.py:27-125):
+        the raw PAF text of the batch comes from `mapper._mappy_batch(sequences=...)` (what
+        `map_sequences` parses, mapper.py:63-64) and is parsed natively with the same
+        `min_len = int(mapper.mu / 2)`.  A mapper that only offers `map_sequences` (a dict of PafLine
+        records) or a `map_batch_paf(sequences) -> str` is accepted as well.  `new_quals` is unused,
+        as in the reference (qt = 0: every base counts, sequences.py:735-736)."""
+        m = self.mapper
+        if m is None:
+            raise RuntimeError("no mapper attached: pass one to init(mapper=...) or use "
+                               "process_batch_paf(paf_text, new_reads)")
+        min_len = int(getattr(m, "mu", 400) / 2)
+        if hasattr(m, "_mappy_batch"):
+            paf_text = m._mappy_batch(sequences=new_reads)
+        elif hasattr(m, "map_batch_paf"):
+            paf_text = m.map_batch_paf(sequences=new_reads)
+        elif hasattr(m, "map_sequences"):
+            from .mapper import paf_dict_to_text
+            paf_text = paf_dict_to_text(m.map_sequences(sequences=new_reads))
+        else:
+            raise TypeError("mapper must provide _mappy_batch, map_batch_paf or map_sequences")
+        self.process_batch_paf(paf_text, new_reads, min_len=min_len)
 
     def process_batch_paf(self, paf_text, new_reads, barcodes=None, min_len=200, starts_filter=None,
                           n_reads_total=None) -> None:

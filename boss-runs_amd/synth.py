@@ -51,9 +51,34 @@ def _rle_cigar(ops):
     return "".join("%d%s" % (l, sym[o]) for l, o in zip(lens.tolist(), ops[starts].tolist()))
 
 
+def _truncated_record(ops, tstart, tend, fl, fr, rev, mu):
+    """The mapping of the first `mu` bases of a read, cut out of its full alignment (columns
+    `ops` in target order: 0 M, 1 I, 2 D).  '+': a prefix of the columns; '-': the read as sequenced
+    is the reverse complement, so its first bases align to the END of the target span.  Returns
+    (qstart, qend, tstart, tend, ops) or None when fewer than 100 aligned bases fall inside."""
+    lead = fr if rev else fl
+    need = mu - lead
+    if need < 100:
+        return None
+    o = ops[::-1] if rev else ops
+    qcons = np.cumsum(o != 2)
+    if qcons[-1] < need:
+        return None
+    k = int(np.searchsorted(qcons, need, side="left"))
+    part = o[:k + 1]
+    while part.shape[0] and part[-1] != 0:          # end on a match column
+        part = part[:-1]
+    if part.shape[0] < 100:
+        return None
+    qc, tc = int((part != 2).sum()), int((part != 1).sum())
+    if rev:
+        return lead, lead + qc, tend - tc, tend, part[::-1]
+    return lead, lead + qc, tstart, tstart + tc, part
+
+
 def make_batch(contigs, n_reads, seed, mean_len=6000.0, min_len=900, max_len=60000,
                sub=0.04, dele=0.03, ins=0.02, nbarcodes=1, start_weights=None, flank=True,
-               extras=True, prefix="r"):
+               extras=True, prefix="r", trunc_mu=None):
     """One synthetic read batch.
 
     contigs: list of (name, codes); reads start uniformly over the concatenated genome
@@ -64,12 +89,17 @@ def make_batch(contigs, n_reads, seed, mean_len=6000.0, min_len=900, max_len=600
 
     Returns dict(paf=str, seqs={id: str}, barcodes={id: int}, read_lengths={id: int},
     aligned=int) where `aligned` counts emitted reference bases of the chosen mappings.
+
+    With `trunc_mu` (simulation mode, boss/runs/simulation.py) the batch also carries `paf_trunc`:
+    the mappings of every read's first `trunc_mu` bases (qlen = trunc_mu), cut out of the full
+    alignments; every 29th read has no truncated mapping, every 31st none at all.
     """
     rng = np.random.default_rng(seed)
     lens = np.array([c[1].shape[0] for c in contigs], dtype=np.int64)
     w = lens.astype(np.float64) if start_weights is None else np.asarray(start_weights, float) * lens
     w = w / w.sum()
     lines, seqs, bcs, rls = [], {}, {}, {}
+    tlines = []
     aligned = 0
     for i in range(n_reads):
         rid = "%s%d_%d" % (prefix, seed, i)
@@ -126,10 +156,20 @@ def make_batch(contigs, n_reads, seed, mean_len=6000.0, min_len=900, max_len=600
         rls[rid] = qlen
         core = "%s\t%d\t%d\t%d\t%s\t%s\t%d\t%d\t%d\t%d\t%d\t%d" % (
             rid, qlen, qstart, qend, "-" if rev else "+", name, L, tstart, tend, nmatch, ncol, 60)
-        lines.append("%s\ttp:A:%s\tcm:i:%d\ts1:i:%d\tdv:f:0.0700\tcg:Z:%s\tAS:i:%d" %
-                     (core, tp, n // 10, n, cigar, n))
-        chosen = tp == "P" and ncol >= 200
-        if extras and i % 53 == 5 and n > 400:
+        unmapped = trunc_mu is not None and i % 31 == 5          # simulation: no mapping at all
+        if not unmapped:
+            lines.append("%s\ttp:A:%s\tcm:i:%d\ts1:i:%d\tdv:f:0.0700\tcg:Z:%s\tAS:i:%d" %
+                         (core, tp, n // 10, n, cigar, n))
+        if trunc_mu is not None and not unmapped and i % 29 != 3:
+            tr = _truncated_record(ops, tstart, tend, fl, fr, rev, int(trunc_mu))
+            if tr is not None:
+                tq0, tq1, tt0, tt1, tops = tr
+                tn = tt1 - tt0
+                tlines.append("%s\t%d\t%d\t%d\t%s\t%s\t%d\t%d\t%d\t%d\t%d\t%d\ttp:A:%s\tcm:i:%d\ts1:i:%d\tcg:Z:%s\tAS:i:%d" %
+                              (rid, int(trunc_mu), tq0, tq1, "-" if rev else "+", name, L, tt0, tt1,
+                               int((tops == 0).sum()), tops.shape[0], 60, tp, tn // 10, tn, _rle_cigar(tops), tn))
+        chosen = tp == "P" and ncol >= 200 and not unmapped
+        if extras and i % 53 == 5 and n > 400 and not unmapped:
             # a second, worse primary-tagged mapping (lower mapq): best_mapper must skip it
             other = contigs[(ci + 1) % len(contigs)]
             o_start = int(rng.integers(0, other[1].shape[0] - n))
@@ -138,4 +178,7 @@ def make_batch(contigs, n_reads, seed, mean_len=6000.0, min_len=900, max_len=600
                           o_start, o_start + 250, 200, 250, 3, 250, 100))
         if chosen:
             aligned += n
-    return dict(paf="\n".join(lines), seqs=seqs, barcodes=bcs, read_lengths=rls, aligned=aligned)
+    out = dict(paf="\n".join(lines), seqs=seqs, barcodes=bcs, read_lengths=rls, aligned=aligned)
+    if trunc_mu is not None:
+        out["paf_trunc"] = "\n".join(tlines)
+    return out

@@ -121,6 +121,13 @@ int bossx_ingest_staged(bossx_engine *h);
 int bossx_paf_summary(bossx_engine *h, const char *paf, size_t paf_len,
                       const char *const *name_ptrs, const int64_t *name_lens, int32_t n_reads,
                       int32_t min_len, bossx_batch_summary *summary, int32_t *n_rec);
+/* The simulation's decision step keeps, per read, either its full-length or its truncated mapping
+ * (runs/simulation.py:87-120): copies to `out` the lines of `paf` whose query name (column 1,
+ * normalised like PafLine: "007" is "7") is read i of the batch with keep[i] != 0, in file order,
+ * newline separated.  `out_cap` >= paf_len + 1 always suffices.  Host only.                    */
+int bossx_paf_select_lines(const char *paf, size_t paf_len, const char *const *name_ptrs,
+                           const int64_t *name_lens, int32_t n_reads, const uint8_t *keep,
+                           char *out, size_t out_cap, size_t *out_len);
 /* ReadlengthDist.update + ccl_approx_constant (readlengthdist.py:36-97) on the host, natively: adds
  * the `n_lens` new read lengths (> min_len_exclusive, clipped to hist_len - 1) to the uint16
  * histogram `hist` (the caller's array of hist_len counters; wraps like the reference's), then

@@ -76,7 +76,7 @@ class OContig:
 
     # -- a7 ------------------------------------------------------------------------------
     def update_scores(self, cache):
-        """sequences.py:398-455 with `cache` playing the 40^5 LUT."""
+        """sequences.py:398-455; `cache.score_arr` / `cache.entropy_arr` are the 40^5 x 4 tables."""
         for b in range(self.nb):
             scores = self.scores[:, b]
             entropy = self.entropy[:, b]
@@ -85,19 +85,19 @@ class OContig:
             maxed = np.where(cov.sum(axis=1) >= 30)[0]
             cm[maxed] = False
             pos = np.nonzero(cm)[0]
-            ent_c, sco_c = cache.lookup(cov[pos])
+            cc = cov[pos]
             ref = self.seq_int[pos]
-            ar = np.arange(pos.shape[0])
-            scores[pos] = sco_c[ref, ar]
+            scores[pos] = cache.score_arr[cc[:, 0], cc[:, 1], cc[:, 2], cc[:, 3], cc[:, 4], ref]
             scores[maxed] = TINY
+            # table misses and sites zeroed by dropout last round read 0.0: computed and inserted
             missing = np.argwhere(scores == 0.0).flatten()
             if missing.shape[0] != 0:
-                ent_m, sco_m = cache.lookup(cov[missing])
+                mp = cov[missing]
+                cache.fill(mp)
                 mb = self.seq_int[missing]
-                am = np.arange(missing.shape[0])
-                scores[missing] = sco_m[mb, am]
-                entropy[missing] = ent_m[mb, am]
-            entropy[pos] = ent_c[ref, ar]
+                scores[missing] = cache.score_arr[mp[:, 0], mp[:, 1], mp[:, 2], mp[:, 3], mp[:, 4], mb]
+                entropy[missing] = cache.entropy_arr[mp[:, 0], mp[:, 1], mp[:, 2], mp[:, 3], mp[:, 4], mb]
+            entropy[pos] = cache.entropy_arr[cc[:, 0], cc[:, 1], cc[:, 2], cc[:, 3], cc[:, 4], ref]
 
     # -- a8 ------------------------------------------------------------------------------
     def modify_scores(self):

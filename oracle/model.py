@@ -166,34 +166,49 @@ class SiteModel:
 
 
 class PatternCache:
-    """Value cache for f(coverage pattern) -> (entropy[4], score[4]).
-
-    Stands in for the reference's 40^5 x 4 dense `score_arr` / `entropy_arr`
-    (sequences.py:347-393) and its on-demand fill (:433-448): a pattern's value does not
-    depend on whether it was precomputed or inserted later, so a dict keyed by the
-    pattern has the same observable behaviour without 6.6 GB of virtual memory.
+    """The reference's dense lookup table `score_arr` / `entropy_arr` float64[40,40,40,40,40,4]
+    (sequences.py:347-393), indexed by the five counts and the reference base, with its
+    on-demand fill (:433-448): an entry that still reads 0.0 is computed from the pattern and
+    inserted.  Like the reference's `np.zeros`, the two 3.3 GB arrays are virtual until touched.
+    The ~137 k patterns the reference precomputes at start-up are not precomputed here: an
+    entry's value does not depend on when it was inserted, and the fill below evaluates each
+    distinct missing pattern once (the reference evaluates every missing SITE, same values).
     """
+    MAXC = 40
 
     def __init__(self, model):
         self.model = model
-        self.store = {}
+        shape = (self.MAXC,) * 5 + (4,)
+        self.score_arr = np.zeros(shape)
+        self.entropy_arr = np.zeros(shape)
+
+    @staticmethod
+    def _idx(cov):
+        return cov[:, 0], cov[:, 1], cov[:, 2], cov[:, 3], cov[:, 4]
+
+    def fill(self, cov):
+        """Insert every pattern of cov[n,5] that the table does not hold yet."""
+        if cov.shape[0] == 0:
+            return
+        c = cov.astype(np.int64)
+        key = (((c[:, 0] * 40 + c[:, 1]) * 40 + c[:, 2]) * 40 + c[:, 3]) * 40 + c[:, 4]
+        key = np.unique(key)
+        u = np.empty((key.shape[0], 5), dtype=np.uint16)
+        for k in (4, 3, 2, 1, 0):
+            u[:, k] = key % 40
+            key = key // 40
+        u = u[self.score_arr[self._idx(u) + (0,)] == 0.0]
+        for lo in range(0, u.shape[0], 1 << 16):
+            part = u[lo: lo + (1 << 16)]
+            e, s = self.model.entropy_and_score(part)
+            self.score_arr[self._idx(part)] = s.T
+            self.entropy_arr[self._idx(part)] = e.T
 
     def lookup(self, cov):
+        """cov [n,5] -> (entropy[4,n], score[4,n]) for all reference bases (fills as needed)."""
         cov = np.ascontiguousarray(cov, dtype=np.uint16)
-        n = cov.shape[0]
-        ent = np.zeros((4, n))
-        sco = np.zeros((4, n))
-        if n == 0:
-            return ent, sco
-        uniq, inv = np.unique(cov, axis=0, return_inverse=True)
-        inv = inv.reshape(-1)
-        todo = [i for i, u in enumerate(uniq) if u.tobytes() not in self.store]
-        if todo:
-            e, s = self.model.entropy_and_score(uniq[todo])
-            for k, i in enumerate(todo):
-                self.store[uniq[i].tobytes()] = (e[:, k].copy(), s[:, k].copy())
-        ue = np.empty((4, len(uniq)))
-        us = np.empty((4, len(uniq)))
-        for i, u in enumerate(uniq):
-            ue[:, i], us[:, i] = self.store[u.tobytes()]
-        return ue[:, inv], us[:, inv]
+        if cov.shape[0] == 0:
+            return np.zeros((4, 0)), np.zeros((4, 0))
+        self.fill(cov)
+        ix = self._idx(cov)
+        return self.entropy_arr[ix].T, self.score_arr[ix].T

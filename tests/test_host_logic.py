@@ -273,6 +273,98 @@ def test_native_parser_errors_are_first_in_record_order():
             host_parse(contigs, "\n".join(bad), batch["seqs"], n_threads=threads, expand=False)
 
 
+def test_native_parser_index_error_class():
+    """IndexError parity (reference.py:138: np.add.at with an out-of-range column / a slice cut
+    short by the contig end).  A base other than A/C/G/T (any case) inside an M run, or a mapping
+    that runs past its contig, fails the whole batch BEFORE anything is staged; the same byte in
+    a clipped flank or inside an insertion is harmless, as in the reference.  Such a failure never
+    hides a ValueError / KeyError of another read (the reference raises those first, in
+    convert_records)."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.engine import host_parse
+    from oracle.pafcigar import parse_paf, convert_records
+    ref = synth.make_reference([200_000], seed=9, names=["c"])
+    batch = synth.make_batch(ref, 400, seed=6, mean_len=3000.0, extras=False)
+    contigs = [("c", 200_000, 0)]
+    lines = batch["paf"].strip().split("\n")
+    seqs = batch["seqs"]
+    good = host_parse(contigs, batch["paf"], seqs, expand=False)["aligned"]
+
+    def first_op_read(strand, need_flank):
+        for i, l in enumerate(lines):
+            f = l.split("\t")
+            if f[4] == strand and (not need_flank or (int(f[2]) > 2 and int(f[1]) - int(f[3]) > 2)) \
+                    and "I" in f[-2 if f[-1].startswith("AS") else -1]:
+                return i, f
+        raise AssertionError("no suitable read")
+
+    for strand in "+-":
+        i, f = first_op_read(strand, True)
+        rid, qlen, qs, qe = f[0], int(f[1]), int(f[2]), int(f[3])
+        s = seqs[rid]
+        # position (in read coordinates) of the first aligned base as the walk reads it
+        first = qs if strand == "+" else qe - 1
+        for ch in "NnaR":
+            bad = dict(seqs)
+            bad[rid] = s[:first] + ch + s[first + 1:]
+            for threads in (1, 4):
+                with pytest.raises(IndexError, match="A/C/G/T"):
+                    host_parse(contigs, batch["paf"], bad, n_threads=threads, expand=False)
+            # the oracle (numpy) raises IndexError on the same input
+            with pytest.raises(IndexError):
+                inc = convert_records(parse_paf(batch["paf"], min_len=200), bad)
+                tmp = np.zeros((200_000, 5, 1), dtype="uint16")
+                for (st, en, q, bc) in inc["c"]:
+                    np.add.at(tmp[st:en], (np.arange(q.shape[0]), q, 0), 1)
+        # the same byte in a clipped flank: ignored
+        ok = dict(seqs)
+        ok[rid] = "N" + s[1:-1] + "N"
+        assert host_parse(contigs, batch["paf"], ok, expand=False)["aligned"] == good
+        # ... and inside an insertion: consumed, never counted (sequences.py:781)
+        cg = [x for x in f if x.startswith("cg:Z:")][0][5:]
+        import re
+        q = 0
+        ins_at = None
+        for n, op in re.findall(r"(\d+)([MIDNSHP=XB])", cg):
+            n = int(n)
+            if op == "I":
+                ins_at = q
+                break
+            if op != "D":
+                q += n
+        rd = s if strand == "+" else None
+        if strand == "+":
+            ok = dict(seqs)
+            ok[rid] = s[:qs + ins_at] + "N" + s[qs + ins_at + 1:]
+            assert host_parse(contigs, batch["paf"], ok, expand=False)["aligned"] == good
+        else:       # the walk reads the reverse complement: alignment column q is read base qe-1-q
+            ok = dict(seqs)
+            p = qe - 1 - ins_at
+            ok[rid] = s[:p] + "N" + s[p + 1:]
+            assert host_parse(contigs, batch["paf"], ok, expand=False)["aligned"] == good
+    # a mapping that runs past the end of its contig
+    short = [("c", 150_000, 0)]
+    with pytest.raises(IndexError, match="past the end"):
+        host_parse(short, batch["paf"], seqs, expand=False)
+    # precedence: a malformed CIGAR in a LATER read wins over the IndexError of an earlier one
+    i, f = first_op_read("+", True)
+    bad = dict(seqs)
+    rid, qs = f[0], int(f[2])
+    bad[rid] = seqs[rid][:qs] + "N" + seqs[rid][qs + 1:]
+    j = len(lines) - 5
+    assert j > i
+    g = lines[j].split("\t")
+    g = [x.replace("cg:Z:", "cg:Z:7M", 1) if x.startswith("cg:Z:") else x for x in g]
+    lines_c = list(lines)
+    lines_c[j] = "\t".join(g)
+    for threads in (1, 4):
+        with pytest.raises(ValueError, match="CIGAR"):
+            host_parse(contigs, "\n".join(lines_c), bad, n_threads=threads, expand=False)
+    # barcode index out of range: IndexError class as well
+    with pytest.raises(IndexError, match="barcode"):
+        host_parse(contigs, batch["paf"], seqs, barcodes=[3] * len(seqs), nbarcodes=2, expand=False)
+
+
 def test_readlength_fast_path_equals_float_scan():
     """ReadlengthDist.update decides approx_ccl on the exact integer histogram; it must agree
     with the reference's float cumsum scan (ccl_approx_constant) and with the oracle on every

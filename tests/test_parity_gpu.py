@@ -691,3 +691,41 @@ def test_mask_views_outlive_the_engine(in_tmp):
     gc.collect()
     for n, v in views.items():
         assert np.array_equal(v, copies[n])
+
+
+def test_reference_loop_through_the_boundary(in_tmp):
+    """SURVEY §8b on the device: `Boss.process_batch(BossRuns.process_batch_runs)` with a mapper of
+    the reference's shape (boss/mapper.py:27-108), then `update_strategy()` (BASELINE.json's name
+    for update_wrapper) without new reads — against the oracle."""
+    from oracle.pipeline import OracleRuns
+    from test_boundary import StubMapper
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.runs import BossRuns
+    contigs = e2e_reference()
+    args = BossConfig()
+    args.general.name = "loop"
+    args.optional.ploidy = 2
+    args.optional.reject_refs = E2E_REJECT
+    mapper = StubMapper(mu=400)
+    runs = BossRuns(args)
+    runs.init(contigs=e2e_contig_strings(contigs), mapper=mapper)
+    o = OracleRuns(e2e_contig_strings(contigs), ploidy=2, reject_refs={E2E_REJECT})
+    state = {}
+    runs.data_source = lambda: (state["reads"], None)
+    for b in range(4):
+        batch = e2e_batch(contigs, b, 1)
+        mapper.paf, state["reads"] = batch["paf"], batch["seqs"]
+        runs.process_batch(runs.process_batch_runs)
+        o.process_batch(batch["paf"], batch["seqs"])
+        assert runs.threshold == o.threshold
+        for n, oc in o.contigs.items():
+            assert np.array_equal(runs.contigs[n].strat, oc.strat), (b, n)
+            if not oc.rej:
+                assert np.array_equal(runs.contigs[n].coverage, oc.coverage)
+                assert np.array_equal(runs.contigs[n].scores, oc.scores)
+    assert o.threshold is not None and mapper.calls and set(mapper.calls) == {"_mappy_batch"}
+    runs.update_strategy()
+    o.update_wrapper()
+    assert runs.threshold == o.threshold
+    for n, oc in o.contigs.items():
+        assert np.array_equal(runs.contigs[n].strat, oc.strat), n
