@@ -76,6 +76,38 @@ class FakeEngine:
                     tend=np.array([r.tend for r in rec_list], dtype=np.int64),
                     qlen=np.array([r.qlen for r in rec_list], dtype=np.int64), ids=ids, aligned=0)
 
+    # ---- the pieces simulation.py uses: mapping choice only, and stage / ingest in two steps ----
+    def paf_summary(self, paf_text, read_ids, min_len=1):
+        if isinstance(paf_text, (bytes, bytearray)):
+            paf_text = paf_text.decode()
+        paf = parse_paf(paf_text, min_len=min_len)
+        ids = list(read_ids)
+        pos = {r: i for i, r in enumerate(ids)}
+        name_idx = {n: i for i, n in enumerate(self.names)}
+        recs = [best_mapper(r) if len(r) > 1 else r[0] for r in paf.values()]
+        return dict(read_idx=np.array([pos[r.qname] for r in recs], dtype=np.int32),
+                    contig_idx=np.array([name_idx.get(r.tname, -1) for r in recs], dtype=np.int32),
+                    rev=np.array([r.rev for r in recs], dtype=np.uint8),
+                    tstart=np.array([r.tstart for r in recs], dtype=np.int64),
+                    tend=np.array([r.tend for r in recs], dtype=np.int64),
+                    qlen=np.array([r.qlen for r in recs], dtype=np.int64), ids=ids)
+
+    def stage_batch(self, paf_text, seqs, barcodes=None, min_len=200, **kw):
+        if isinstance(paf_text, (bytes, bytearray)):
+            paf_text = paf_text.decode()
+        if barcodes is not None and not isinstance(barcodes, dict):
+            barcodes = dict(zip(seqs.keys(), [int(b) for b in barcodes]))
+        saved = self.pending
+        self.pending = {i: [] for i in self.filt}
+        summ = self.ingest_paf(paf_text, seqs, barcodes=barcodes, min_len=min_len)
+        self._staged, self.pending = self.pending, saved
+        return summ
+
+    def ingest_staged(self, slot=None):
+        for i, lst in self._staged.items():
+            self.pending[i].extend(lst)
+        self._staged = {i: [] for i in self.filt}
+
     def _local(self):
         return [(i, self.contigs[i]) for i in self.filt if not self.remote[i]]
 

@@ -180,6 +180,104 @@ def run_scenario(out, tag, ploidy, nb):
     return d
 
 
+SIM_SCENARIOS = [("nb1", 1, False), ("nb2_unmapped", 2, True)]      # tag, nbarcodes, accept_unmapped
+SIM_BATCHES = 5
+
+
+def sim_batch(contigs, b, nb):
+    """Sampled batch of the simulation scenario: full-length and mu-truncated mappings."""
+    return synth.make_batch(contigs, 420, seed=40 + b, mean_len=3000.0, nbarcodes=nb,
+                            start_weights=[0.6, 1.6, 0.5, 0.5], trunc_mu=400)
+
+
+def run_sim_scenario(out, tag, nb, accept_unmapped):
+    """Drives the reference's `BossRunsSim.process_batch_runs_sim` (boss/runs/simulation.py:139-190;
+    make_decisions :37-120) with a stub sampler / read cache (sampling from files and the pseudo-time
+    read cache are out of scope) and records decisions, counters and masks per batch."""
+    import boss.config
+    import boss.runs.simulation
+    contigs = e2e_reference()
+    tmp = tempfile.mkdtemp(prefix="golden_sim_")
+    os.chdir(tmp)
+    fa = os.path.join(tmp, "ref.fa")
+    synth.write_fasta(fa, contigs)
+    open(os.path.join(tmp, "ref.mmi"), "w").close()
+    args = boss.config.BossConfig()
+    args.general.ref = fa
+    args.general.mmi = os.path.join(tmp, "ref.mmi")
+    args.general.name = "goldensim"
+    args.optional.reject_refs = E2E_REJECT
+    args.optional.bucket_threshold = 2
+    args.simulation.accept_unmapped = accept_unmapped
+    if nb > 1:
+        args.general.barcodes = ["barcode%02d" % (i + 1) for i in range(nb)]
+    runs = boss.runs.simulation.BossRunsSim(args=args)
+    runs.init()                               # init_sim minus the file-backed Sampler / ReadCache
+
+    class FqStream:
+        read_ids, total_bases, read_sequences = set(), 0, {}
+
+    class StubSampler:
+        fq_stream = FqStream()
+
+        def sample(self):
+            return self.batch
+
+    class StubCache:
+        mu = 400
+
+        def update_times_runs(self, **kw):
+            pass
+
+        def fill_cache(self, **kw):
+            pass
+    runs.sampler, runs.read_cache, runs.mu, runs.accept_unmapped = StubSampler(), StubCache(), 400, accept_unmapped
+    d = dict(movesum_unpinned=np.array(1), nb=np.array(nb), accept_unmapped=np.array(int(accept_unmapped)))
+    for b in range(SIM_BATCHES):
+        batch = sim_batch(contigs, b, nb)
+        d["b%d_input_digest" % b] = np.array(digest(batch["paf"].encode(), batch["paf_trunc"].encode(),
+                                                    "".join(batch["seqs"].values()).encode()))
+        names = {rid: (bc + 1 if nb > 1 else 0) for rid, bc in batch["barcodes"].items()}   # sampler.py:214-221
+        if nb > 1:
+            for k, rid in enumerate(names):
+                if k % 37 == 11:
+                    names[rid] = 99                                        # 'unclassified' -> index 0 (simulation.py:148)
+        runs.sampler.batch = (batch["seqs"], {k: "I" * len(v) for k, v in batch["seqs"].items()}, names,
+                              batch["paf"], batch["paf_trunc"])
+        runs.sampler.fq_stream.read_ids = set(batch["seqs"].keys())
+        captured = {}
+        orig = runs.make_decisions
+
+        def spy(**kw):
+            res = orig(**kw)
+            paf_dict, reads_decision = res[0], res[1]
+            captured.update(counts=np.array(res[2:], dtype=np.int64),
+                            full_kept=np.array([int(len(reads_decision[r]) == len(kw["seqs"][r])) for r in kw["seqs"]],
+                                               dtype=np.uint8),
+                            chosen_qlen=np.array([paf_dict[r][0].qlen if r in paf_dict else -1 for r in kw["seqs"]],
+                                                 dtype=np.int64))
+            return res
+        runs.make_decisions = spy
+        runs.process_batch_runs_sim()
+        runs.make_decisions = orig
+        d["b%d_counts" % b] = captured["counts"]             # n_mapped, n_unmapped, n_accepted, n_rejected
+        d["b%d_full_kept" % b] = captured["full_kept"]
+        d["b%d_chosen_qlen" % b] = captured["chosen_qlen"]
+        d["b%d_approx_ccl" % b] = runs.rl_dist.approx_ccl.copy()
+        d["b%d_read_starts" % b] = runs.read_starts.merge()
+        d["b%d_total_reads" % b] = np.array(runs.tracker.total_reads)
+        d["b%d_read_counts" % b] = np.array([runs.tracker.read_counts[n] for n in runs.contigs], dtype=np.int64)
+        for cname, c in runs.contigs.items():
+            key = "b%d_%s_" % (b, cname)
+            d[key + "strat"] = np.packbits(c.strat.reshape(-1))
+            d[key + "strat_shape"] = np.array(c.strat.shape)
+            if not c.rej:
+                d[key + "cov_digest"] = np.array(digest(c.coverage))
+                d[key + "cov_total"] = np.array(int(c.coverage.sum(dtype=np.uint64)))
+    np.savez_compressed(os.path.join(out, "g_sim_%s.npz" % tag), **d)
+    return d
+
+
 def main():
     out = HERE
     gen_tables(out)
@@ -189,6 +287,9 @@ def main():
         d = run_scenario(out, tag, pl, nb)
         print(tag, "updated:", [int(d["b%d_updated" % b]) for b in range(E2E_BATCHES)],
               "thr:", [float(d.get("b%d_threshold" % b, np.nan)) for b in range(E2E_BATCHES)])
+    for tag, nb, au in SIM_SCENARIOS:
+        d = run_sim_scenario(out, tag, nb, au)
+        print("sim", tag, [d["b%d_counts" % b].tolist() for b in range(SIM_BATCHES)])
     for f in sorted(os.listdir(out)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(out, f)))
