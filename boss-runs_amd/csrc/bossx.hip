@@ -15,6 +15,7 @@
 
 #include "engine.hpp"
 #include "kernels.hip.inc"
+#include "front_end.hip.inc"
 
 using namespace bossx;
 
@@ -90,6 +91,14 @@ struct bossx_engine {
     double pending_emit = 0, pending_ops = 0;
     bool touched_dirty = false;     // the `touched` byte array holds flags the next sweep must read
     uint32_t *d_tile_ref = nullptr;
+    // device CIGAR walk (front_end.hip.inc): staging scratch shared by all slots
+    char *h_paf_pin = nullptr; size_t paf_pin_cap = 0;        // PAF text, page-locked
+    char *d_paf = nullptr; size_t d_paf_cap = 0;
+    uint8_t *h_plan_pin = nullptr; size_t plan_pin_cap = 0;   // MapPlan[] + TileRef[] + read-back block
+    MapPlan *d_plans = nullptr; size_t d_plans_cap = 0;
+    uint32_t *d_walk = nullptr; size_t d_walk_cap = 0;        // n_runs | walk_err | ops_off | group_count | group_cursor | totals
+    std::vector<uint8_t> read_dirty;                          // per read: holds a byte other than A/C/G/T
+    bool blob_is_pinned = false;                              // the blob handed to stage_core lies in h_blob_pin
     // pinned scratch
     void *h_pin = nullptr; size_t pin_cap = 0;
     void *h_blob_pin = nullptr; size_t blob_pin_cap = 0;
@@ -324,6 +333,11 @@ void bossx_destroy(bossx_engine *h) {
     for (auto &st : h->slots) { if (st.d_ops) hipFree(st.d_ops); if (st.d_tiles) hipFree(st.d_tiles); if (st.d_blob) hipFree(st.d_blob); if (st.d_segs) hipFree(st.d_segs); if (st.d_tilerefs) hipFree(st.d_tilerefs); }
     if (h->d_tile_ref) hipFree(h->d_tile_ref);
     if (h->h_pin) hipHostFree(h->h_pin);
+    if (h->h_paf_pin) hipHostFree(h->h_paf_pin);
+    if (h->h_plan_pin) hipHostFree(h->h_plan_pin);
+    if (h->d_paf) hipFree(h->d_paf);
+    if (h->d_plans) hipFree(h->d_plans);
+    if (h->d_walk) hipFree(h->d_walk);
     if (h->h_blob_pin) hipHostFree(h->h_blob_pin);
     if (h->h_ops_pin) hipHostFree(h->h_ops_pin);
     for (int k = 0; k < BOSSX_K_COUNT; ++k) { if (h->ev0[k]) hipEventDestroy(h->ev0[k]); if (h->ev1[k]) hipEventDestroy(h->ev1[k]); }
@@ -536,18 +550,70 @@ int bossx_set_lut(bossx_engine *h, const double *score, const double *entropy, i
     return BOSSX_OK;
 }
 
-int bossx_stage_batch(bossx_engine *h, const char *paf, size_t paf_len, const char *names,
-                      const int64_t *name_off, const char *seqs, const int64_t *seq_off,
-                      const int32_t *barcodes, int32_t n_reads, int32_t min_len,
-                      bossx_batch_summary *summary, int32_t *n_rec, int64_t *aligned_bases) {
-    if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "stage_batch before finalize");
-    if (n_reads < 0 || (n_reads > 0 && (!names || !name_off || !seqs || !seq_off))) return fail(h, BOSSX_E_INVALID, "bad batch arrays");
-    HIPCHK(hipSetDevice(h->cfg.device));
-    // the pinned run buffer may still feed the previous batch's upload
-    HIPCHK(hipStreamSynchronize(h->stream));
-    const bool timing = getenv("BOSSX_STAGE_TIMING") != nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
-    const size_t ops_need = ops_capacity_for(paf ? paf_len : 0);
+extern "C++" {
+namespace {
+
+template <typename F>
+void run_threads(int nt, F &&fn) {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(fn, t);
+    fn(0);
+    for (auto &th : pool) th.join();
+}
+
+bool bytes_all_acgt(const char *p, size_t n) {       // vectorised by the compiler
+    unsigned bad = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned char c = static_cast<unsigned char>(p[i]);
+        bad |= unsigned(!((c == 'A') | (c == 'C') | (c == 'G') | (c == 'T')));
+    }
+    return bad == 0;
+}
+
+template <typename T>
+int grow_dev(bossx_engine *h, T **p, size_t *cap, size_t need, size_t slack) {
+    if (need <= *cap) return BOSSX_OK;
+    if (*p) HIPCHK(hipFree(*p));
+    *p = nullptr; *cap = 0;
+    const size_t c = need * 9 / 8 + slack;
+    int rc = dev_alloc(h, p, c);
+    if (rc) return rc;
+    *cap = c;
+    return BOSSX_OK;
+}
+
+template <typename T>
+int grow_pin(bossx_engine *h, T **p, size_t *cap, size_t need) {
+    if (need <= *cap) return BOSSX_OK;
+    if (*p) HIPCHK(hipHostFree(*p));
+    *p = nullptr; *cap = 0;
+    const size_t c = need * 5 / 4 + 4096;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(p), c * sizeof(T), hipHostMallocDefault));
+    *cap = c;
+    return BOSSX_OK;
+}
+
+}  // namespace
+}  // extern "C++"
+
+namespace {
+
+const char *walk_message(uint32_t e) {
+    if (e & kWalkBadCigar) return "malformed CIGAR";
+    if (e & kWalkBadOp) return "unknown CIGAR op";
+    if (e & kWalkOutsideRead) return "CIGAR walks outside the read";
+    if (e & kWalkQueryMismatch) return "CIGAR does not consume qend - qstart query bases";
+    if (e & kWalkSpanMismatch) return "CIGAR does not span tend - tstart reference bases";
+    if (e & kWalkRangeEnd) return "mapping extends past the end of its contig";
+    if (e & kWalkRangeBase) return "base other than A/C/G/T inside an aligned segment";
+    return "";
+}
+
+// Host walk (paf_host.cpp): the whole front end on the host, emit runs and segments uploaded.
+// Kept as the checker of the device walk (BOSSX_CHECK_DEVICE_WALK=1) and as an escape hatch
+// (BOSSX_HOST_WALK=1).
+int stage_host_walk(bossx_engine *h, bossx_engine::Staged &st, ParseInput in, bossx_batch_summary *summary, ParsedBatch &pb) {
+    const size_t ops_need = ops_capacity_for(in.paf_len);
     if (ops_need > h->ops_pin_cap) {
         if (h->h_ops_pin) HIPCHK(hipHostFree(h->h_ops_pin));
         h->h_ops_pin = nullptr; h->ops_pin_cap = 0;
@@ -555,20 +621,79 @@ int bossx_stage_batch(bossx_engine *h, const char *paf, size_t paf_len, const ch
         HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->h_ops_pin), cap * sizeof(EmitOp), hipHostMallocDefault));
         h->ops_pin_cap = cap;
     }
-    ParseInput in{paf ? paf : "", paf ? paf_len : 0, names, name_off, seq_off, barcodes, n_reads, min_len, h->nb};
     in.ops_buf = h->h_ops_pin; in.ops_cap = h->ops_pin_cap;
-    in.seqs = seqs;
-    ParsedBatch pb;
+    in.device_walk = false;
     std::string err;
     int rc = parse_paf_batch(in, h->contigs, h->index, summary, pb, err);
     if (rc) return fail(h, rc, err);
-    const auto t1 = std::chrono::steady_clock::now();
-    if (n_rec) *n_rec = pb.n_rec;
-    if (aligned_bases) *aligned_bases = int64_t(pb.total_emit);
-    // the previous staged batch may still be read by an in-flight ingest kernel
+    if ((rc = grow_dev(h, &st.d_ops, &st.ops_cap, pb.n_ops, 1024))) return rc;
+    if ((rc = grow_dev(h, &st.d_segs, &st.segs_cap, pb.segs.size(), 64))) return rc;
+    if ((rc = grow_dev(h, &st.d_tilerefs, &st.tilerefs_cap, pb.tiles.size(), 64))) return rc;
+    if (pb.n_ops) {
+        HIPCHK(hipMemcpyAsync(st.d_segs, pb.segs.data(), pb.segs.size() * sizeof(TileSeg), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(st.d_tilerefs, pb.tiles.data(), pb.tiles.size() * sizeof(TileRef), hipMemcpyHostToDevice, h->stream));
+        for (const OpsChunk &ck : pb.chunks)
+            HIPCHK(hipMemcpyAsync(st.d_ops + ck.dev_off, ck.host, ck.n * sizeof(EmitOp), hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return BOSSX_OK;
+}
+
+// BOSSX_CHECK_DEVICE_WALK=1: the device walk's emit runs must equal the host walk's exactly, and its
+// segments group by group (as sets: their order inside a group is not defined).
+int check_device_walk(bossx_engine *h, bossx_engine::Staged &st, const ParseInput &in0, const ParsedBatch &dev, uint32_t n_segs) {
+    ParseInput in = in0;
+    std::vector<EmitOp> buf(ops_capacity_for(in.paf_len));
+    in.ops_buf = buf.data(); in.ops_cap = buf.size(); in.device_walk = false;
+    ParsedBatch pb;
+    std::string err;
+    int rc = parse_paf_batch(in, h->contigs, h->index, nullptr, pb, err);
+    if (rc) return fail(h, BOSSX_E_INVALID, "device walk check: the host walk fails where the device walk passed: " + err);
+    if (pb.n_ops != dev.n_ops || pb.segs.size() != n_segs || pb.tiles.size() != dev.tiles.size() || pb.total_emit != dev.total_emit ||
+        pb.n_touched_tiles != dev.n_touched_tiles)
+        return fail(h, BOSSX_E_INVALID, "device walk check: counts differ (runs " + std::to_string(dev.n_ops) + " vs " + std::to_string(pb.n_ops) +
+                                           ", segments " + std::to_string(n_segs) + " vs " + std::to_string(pb.segs.size()) +
+                                           ", groups " + std::to_string(dev.tiles.size()) + " vs " + std::to_string(pb.tiles.size()) + ")");
+    std::vector<EmitOp> ops(pb.n_ops), dops(pb.n_ops);
+    for (const OpsChunk &ck : pb.chunks) memcpy(ops.data() + ck.dev_off, ck.host, ck.n * sizeof(EmitOp));
+    std::vector<TileSeg> dsegs(n_segs);
+    std::vector<TileRef> dgroups(dev.tiles.size());
+    if (pb.n_ops) HIPCHK(hipMemcpy(dops.data(), st.d_ops, pb.n_ops * sizeof(EmitOp), hipMemcpyDeviceToHost));
+    if (n_segs) HIPCHK(hipMemcpy(dsegs.data(), st.d_segs, n_segs * sizeof(TileSeg), hipMemcpyDeviceToHost));
+    if (!dgroups.empty()) HIPCHK(hipMemcpy(dgroups.data(), st.d_tilerefs, dgroups.size() * sizeof(TileRef), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < ops.size(); ++i) {
+        EmitOp a = ops[i], b = dops[i];
+        if (a.meta & kOpDel) a.qpos = b.qpos = 0;
+        if (memcmp(&a, &b, sizeof(EmitOp)))
+            return fail(h, BOSSX_E_INVALID, "device walk check: emit run " + std::to_string(i) + " differs");
+    }
+    auto key = [](const TileSeg &x) { return std::make_tuple(x.e_lo, x.e_hi, x.op_lo, x.op_hi); };
+    for (size_t g = 0; g < dgroups.size(); ++g) {
+        const TileRef &a = pb.tiles[g], &b = dgroups[g];
+        if (a.tile != b.tile || a.bc != b.bc || a.seg_hi - a.seg_lo != b.seg_hi - b.seg_lo || a.seg_lo != b.seg_lo)
+            return fail(h, BOSSX_E_INVALID, "device walk check: group " + std::to_string(g) + " differs");
+        std::vector<TileSeg> x(pb.segs.begin() + a.seg_lo, pb.segs.begin() + a.seg_hi), y(dsegs.begin() + b.seg_lo, dsegs.begin() + b.seg_hi);
+        auto lt = [&](const TileSeg &p, const TileSeg &q) { return key(p) < key(q); };
+        std::sort(x.begin(), x.end(), lt); std::sort(y.begin(), y.end(), lt);
+        for (size_t i = 0; i < x.size(); ++i)
+            if (key(x[i]) != key(y[i])) return fail(h, BOSSX_E_INVALID, "device walk check: segments of group " + std::to_string(g) + " differ");
+    }
+    return BOSSX_OK;
+}
+
+// Parse + upload one batch into the selected slot.  `seqs` is the read blob (page-locked when it
+// comes from the gather of bossx_stage_batch_ptrs).
+int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *names, const int64_t *name_off,
+               const char *seqs, const int64_t *seq_off, const int32_t *barcodes, int32_t n_reads, int32_t min_len,
+               bossx_batch_summary *summary, int32_t *n_rec, int64_t *aligned_bases) {
+    const bool timing = getenv("BOSSX_STAGE_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc;
+    // the previous batch's uploads / an ingest kernel may still read the staging buffers
     HIPCHK(hipStreamSynchronize(h->stream));
     const size_t blob_bytes = n_reads > 0 ? size_t(seq_off[n_reads]) : 0;
     if (blob_bytes >= (size_t(1) << 32)) return fail(h, BOSSX_E_RANGE, "read blob larger than 4 GiB");
+    if (paf_len >= (size_t(1) << 32)) return fail(h, BOSSX_E_RANGE, "PAF text larger than 4 GiB");
     if (h->pending_slot == h->slot) {     // the slot still feeds the next sweep: apply it now
         if ((rc = flush_pending(h))) return rc;
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -576,48 +701,130 @@ int bossx_stage_batch(bossx_engine *h, const char *paf, size_t paf_len, const ch
     bossx_engine::Staged &st = h->slots[size_t(h->slot)];
     st.valid = false;
     st.emit_tiles_built = false;
-    if (pb.n_ops > st.ops_cap) {
-        if (st.d_ops) HIPCHK(hipFree(st.d_ops));
-        st.d_ops = nullptr;
-        st.ops_cap = pb.n_ops * 9 / 8 + 1024;
-        if ((rc = dev_alloc(h, &st.d_ops, st.ops_cap))) return rc;
-    }
-    if (blob_bytes + 1024 > st.blob_cap) {       // slack: the ingest prologue reads a 384-byte window that may start at the last base
-        if (st.d_blob) HIPCHK(hipFree(st.d_blob));
-        st.d_blob = nullptr;
-        st.blob_cap = (blob_bytes + 1024) * 9 / 8;
-        if ((rc = dev_alloc(h, &st.d_blob, st.blob_cap))) return rc;
-    }
-    if (pb.segs.size() > st.segs_cap) {
-        if (st.d_segs) HIPCHK(hipFree(st.d_segs));
-        st.d_segs = nullptr;
-        st.segs_cap = pb.segs.size() * 9 / 8 + 64;
-        if ((rc = dev_alloc(h, &st.d_segs, st.segs_cap))) return rc;
-    }
-    if (pb.tiles.size() > st.tilerefs_cap) {
-        if (st.d_tilerefs) HIPCHK(hipFree(st.d_tilerefs));
-        st.d_tilerefs = nullptr;
-        st.tilerefs_cap = pb.tiles.size() * 9 / 8 + 64;
-        if ((rc = dev_alloc(h, &st.d_tilerefs, st.tilerefs_cap))) return rc;
-    }
-    if (pb.n_ops) {
-        HIPCHK(hipMemcpyAsync(st.d_segs, pb.segs.data(), pb.segs.size() * sizeof(TileSeg), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(st.d_tilerefs, pb.tiles.data(), pb.tiles.size() * sizeof(TileRef), hipMemcpyHostToDevice, h->stream));
-        for (const OpsChunk &ck : pb.chunks)
-            HIPCHK(hipMemcpyAsync(st.d_ops + ck.dev_off, ck.host, ck.n * sizeof(EmitOp), hipMemcpyHostToDevice, h->stream));
+    // slack: the ingest prologue reads a 384-byte window that may start at the last base
+    if ((rc = grow_dev(h, &st.d_blob, &st.blob_cap, blob_bytes + 1024, 0))) return rc;
+    ParseInput in{paf ? paf : "", paf ? paf_len : 0, names, name_off, seq_off, barcodes, n_reads, min_len, h->nb};
+    in.seqs = seqs;
+    ParsedBatch pb;
+    const bool host_walk = getenv("BOSSX_HOST_WALK") != nullptr;
+    if (host_walk) {
         if (blob_bytes) HIPCHK(hipMemcpyAsync(st.d_blob, seqs, blob_bytes, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));   // inputs are borrowed for the call only
+        if ((rc = stage_host_walk(h, st, in, summary, pb))) return rc;
+    } else {
+        // ---- uploads that do not wait for the parse: the read blob and the PAF text ------------
+        if (blob_bytes) HIPCHK(hipMemcpyAsync(st.d_blob, seqs, blob_bytes, hipMemcpyHostToDevice, h->stream));
+        if ((rc = grow_pin(h, &h->h_paf_pin, &h->paf_pin_cap, in.paf_len + 64))) return rc;
+        if ((rc = grow_dev(h, &h->d_paf, &h->d_paf_cap, in.paf_len + 64, 4096))) return rc;
+        {
+            const int nt = in.paf_len > (size_t(1) << 20) ? std::min(parse_threads(), 8) : 1;
+            run_threads(nt, [&](int t) {
+                const size_t lo = in.paf_len * size_t(t) / size_t(nt), hi = in.paf_len * size_t(t + 1) / size_t(nt);
+                memcpy(h->h_paf_pin + lo, in.paf + lo, hi - lo);
+            });
+        }
+        if (in.paf_len) HIPCHK(hipMemcpyAsync(h->d_paf, h->h_paf_pin, in.paf_len, hipMemcpyHostToDevice, h->stream));
+        // ---- host: lines -> records -> best mapping per read -> plans + (tile, barcode) groups ----
+        if (h->read_dirty.size() != size_t(n_reads)) {       // blob handed in by the caller: look at it here
+            h->read_dirty.assign(size_t(n_reads), 0);
+            const int nt = blob_bytes > (size_t(1) << 20) ? parse_threads() : 1;
+            run_threads(nt, [&](int t) {
+                for (int32_t i = int32_t(int64_t(n_reads) * t / nt), e = int32_t(int64_t(n_reads) * (t + 1) / nt); i < e; ++i)
+                    h->read_dirty[size_t(i)] = bytes_all_acgt(seqs + seq_off[i], size_t(seq_off[i + 1] - seq_off[i])) ? 0 : 1;
+            });
+        }
+        in.device_walk = true;
+        in.read_dirty = h->read_dirty.data();
+        in.n_tiles = h->n_tiles;
+        std::string err;
+        rc = parse_paf_batch(in, h->contigs, h->index, summary, pb, err);
+        h->read_dirty.clear();
+        if (rc) return fail(h, rc, err);
+        const auto t1 = std::chrono::steady_clock::now();
+        const uint32_t n_plans = uint32_t(pb.plans.size()), n_groups = uint32_t(pb.tiles.size());
+        uint32_t totals[4] = {0, 0, 0, 0};
+        std::vector<uint32_t> walk_err;
+        if (n_plans) {
+            if ((rc = grow_dev(h, &st.d_ops, &st.ops_cap, pb.ops_cap, 1024))) return rc;
+            if ((rc = grow_dev(h, &st.d_segs, &st.segs_cap, pb.segs_cap, 64))) return rc;
+            if ((rc = grow_dev(h, &st.d_tilerefs, &st.tilerefs_cap, size_t(n_groups), 64))) return rc;
+            if ((rc = grow_dev(h, &h->d_plans, &h->d_plans_cap, size_t(n_plans), 64))) return rc;
+            const size_t n_walk = size_t(n_plans) * 3 + 1 + size_t(n_groups) * 2 + 4;
+            if ((rc = grow_dev(h, &h->d_walk, &h->d_walk_cap, n_walk, 64))) return rc;
+            const size_t plan_bytes = size_t(n_plans) * sizeof(MapPlan), group_bytes = size_t(n_groups) * sizeof(TileRef);
+            if ((rc = grow_pin(h, &h->h_plan_pin, &h->plan_pin_cap, plan_bytes + group_bytes + size_t(n_plans) * 4 + 64))) return rc;
+            memcpy(h->h_plan_pin, pb.plans.data(), plan_bytes);
+            memcpy(h->h_plan_pin + plan_bytes, pb.tiles.data(), group_bytes);
+            HIPCHK(hipMemcpyAsync(h->d_plans, h->h_plan_pin, plan_bytes, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(st.d_tilerefs, h->h_plan_pin + plan_bytes, group_bytes, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemsetAsync(h->d_walk, 0, n_walk * sizeof(uint32_t), h->stream));
+            WalkParams W;
+            W.plans = h->d_plans; W.n_plans = n_plans; W.paf = h->d_paf; W.blob = st.d_blob;
+            W.n_runs = h->d_walk; W.walk_err = W.n_runs + n_plans; W.ops_off = W.walk_err + n_plans;
+            W.group_count = W.ops_off + n_plans + 1; W.group_cursor = W.group_count + n_groups;
+            W.totals = W.group_cursor + n_groups;
+            W.ops = st.d_ops; W.groups = st.d_tilerefs; W.n_groups = n_groups; W.segs = st.d_segs;
+            const dim3 grid((n_plans + 3) / 4), block(256);
+            hipLaunchKernelGGL(cigar_walk_kernel<false>, grid, block, 0, h->stream, W);
+            hipLaunchKernelGGL(walk_scan_kernel, dim3(1), dim3(1024), 0, h->stream, W);
+            hipLaunchKernelGGL(cigar_walk_kernel<true>, grid, block, 0, h->stream, W);
+            HIPCHK(hipGetLastError());
+            uint32_t *back = reinterpret_cast<uint32_t *>(h->h_plan_pin + plan_bytes + group_bytes);
+            HIPCHK(hipMemcpyAsync(back, W.totals, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            memcpy(totals, back, sizeof(totals));
+            if (totals[2]) {
+                walk_err.resize(n_plans);
+                HIPCHK(hipMemcpy(walk_err.data(), W.walk_err, size_t(n_plans) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            }
+        } else {
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+        // ---- failures: the first ValueError / KeyError class one in record order; the IndexError
+        // class (raised later in the reference, inside _effect_increments) only if nothing else failed
+        for (uint32_t i = 0; i < uint32_t(walk_err.size()); ++i)
+            if (walk_err[i] & kWalkParseMask)
+                return fail(h, BOSSX_E_PARSE, "read '" + pb.plan_names[i] + "': " + walk_message(walk_err[i] & kWalkParseMask));
+        if (pb.pre_code) return fail(h, pb.pre_code, pb.pre_msg);
+        {
+            int64_t best_gi = pb.pre_range_gi;
+            std::string msg = pb.pre_range_msg;
+            for (uint32_t i = 0; i < uint32_t(walk_err.size()); ++i)
+                if (walk_err[i] && (best_gi < 0 || pb.plan_gi[i] < best_gi)) {
+                    best_gi = pb.plan_gi[i];
+                    msg = "read '" + pb.plan_names[i] + "': " + walk_message(walk_err[i]);
+                    break;
+                }
+            if (best_gi >= 0) return fail(h, BOSSX_E_RANGE, msg);
+        }
+        pb.n_ops = totals[0];
+        if (getenv("BOSSX_CHECK_DEVICE_WALK") && (rc = check_device_walk(h, st, in, pb, totals[1]))) return rc;
+        if (timing) {
+            const auto t2 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[bossx] stage_batch: host parse %.2f ms, device walk + uploads %.2f ms (%u mappings, %u runs, %u segments, %u groups)\n",
+                    std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(),
+                    n_plans, totals[0], totals[1], n_groups);
+        }
+        pb.plans.clear(); pb.plans.shrink_to_fit();
+        pb.plan_names.clear(); pb.plan_gi.clear();
     }
-    if (timing) {
-        const auto t2 = std::chrono::steady_clock::now();
-        fprintf(stderr, "[bossx] stage_batch: parse %.2f ms, alloc+upload %.2f ms (%.1f MB)\n",
-                std::chrono::duration<double, std::milli>(t1 - t0).count(),
-                std::chrono::duration<double, std::milli>(t2 - t1).count(),
-                double(pb.n_ops * sizeof(EmitOp) + blob_bytes + pb.segs.size() * sizeof(TileSeg)) / 1e6);
-    }
+    if (n_rec) *n_rec = pb.n_rec;
+    if (aligned_bases) *aligned_bases = int64_t(pb.total_emit);
     st.pb = std::move(pb);
     st.valid = true;
     return BOSSX_OK;
+}
+
+}  // namespace
+
+int bossx_stage_batch(bossx_engine *h, const char *paf, size_t paf_len, const char *names,
+                      const int64_t *name_off, const char *seqs, const int64_t *seq_off,
+                      const int32_t *barcodes, int32_t n_reads, int32_t min_len,
+                      bossx_batch_summary *summary, int32_t *n_rec, int64_t *aligned_bases) {
+    if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "stage_batch before finalize");
+    if (n_reads < 0 || (n_reads > 0 && (!names || !name_off || !seqs || !seq_off))) return fail(h, BOSSX_E_INVALID, "bad batch arrays");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    h->read_dirty.clear();
+    return stage_core(h, paf, paf_len, names, name_off, seqs, seq_off, barcodes, n_reads, min_len, summary, n_rec, aligned_bases);
 }
 
 int bossx_stage_batch_ptrs(bossx_engine *h, const char *paf, size_t paf_len, const char *const *name_ptrs,
@@ -646,26 +853,26 @@ int bossx_stage_batch_ptrs(bossx_engine *h, const char *paf, size_t paf_len, con
     }
     char *blob = static_cast<char *>(h->h_blob_pin);
     const auto tg0 = std::chrono::steady_clock::now();
+    h->read_dirty.assign(size_t(n_reads), 0);
     {
-        // parallel gather, ranges balanced by bytes
+        // parallel gather, ranges balanced by bytes; each read is looked at once for bytes other
+        // than A/C/G/T (only such reads get the per-run base check of the walk)
         const int nt = (blob_bytes > (size_t(1) << 20)) ? parse_threads() : 1;
-        auto gather = [&](int t) {
+        run_threads(nt, [&](int t) {
             const size_t lo_b = blob_bytes * size_t(t) / size_t(nt), hi_b = blob_bytes * size_t(t + 1) / size_t(nt);
             const int64_t *b = std::lower_bound(seq_off.data(), seq_off.data() + n_reads, int64_t(lo_b));
             const int64_t *e = std::lower_bound(seq_off.data(), seq_off.data() + n_reads, int64_t(hi_b));
-            for (int32_t i = int32_t(b - seq_off.data()), ie = int32_t(e - seq_off.data()); i < ie; ++i)
+            for (int32_t i = int32_t(b - seq_off.data()), ie = int32_t(e - seq_off.data()); i < ie; ++i) {
                 memcpy(blob + seq_off[size_t(i)], seq_ptrs[i], size_t(seq_lens[i]));
-        };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nt; ++t) pool.emplace_back(gather, t);
-        gather(0);
-        for (auto &th : pool) th.join();
+                h->read_dirty[size_t(i)] = bytes_all_acgt(blob + seq_off[size_t(i)], size_t(seq_lens[i])) ? 0 : 1;
+            }
+        });
     }
     if (getenv("BOSSX_STAGE_TIMING"))
         fprintf(stderr, "[bossx] stage_batch: gather %.2f ms\n",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg0).count());
-    return bossx_stage_batch(h, paf, paf_len, names.data(), name_off.data(), blob, seq_off.data(), barcodes, n_reads,
-                             min_len, summary, n_rec, aligned_bases);
+    return stage_core(h, paf, paf_len, names.data(), name_off.data(), blob, seq_off.data(), barcodes, n_reads,
+                      min_len, summary, n_rec, aligned_bases);
 }
 
 int bossx_paf_summary(bossx_engine *h, const char *paf, size_t paf_len, const char *const *name_ptrs,

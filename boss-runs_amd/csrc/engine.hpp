@@ -65,6 +65,41 @@ struct TileRef {
     uint32_t bc;              // barcode index of every segment of the group
 };
 
+// Device-side CIGAR walk (front_end.hip.inc): what the device needs to know about one chosen
+// mapping.  The host resolves names, picks the best mapping and lays out the emit order; the
+// CIGAR text itself is tokenised and walked on the GPU.
+struct alignas(16) MapPlan {
+    uint32_t cg_off, cg_len;   // the cg:Z: value inside the uploaded PAF text
+    uint32_t emit0;            // batch-wide emit index of the mapping's first emitted base
+    uint32_t span;             // |tend - tstart| = emitted bases the CIGAR must produce
+    uint64_t site0;            // padded global site of the first emitted base
+    uint32_t q0;               // blob index of the first query base the walk reads
+    uint32_t q_need;           // qend - qstart = query bases the CIGAR must consume
+    uint32_t seq_b, seq_len;   // the read's bytes in the blob
+    uint32_t room;             // contig length - tlo: emitting past it is an IndexError
+    uint32_t ops_cap;          // upper bound of its emit runs (cg_len / 2 + 1)
+    uint32_t flags;            // bits 0-7 barcode, bit 8 reverse strand, bit 9 read holds a byte other than ACGT
+    uint32_t seg_cap;          // upper bound of its tile segments
+    int32_t q_rel;             // index of q0 inside the read (for the bounds checks; may be out of range)
+    uint32_t pad;
+};
+static_assert(sizeof(MapPlan) == 64, "MapPlan is uploaded as is");
+constexpr uint32_t kPlanRev = 1u << 8;
+constexpr uint32_t kPlanCheckBases = 1u << 9;
+
+// Outcome of the device walk per mapping (read back by the host before anything is ingested).
+enum : uint32_t {
+    kWalkOk = 0,
+    kWalkBadCigar = 1,        // malformed CIGAR (no digits before an operation / trailing digits)   [bit flags]
+    kWalkBadOp = 2,           // operation letter outside MIDNSHP=XB
+    kWalkOutsideRead = 4,     // an aligned run reads outside the read
+    kWalkQueryMismatch = 8,   // consumed query bases != qend - qstart
+    kWalkSpanMismatch = 16,   // emitted reference bases != tend - tstart
+    kWalkParseMask = 0xff,
+    kWalkRangeEnd = 1u << 8,  // IndexError class: emits past the end of the contig
+    kWalkRangeBase = 1u << 9  // IndexError class: base other than A/C/G/T in an aligned run
+};
+
 // The emit runs are written by the parser's threads into the caller's buffer (ParseInput::
 // ops_buf) as one dense chunk per thread; on the device the chunks are laid back to back.
 struct OpsChunk {
@@ -82,6 +117,14 @@ struct ParsedBatch {
     uint64_t total_emit = 0;
     std::vector<uint64_t> emitted_per_contig;   // indexed by contig add order
     int32_t n_rec = 0;
+    // device walk: the host stops after the plan pre-pass; `tiles` holds the (tile, barcode) groups
+    // with empty segment ranges, the emit runs and segments are produced on the device
+    std::vector<MapPlan> plans;
+    std::vector<std::string> plan_names;   // read name per plan (error messages)
+    std::vector<int64_t> plan_gi;          // record-order index per plan (error precedence)
+    int pre_code = 0; std::string pre_msg; int64_t pre_gi = -1;      // first KeyError / ValueError class failure of the pre-pass
+    int64_t pre_range_gi = -1; std::string pre_range_msg;            // first IndexError class failure of the pre-pass
+    size_t ops_cap = 0, segs_cap = 0;      // capacities the device buffers need
 };
 
 struct ParseInput {
@@ -97,6 +140,9 @@ struct ParseInput {
     EmitOp *ops_buf = nullptr;   // storage for the emit runs: ops_capacity_for(paf_len) entries
     size_t ops_cap = 0;
     int32_t n_threads = 0;       // 0: parse_threads()
+    bool device_walk = false;    // fill ParsedBatch::plans / groups only; the CIGAR walk runs on the GPU
+    const uint8_t *read_dirty = nullptr;   // per read: 1 if it holds a byte other than A/C/G/T (null: unknown, assume 1)
+    int64_t n_tiles = 0, paf_base = 0;     // device walk: tile count of the engine (group marking)
 };
 
 size_t ops_capacity_for(size_t paf_len);

@@ -164,6 +164,7 @@ void parse_lines(const char *p, const char *end, int64_t min_len, LineOut &lo) {
 // One chosen mapping, resolved against the batch and the contig table (sequential pre-pass).
 struct Plan {
     const Rec *rec;
+    int64_t gi;              // index of the chosen mapping in record (first appearance) order
     int32_t read, cidx, bc;
     uint64_t emit0;          // index of its first emitted base in the batch-wide emit order
     size_t ops_at;           // where its emit runs start in the caller's buffer (upper-bound spacing)
@@ -409,7 +410,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             pre_fail(BOSSX_E_PARSE, "read '" + r.qname + "': mapping without cg tag");   // assert rec.cigar is not None
             break;
         }
-        Plan pl{&r, read, cidx, 0, cur_emit, ops_at};
+        Plan pl{&r, int64_t(gi), read, cidx, 0, cur_emit, ops_at};
         if (cidx < 0 || contigs[size_t(cidx)].rejected || contigs[size_t(cidx)].remote) {
             pl.cidx = -1;               // core.py:83-86: only (local) contigs_filt receive coverage
         } else {
@@ -426,6 +427,99 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
     }
 
     PT(T2);
+    if (in.device_walk && !in.summary_only) {
+        // The CIGAR walk runs on the GPU (front_end.hip.inc): hand over one MapPlan per mapping that
+        // lands on a local contig, the (tile, barcode) groups its emitted stretch touches, and the
+        // buffer sizes the device needs.  Errors of the pre-pass are reported by the caller after the
+        // device walk, so that an earlier record's CIGAR error still wins (record order).
+        static thread_local std::vector<uint64_t> marks;
+        const size_t n_keys = size_t(in.n_tiles) * size_t(in.nbarcodes);
+        marks.assign((n_keys + 63) / 64, 0);
+        out.plans.reserve(plans.size());
+        out.plan_names.reserve(plans.size());
+        size_t seg_cap = 0;
+        for (const Plan &pl : plans) {
+            if (pl.cidx < 0) continue;
+            const Rec &r = *pl.rec;
+            const ContigInfo &c = contigs[size_t(pl.cidx)];
+            const int64_t seq_b = in.seq_off[pl.read], seq_len = in.seq_off[pl.read + 1] - seq_b;
+            const int64_t tlo = r.tstart < r.tend ? r.tstart : r.tend;
+            const int64_t thi = r.tstart < r.tend ? r.tend : r.tstart;
+            const int64_t q = r.rev ? (seq_len - 1 - (r.qlen - r.qend)) : r.qstart;
+            const int64_t q_need = r.qend - r.qstart;
+            if (tlo < 0 || q_need < 0 || q_need > int64_t(UINT32_MAX) || r.cg_len > size_t(UINT32_MAX) ||
+                q < INT32_MIN || q > INT32_MAX) {
+                // malformed PAF columns (the reference fails on them as well); records after it are not walked
+                if (!pre_err.code || pl.gi < pre_err.group) {
+                    pre_err.group = pl.gi; pre_err.code = BOSSX_E_PARSE;
+                    pre_err.msg = "read '" + r.qname + "': inconsistent PAF coordinates";
+                }
+                break;
+            }
+            MapPlan mp{};
+            mp.cg_off = uint32_t(size_t(r.cg - in.paf) + size_t(in.paf_base));
+            mp.cg_len = uint32_t(r.cg_len);
+            mp.emit0 = uint32_t(pl.emit0);
+            mp.span = uint32_t(thi - tlo);
+            mp.site0 = uint64_t(c.site_off + tlo);
+            mp.q_rel = int32_t(q);
+            mp.q0 = uint32_t(seq_b + (q >= 0 && q < seq_len ? q : 0));
+            mp.q_need = uint32_t(q_need);
+            mp.seq_b = uint32_t(seq_b);
+            mp.seq_len = uint32_t(seq_len);
+            const int64_t room = c.length - tlo;
+            mp.room = uint32_t(room < 0 ? 0 : (room > int64_t(UINT32_MAX) ? int64_t(UINT32_MAX) : room));
+            mp.ops_cap = uint32_t(r.cg_len / 2 + 1);
+            const bool dirty = in.read_dirty ? in.read_dirty[pl.read] != 0 : true;
+            mp.flags = uint32_t(pl.bc & 0xff) | (r.rev ? kPlanRev : 0u) | (dirty ? kPlanCheckBases : 0u);
+            // groups: every sweep tile the stretch [site0, site0 + span) touches, for this barcode.
+            // A stretch that runs past its contig (an IndexError reported by the device walk) is
+            // clipped here so that no key outside the table is marked.
+            int64_t s_end = c.site_off + thi;
+            const int64_t c_end = c.site_off + c.n_tiles * kTileSites;
+            if (s_end > c_end) s_end = c_end;
+            uint32_t ntile = 0;
+            for (int64_t t = int64_t(mp.site0) / kTileSites; t * kTileSites < s_end; ++t) {
+                const size_t key = size_t(t) * size_t(in.nbarcodes) + size_t(pl.bc);
+                if (key < n_keys) marks[key >> 6] |= 1ull << (key & 63);
+                ++ntile;
+            }
+            mp.seg_cap = mp.span / kSegMax + ntile + 1;
+            seg_cap += mp.seg_cap;
+            out.emitted_per_contig[size_t(pl.cidx)] += uint64_t(thi - tlo);
+            out.plans.push_back(mp);
+            out.plan_names.push_back(r.qname);
+            out.plan_gi.push_back(pl.gi);
+        }
+        if (cur_emit >= (1ull << 32) - kEmitTile) {
+            err = "batch too large: more than 2^32 aligned bases";
+            return BOSSX_E_RANGE;
+        }
+        out.n_touched_tiles = 0;
+        uint32_t last_tile = UINT32_MAX;
+        for (size_t w = 0; w < marks.size(); ++w) {
+            uint64_t bits = marks[w];
+            while (bits) {
+                const size_t key = (w << 6) + size_t(__builtin_ctzll(bits));
+                bits &= bits - 1;
+                const uint32_t t = uint32_t(key / size_t(in.nbarcodes)), bc = uint32_t(key % size_t(in.nbarcodes));
+                if (t != last_tile) { ++out.n_touched_tiles; last_tile = t; }
+                out.tiles.push_back(TileRef{t, 0u, 0u, bc});
+            }
+        }
+        out.ops_cap = ops_at + 1;
+        out.segs_cap = seg_cap + 1;
+        out.total_emit = cur_emit;
+        out.n_rec = n_rec;
+        // failures of the pre-pass travel with the batch: the caller merges them with the device
+        // walk's per-mapping outcome (first ValueError / KeyError class failure in record order; the
+        // IndexError class only if nothing else failed)
+        out.pre_code = pre_err.code; out.pre_msg = pre_err.msg; out.pre_gi = pre_err.code ? pre_err.group : -1;
+        out.pre_range_gi = pre_range.code ? pre_range.group : -1; out.pre_range_msg = pre_range.msg;
+        PT(T3); PT(T4);
+        PTREPORT();
+        return BOSSX_OK;
+    }
     // ---- pass 2b (threads over contiguous record ranges): CIGAR walk -> emit runs + segments ----
     std::vector<WalkOut> wos;
     if (!in.summary_only && !plans.empty()) {
@@ -621,6 +715,33 @@ extern "C" int bossx_host_parse(const char *const *contig_names, const int64_t *
     for (size_t i = 1; i < pb.tiles.size(); ++i) {
         const TileRef &a = pb.tiles[i - 1], &b = pb.tiles[i];
         if (b.tile < a.tile || (b.tile == a.tile && b.bc <= a.bc)) return fail(BOSSX_E_INVALID, "tile groups out of order");
+    }
+    // the host half of the device walk (plans + groups + capacities) must describe the same batch
+    {
+        ParseInput in2 = in;
+        in2.device_walk = true; in2.ops_buf = nullptr; in2.ops_cap = 0;
+        int64_t n_tiles = 0;
+        for (const ContigInfo &c : contigs) if (!c.rejected && !c.remote) n_tiles += c.n_tiles;
+        in2.n_tiles = n_tiles;
+        ParsedBatch pd;
+        std::string err2;
+        rc = parse_paf_batch(in2, contigs, index, nullptr, pd, err2);
+        if (rc || pd.pre_code || pd.pre_range_gi >= 0) return fail(BOSSX_E_INVALID, "device-walk planning fails where the host walk passed: " + err2 + pd.pre_msg);
+        if (pd.total_emit != pb.total_emit || pd.n_rec != pb.n_rec || pd.emitted_per_contig != pb.emitted_per_contig)
+            return fail(BOSSX_E_INVALID, "device-walk planning: totals differ");
+        if (pd.ops_cap < pb.n_ops || pd.segs_cap < pb.segs.size()) return fail(BOSSX_E_INVALID, "device-walk planning: capacity too small");
+        if (pd.tiles.size() != pb.tiles.size() || pd.n_touched_tiles != pb.n_touched_tiles)
+            return fail(BOSSX_E_INVALID, "device-walk planning: group count differs");
+        for (size_t i = 0; i < pd.tiles.size(); ++i)
+            if (pd.tiles[i].tile != pb.tiles[i].tile || pd.tiles[i].bc != pb.tiles[i].bc)
+                return fail(BOSSX_E_INVALID, "device-walk planning: groups differ");
+        uint64_t span_sum = 0;
+        for (const MapPlan &mp : pd.plans) {
+            if (mp.emit0 != uint32_t(span_sum)) return fail(BOSSX_E_INVALID, "device-walk planning: emit order broken");
+            span_sum += mp.span;
+            if (size_t(mp.cg_off) + mp.cg_len > paf_len) return fail(BOSSX_E_INVALID, "device-walk planning: CIGAR outside the text");
+        }
+        if (span_sum != pb.total_emit) return fail(BOSSX_E_INVALID, "device-walk planning: spans do not add up");
     }
     if (!out_contig) return BOSSX_OK;
     if (out_cap < int64_t(pb.total_emit)) return fail(BOSSX_E_INVALID, "output arrays too small");

@@ -729,3 +729,77 @@ def test_reference_loop_through_the_boundary(in_tmp):
     assert runs.threshold == o.threshold
     for n, oc in o.contigs.items():
         assert np.array_equal(runs.contigs[n].strat, oc.strat), n
+
+
+def test_device_cigar_walk_equals_host_walk(in_tmp, monkeypatch):
+    """The CIGAR text is tokenised and walked on the GPU (front_end.hip.inc).  With
+    BOSSX_CHECK_DEVICE_WALK=1 every staged batch is also walked on the host (paf_host.cpp, the
+    walk the CPU tier holds to the oracle) and the two must agree: emit runs exactly, segments
+    group by group.  Long reads (thousands of runs, numbers split across 64-byte steps), both
+    strands, 8 barcodes, zero-length runs, every operation letter; then the failure classes."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.runs import BossRuns
+    monkeypatch.setenv("BOSSX_CHECK_DEVICE_WALK", "1")
+    nb = 8
+    contigs = synth.make_reference([400_000, 150_000, 101_000], seed=23, names=["w1", "w2", "w3"])
+    strs = [(n, synth.codes_to_str(c)) for n, c in contigs]
+    args = BossConfig()
+    args.general.name = "walk"
+    args.general.barcodes = ["barcode%02d" % (i + 1) for i in range(nb)]
+    runs = BossRuns(args)
+    runs.init(contigs=strs)
+    eng = runs.engine
+    for b, (mean, mx) in enumerate([(3000.0, 20000), (30000.0, 200000), (900.0, 2000)]):
+        batch = synth.make_batch(contigs, 1200, seed=600 + b, mean_len=mean, max_len=mx, nbarcodes=nb)
+        lines = batch["paf"].split("\n")
+        for i in range(0, len(lines), 5):        # legal no-ops and the rarer letters (all treated like M)
+            lines[i] = lines[i].replace("cg:Z:", "cg:Z:0M0D0I", 1)
+        for i in range(1, len(lines), 7):
+            f = lines[i].split("\t")
+            k = [j for j, x in enumerate(f) if x.startswith("cg:Z:")][0]
+            m = __import__("re").match(r"cg:Z:(\d+)M(.*)", f[k])
+            if m and int(m.group(1)) > 6:
+                n0 = int(m.group(1))
+                f[k] = "cg:Z:1=1X1N1S1H1P%dB%s" % (n0 - 6, m.group(2))
+                lines[i] = "\t".join(f)
+        summ = eng.stage_batch("\n".join(lines), batch["seqs"], barcodes=batch["barcodes"])
+        assert summ["aligned"] > 0
+    # ---- failure classes through the device walk -------------------------------------------
+    monkeypatch.delenv("BOSSX_CHECK_DEVICE_WALK")
+    batch = synth.make_batch(contigs, 300, seed=77, mean_len=3000.0, nbarcodes=nb, extras=False)
+    lines = batch["paf"].split("\n")
+    seqs = batch["seqs"]
+
+    def with_cigar(i, fn):
+        f = lines[i].split("\t")
+        k = [j for j, x in enumerate(f) if x.startswith("cg:Z:")][0]
+        f[k] = "cg:Z:" + fn(f[k][5:])
+        out = list(lines)
+        out[i] = "\t".join(f)
+        return "\n".join(out)
+    stage = lambda paf, s=seqs: eng.stage_batch(paf, s, barcodes=batch["barcodes"])
+    with pytest.raises(ValueError, match="CIGAR"):
+        stage(with_cigar(40, lambda c: "7M" + c))                 # spans / consumes too much
+    with pytest.raises(ValueError, match="malformed CIGAR"):
+        stage(with_cigar(40, lambda c: c + "12"))                 # trailing digits
+    with pytest.raises(ValueError, match="malformed CIGAR"):
+        stage(with_cigar(40, lambda c: "M" + c))                  # operation without a length
+    with pytest.raises(ValueError, match="unknown CIGAR op"):
+        stage(with_cigar(40, lambda c: c.replace("M", "Z", 1)))
+    with pytest.raises(ValueError, match="outside the read"):
+        f = lines[41].split("\t")
+        rid = f[0]
+        stage(batch["paf"], {**seqs, rid: seqs[rid][: int(f[3]) - 50]})   # read shorter than qend
+    f = lines[50].split("\t")
+    rid, qs, qe = f[0], int(f[2]), int(f[3])
+    bad = dict(seqs)
+    bad[rid] = seqs[rid][: (qs + qe) // 2] + "N" + seqs[rid][(qs + qe) // 2 + 1:]
+    with pytest.raises(IndexError, match="A/C/G/T"):
+        stage(batch["paf"], bad)
+    with pytest.raises(ValueError, match="CIGAR"):                    # a later ValueError wins over the IndexError
+        stage(with_cigar(200, lambda c: "7M" + c), bad)
+    with pytest.raises(KeyError):                                     # ... and so does a later KeyError
+        stage(batch["paf"], {k: v for k, v in bad.items() if k != lines[250].split("\t")[0]})
+    # a good batch still goes through afterwards
+    assert stage(batch["paf"])["aligned"] == batch["aligned"]
