@@ -227,6 +227,8 @@ SweepParams sweep_params(bossx_engine *h) {
     P.tile_done = h->d_tile_done; P.epoch = h->epoch;
     P.publish = h->sweep_published ? 1 : 0;
     P.dense = 0; P.ingest_only = 0; P.ingest_first = 0;
+    P.lut_hot = getenv("BOSSX_LUT_HOT") ? 1 : 0;
+    P.lut_hot = getenv("BOSSX_LUT_HOT") ? 1 : 0;
     P.order = h->d_tile_order;
     return P;
 }
@@ -484,7 +486,7 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
         h->result_bytes = bytes;
     }
     if ((rc = dev_alloc(h, &h->d_limbs, size_t(BOSSX_HIST_BINS + 1) * 5, true))) return rc;
-    if ((rc = dev_alloc(h, &h->d_lut_score, size_t(BOSSX_NCOMP) * 4, true))) return rc;
+    if ((rc = dev_alloc(h, &h->d_lut_score, size_t(BOSSX_NCOMP) * 4 + 4, true))) return rc;   // + score0, tiny, 0.0 (site_sweep_kernel)
     if ((rc = dev_alloc(h, &h->d_lut_ent, size_t(BOSSX_NCOMP) * 4, true))) return rc;
     if ((rc = upload_vec(h, &h->d_tile_off, tile_off))) return rc;
     if ((rc = upload_vec(h, &h->d_site_off, site_off))) return rc;
@@ -546,6 +548,9 @@ int bossx_set_lut(bossx_engine *h, const double *score, const double *entropy, i
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipMemcpy(h->d_lut_score, score, size_t(n) * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_lut_ent, entropy, size_t(n) * sizeof(double), hipMemcpyHostToDevice));
+    // the three values of the scores array that are not table entries (site_sweep_kernel selects an index, not a value)
+    const double extra[4] = {h->score0, std::numeric_limits<double>::min(), 0.0, 0.0};
+    HIPCHK(hipMemcpy(h->d_lut_score + size_t(n), extra, sizeof(extra), hipMemcpyHostToDevice));
     h->lut_set = true;
     return BOSSX_OK;
 }
@@ -929,6 +934,12 @@ int bossx_ingest_paf(bossx_engine *h, const char *paf, size_t paf_len, const cha
 }
 
 namespace {
+// the entropy-tracking variant is a separate instantiation: the default (no entropy array) carries no code for it
+#define LAUNCH_SWEEP(ING, grid, block, lds, stream, P)                                                    \
+    do {                                                                                                  \
+        if (h->d_entropy) hipLaunchKernelGGL((site_sweep_kernel<ING, true>), grid, block, lds, stream, P); \
+        else hipLaunchKernelGGL((site_sweep_kernel<ING, false>), grid, block, lds, stream, P);            \
+    } while (0)
 int launch_sweep(bossx_engine *h) {
     // dropout thresholds of this update: mean depth per contig (reference.py:157-158, 174-176)
     std::vector<int32_t> &thr = h->drop_thr_host;    // member: must outlive the async copy
@@ -977,24 +988,24 @@ int launch_sweep(bossx_engine *h) {
     const bool split = n_groups > 0 && (split_env ? atoi(split_env) != 0 : h->nb >= 3);
     if (split) {
         P.ingest_only = 1;
-        hipLaunchKernelGGL(site_sweep_kernel<true>, dim3(uint32_t(n_groups)), dim3(256), 0, h->stream, P);
+        LAUNCH_SWEEP(true, dim3(uint32_t(n_groups)), dim3(256), 0, h->stream, P);
         P.ingest_only = 0; P.tiles = nullptr; P.n_groups = 0; P.use_touched = 1;
-        hipLaunchKernelGGL(site_sweep_kernel<false>, dim3(uint32_t(h->n_tiles)), dim3(256), 0, h->stream, P);
+        LAUNCH_SWEEP(false, dim3(uint32_t(h->n_tiles)), dim3(256), 0, h->stream, P);
     } else if (n_touched * 2 >= size_t(h->n_tiles) && n_touched > 0) {
         // most tiles receive bases: one launch over all tiles, each block looks its tile up
         P.dense = 1;
-        hipLaunchKernelGGL(site_sweep_kernel<true>, dim3(uint32_t(h->n_tiles)), dim3(256), 0, h->stream, P);
+        LAUNCH_SWEEP(true, dim3(uint32_t(h->n_tiles)), dim3(256), 0, h->stream, P);
     } else if (P.publish && n_groups) {
         // a chain is waiting for tiles in walk order: the touched ones are scattered along it, so
         // they go first (DONE marks keep the plain launch off them), then everything else in order
         P.ingest_first = 1;
-        hipLaunchKernelGGL(site_sweep_kernel<true>, dim3(uint32_t(n_groups)), dim3(256), 0, h->stream, P);
-        hipLaunchKernelGGL(site_sweep_kernel<false>, dim3(uint32_t(h->n_tiles)), dim3(256), 0, h->stream, P);
+        LAUNCH_SWEEP(true, dim3(uint32_t(n_groups)), dim3(256), 0, h->stream, P);
+        LAUNCH_SWEEP(false, dim3(uint32_t(h->n_tiles)), dim3(256), 0, h->stream, P);
     } else {
         if (h->n_tiles > 0)
-            hipLaunchKernelGGL(site_sweep_kernel<false>, dim3(uint32_t(h->n_tiles)), dim3(256), 0, h->stream, P);
+            LAUNCH_SWEEP(false, dim3(uint32_t(h->n_tiles)), dim3(256), 0, h->stream, P);
         if (n_groups)    // one block per (tile, barcode) group; the first group of a tile does the tile
-            hipLaunchKernelGGL(site_sweep_kernel<true>, dim3(uint32_t(n_groups)), dim3(256), 0, h->stream, P);
+            LAUNCH_SWEEP(true, dim3(uint32_t(n_groups)), dim3(256), 0, h->stream, P);
     }
     // algorithmic bytes: per site*barcode 10 B counters + 1 B state read; per 100-site bin 8 B
     // downsampled score write; per ingested base 1 B read base + 2 B counter write-back, per
@@ -1044,8 +1055,10 @@ int bossx_get_bucket_sums(bossx_engine *h, int32_t contig, uint64_t *dst) {
     HIPCHK(hipMemcpyAsync(&flag, h->d_err, sizeof(flag), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (flag) {
+        const int32_t flag_bits = flag;
         HIPCHK(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
-        return fail(h, BOSSX_E_RANGE, "a read contains a base other than A/C/G/T inside an aligned segment");
+        return fail(h, BOSSX_E_RANGE, (flag_bits & 8) ? "a coverage counter reached 8192: beyond the depth this engine scores exactly (the reference's uint16 counters wrap at 65536)"
+                                                      : "a read contains a base other than A/C/G/T inside an aligned segment");
     }
     return BOSSX_OK;
 }
@@ -1400,8 +1413,10 @@ int bossx_dist_finish(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, b
     if (strat_all && (rc = copy_masks(h, strat_all, false))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     if (*herr) {
+        const int32_t flag_bits = *herr;
         HIPCHK(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
-        return fail(h, BOSSX_E_RANGE, "a read contains a base other than A/C/G/T inside an aligned segment");
+        return fail(h, BOSSX_E_RANGE, (flag_bits & 8) ? "a coverage counter reached 8192: beyond the depth this engine scores exactly (the reference's uint16 counters wrap at 65536)"
+                                                      : "a read contains a base other than A/C/G/T inside an aligned segment");
     }
     if (contig_on) {
         for (size_t i = 0; i < h->contigs.size(); ++i) contig_on[i] = 0;
@@ -1598,8 +1613,10 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
     }
     if (hc->any_on) h->host_armed = true;
     if (*herr) {
+        const int32_t flag_bits = *herr;
         HIPCHK(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
-        return fail(h, BOSSX_E_RANGE, "a read contains a base other than A/C/G/T inside an aligned segment");
+        return fail(h, BOSSX_E_RANGE, (flag_bits & 8) ? "a coverage counter reached 8192: beyond the depth this engine scores exactly (the reference's uint16 counters wrap at 65536)"
+                                                      : "a read contains a base other than A/C/G/T inside an aligned segment");
     }
     if (contig_on) {
         for (size_t i = 0; i < h->contigs.size(); ++i) contig_on[i] = 0;
