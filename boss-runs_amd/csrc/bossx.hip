@@ -220,15 +220,13 @@ SweepParams sweep_params(bossx_engine *h) {
         const bossx_engine::Staged &st = h->slots[size_t(h->pending_slot)];
         P.tiles = st.d_tilerefs; P.n_groups = uint32_t(st.pb.tiles.size()); P.segs = st.d_segs; P.ops = st.d_ops; P.blob = st.d_blob;
     }
-    P.ds = h->d_ds; P.bucket_sums = h->d_bucket_sums; P.drop_count = h->d_drop_count;
+    P.ds = h->d_ds; P.bucket_sums = h->d_bucket_sums;
     P.lut_score = h->d_lut_score; P.lut_ent = h->d_lut_ent; P.ct = table_of(h);
     P.Gp = h->Gp; P.B = h->B; P.NBK = h->NBK; P.nb = h->nb;
     P.score0 = h->score0; P.tiny = std::numeric_limits<double>::min();
     P.tile_done = h->d_tile_done; P.epoch = h->epoch;
     P.publish = h->sweep_published ? 1 : 0;
     P.dense = 0; P.ingest_only = 0; P.ingest_first = 0;
-    P.lut_hot = getenv("BOSSX_LUT_HOT") ? 1 : 0;
-    P.lut_hot = getenv("BOSSX_LUT_HOT") ? 1 : 0;
     P.order = h->d_tile_order;
     return P;
 }
