@@ -38,6 +38,7 @@ struct bossx_engine {
     bool sweep_published = false;      // the last sweep launch publishes its tiles (tile_done flags, agent-scope bin stores)
     bool sweep_in_flight = false;      // update_begin enqueued a sweep that no update has consumed yet
     bool chain_on_stream2 = false;     // update_benefit put the chain on stream2 (ev_chain pending)
+    ChainParams last_chain{}; size_t last_chain_lds = 0;   // what that launch ran with (settle_chain reruns it serially after a time-out)
     bool finalized = false;
     bool lut_set = false;
     bool all_local = true;
@@ -1032,11 +1033,13 @@ int launch_sweep(bossx_engine *h) {
 }
 }  // namespace
 
+namespace { int settle_chain(bossx_engine *h); }
+
 int bossx_sweep(bossx_engine *h) {
     if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "sweep before finalize");
     if (!h->lut_set) return fail(h, BOSSX_E_INVALID, "sweep before set_lut");
     HIPCHK(hipSetDevice(h->cfg.device));
-    { int jrc = join_chain(h); if (jrc) return jrc; }
+    { int jrc = settle_chain(h); if (jrc) return jrc; }
     return launch_sweep(h);
 }
 
@@ -1145,10 +1148,35 @@ void launch_chain(bossx_engine *h, const ChainParams &P, size_t lds, hipStream_t
 
 }  // namespace
 
+namespace {
+// For every consumer of the chain's results other than bossx_update (which has its own retry): a
+// chain that ran next to the sweep may have given up waiting for it (kernels serialised by a
+// profiler, or chain blocks starving the sweep) — its benefit array and running maximum are then
+// void.  Wait for it, and if it timed out rerun it on the main stream, after the sweep, and keep
+// the serial schedule from now on.  A no-op (no synchronisation) when no such chain is pending.
+int settle_chain(bossx_engine *h) {
+    if (!h->chain_on_stream2) return BOSSX_OK;
+    HIPCHK(hipStreamSynchronize(h->stream2));
+    h->chain_on_stream2 = false;
+    int32_t err = 0;
+    HIPCHK(hipMemcpy(&err, &h->d_ctrl->err, sizeof(err), hipMemcpyDeviceToHost));
+    if (!(err & 4)) return BOSSX_OK;
+    err &= ~4;
+    HIPCHK(hipMemcpyAsync(&h->d_ctrl->err, &err, sizeof(err), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream));
+    h->overlap_ok = false;
+    ChainParams CP = h->last_chain;
+    CP.tile_done = nullptr;                 // the main stream is behind the sweep: no waiting
+    launch_chain(h, CP, h->last_chain_lds);
+    HIPCHK(hipGetLastError());
+    return BOSSX_OK;
+}
+}  // namespace
+
 int bossx_benefit(bossx_engine *h, const int32_t *windows, const double *mult, double *max_benefit) {
     if (!h || !h->finalized || !windows || !mult) return fail(h, BOSSX_E_INVALID, "bad benefit call");
     HIPCHK(hipSetDevice(h->cfg.device));
-    { int jrc = join_chain(h); if (jrc) return jrc; }
+    { int jrc = settle_chain(h); if (jrc) return jrc; }
     ChainParams P;
     size_t lds = 0;
     int rc = fill_chain_params(h, windows, mult, P, lds);
@@ -1250,7 +1278,7 @@ int bossx_histogram(bossx_engine *h, double normaliser, const bossx_fhat_desc *f
     if (!h || !h->finalized || !fh || !fh->fhat_c || !counts || !fgrid_fx || !ubar0_fx) return fail(h, BOSSX_E_INVALID, "bad histogram call");
     if (!(normaliser > 0)) return fail(h, BOSSX_E_EMPTY, "no non-zero benefit (np.max of an empty array)");
     HIPCHK(hipSetDevice(h->cfg.device));
-    { int jrc = join_chain(h); if (jrc) return jrc; }
+    { int jrc = settle_chain(h); if (jrc) return jrc; }
     int rc = upload_fhat(h, fh);
     if (rc) return rc;
     unsigned long long bits;
@@ -1270,7 +1298,7 @@ int bossx_histogram(bossx_engine *h, double normaliser, const bossx_fhat_desc *f
 int bossx_apply_threshold(bossx_engine *h, double threshold) {
     if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "bad apply_threshold call");
     HIPCHK(hipSetDevice(h->cfg.device));
-    { int jrc = join_chain(h); if (jrc) return jrc; }
+    { int jrc = settle_chain(h); if (jrc) return jrc; }
     HIPCHK(hipMemcpyAsync(&h->d_ctrl->threshold, &threshold, sizeof(double), hipMemcpyHostToDevice, h->stream));
     return launch_mask(h, 0);
 }
@@ -1289,7 +1317,7 @@ int bossx_update_begin(bossx_engine *h, double bucket_threshold) {
     if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "bad update_begin call");
     if (!h->lut_set) return fail(h, BOSSX_E_INVALID, "update before set_lut");
     HIPCHK(hipSetDevice(h->cfg.device));
-    { int jrc = join_chain(h); if (jrc) return jrc; }
+    { int jrc = settle_chain(h); if (jrc) return jrc; }
     int rc = launch_sweep(h);      // records ev_begin between its prep launch and the sweep proper
     if (rc) return rc;
     launch_buckets(h, bucket_threshold);
@@ -1324,7 +1352,7 @@ static void launch_tails(bossx_engine *h) {
 int bossx_dist_hist(bossx_engine *h, const bossx_fhat_desc *fh) {
     if (!h || !h->finalized || !fh || !fh->fhat_c) return fail(h, BOSSX_E_INVALID, "bad dist_hist call");
     HIPCHK(hipSetDevice(h->cfg.device));
-    { int jrc = join_chain(h); if (jrc) return jrc; }
+    { int jrc = settle_chain(h); if (jrc) return jrc; }
     int rc = upload_fhat(h, fh);
     if (rc) return rc;
     if ((rc = launch_hist(h, fh, 1))) return rc;
@@ -1337,7 +1365,7 @@ int bossx_dist_hist(bossx_engine *h, const bossx_fhat_desc *fh) {
 int bossx_dist_pick(bossx_engine *h, double tc) {
     if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "bad dist_pick call");
     HIPCHK(hipSetDevice(h->cfg.device));
-    { int jrc = join_chain(h); if (jrc) return jrc; }
+    { int jrc = settle_chain(h); if (jrc) return jrc; }
     if (h->norm_in_tails) {
         // short form: the halo rows are already exchanged, so nothing separates the threshold choice
         // from the masks — bossx_dist_finish's mask kernel picks it itself (one launch fewer)
@@ -1358,7 +1386,7 @@ int bossx_dist_pick(bossx_engine *h, double tc) {
 int bossx_dist_tails(bossx_engine *h) {
     if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "bad dist_tails call");
     HIPCHK(hipSetDevice(h->cfg.device));
-    { int jrc = join_chain(h); if (jrc) return jrc; }
+    { int jrc = settle_chain(h); if (jrc) return jrc; }
     launch_tails(h);          // the normaliser already sits behind the tails (ctrl.max_bits)
     h->norm_in_tails = true;
     HIPCHK(hipGetLastError());
@@ -1388,7 +1416,7 @@ static int copy_masks(bossx_engine *h, uint8_t *dst, bool bits) {
 int bossx_dist_finish(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, bossx_update_result *res) {
     if (!h || !h->finalized || !res) return fail(h, BOSSX_E_INVALID, "bad dist_finish call");
     HIPCHK(hipSetDevice(h->cfg.device));
-    { int jrc = join_chain(h); if (jrc) return jrc; }
+    { int jrc = settle_chain(h); if (jrc) return jrc; }
     h->sweep_in_flight = false;
     int rc;
     if (h->dist_pick_fused) {
@@ -1471,7 +1499,7 @@ int bossx_arm(bossx_engine *h) {
 int bossx_get_max(bossx_engine *h, double *max_benefit) {
     if (!h || !h->finalized || !max_benefit) return fail(h, BOSSX_E_INVALID, "bad get_max call");
     HIPCHK(hipSetDevice(h->cfg.device));
-    { int jrc = join_chain(h); if (jrc) return jrc; }
+    { int jrc = settle_chain(h); if (jrc) return jrc; }
     unsigned long long bits = 0;
     HIPCHK(hipMemcpyAsync(&bits, &h->d_ctrl->max_bits, sizeof(bits), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1500,6 +1528,7 @@ int bossx_update_benefit(bossx_engine *h, const int32_t *windows, const double *
         launch_chain(h, CP, lds, h->stream2);
         HIPCHK(hipEventRecord(h->ev_chain, h->stream2));
         h->chain_on_stream2 = true;
+        h->last_chain = CP; h->last_chain_lds = lds;
     } else {
         if (!h->max_bits_clear) HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream));
         launch_chain(h, CP, lds);
@@ -1676,7 +1705,7 @@ int bossx_export(bossx_engine *h, int32_t contig, int32_t which, void *dst, size
     int rc = check_contig(h, contig, true);
     if (rc) return rc;
     HIPCHK(hipSetDevice(h->cfg.device));
-    { int jrc = join_chain(h); if (jrc) return jrc; }
+    { int jrc = settle_chain(h); if (jrc) return jrc; }
     if (h->pending_slot >= 0 && (rc = flush_pending(h))) return rc;   // make staged increments visible
     const ContigInfo &c = h->contigs[size_t(contig)];
     const int64_t L = c.length, nb = h->nb, nbin = c.T + 1;

@@ -803,3 +803,57 @@ def test_device_cigar_walk_equals_host_walk(in_tmp, monkeypatch):
         stage(batch["paf"], {k: v for k, v in bad.items() if k != lines[250].split("\t")[0]})
     # a good batch still goes through afterwards
     assert stage(batch["paf"])["aligned"] == batch["aligned"]
+
+
+def test_stagewise_consumers_recover_from_a_timed_out_chain(in_tmp, monkeypatch):
+    """bossx_update_begin + bossx_update_benefit put the chain next to the sweep; if it gives up
+    waiting (BOSSX_OVERLAP_SELFTEST makes it), every stage-wise consumer — bossx_get_max,
+    bossx_histogram, bossx_apply_threshold, bossx_export — must see the serially recomputed chain,
+    not the aborted one.  Reference values: the same update on an engine that never overlaps."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.runs import BossRuns, MULT, choose_threshold, fx_to_float
+    contigs = synth.make_reference([300_700, 123_400], seed=31, names=["s1", "s2"])
+    strs = [(n, synth.codes_to_str(c)) for n, c in contigs]
+    batches = [synth.make_batch(contigs, 1200, seed=950 + b, mean_len=4000.0) for b in range(3)]
+
+    def run(env):
+        for k in ("BOSSX_NO_OVERLAP", "BOSSX_OVERLAP", "BOSSX_OVERLAP_SELFTEST"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        args = BossConfig()
+        args.general.name = "settle_" + "_".join(env) if env else "settle"
+        args.optional.bucket_threshold = 0
+        r = BossRuns(args)
+        r.init(contigs=strs)
+        r.write_masks = False
+        eng = r.engine
+        out = []
+        for b in batches:
+            r.rl_dist.update(b["read_lengths"])
+            summ = eng.ingest_paf(b["paf"], b["seqs"])
+            r._account_reads(summ, len(b["seqs"]))
+            eng.update_begin(0)
+            windows = np.concatenate(([4], r.rl_dist.approx_ccl // 100)).astype(np.int32)
+            eng.update_benefit(windows, MULT)            # next to the sweep once the strategy is on
+            mx = eng.get_max()
+            if mx > 0:
+                fh, trs = r.read_starts.fhat_compact()
+                counts, fg, ub = eng.histogram(mx, fh, trs, r.ref.n_sites // 100)
+                fgrid = np.array([fx_to_float(lo, hi) for lo, hi in fg])
+                thr, size, uniq = choose_threshold(mx, counts, fgrid, fx_to_float(ub[0], ub[1]), r.rl_dist.time_cost)
+                eng.apply_threshold(thr)
+                out.append((mx, thr, counts.copy(), eng.export(0, "benefit"), eng.get_strat(0), eng.get_strat(1)))
+            else:
+                out.append((mx,))
+            eng.arm()         # the host has seen that a strategy is on: later chains may run next to the sweep
+        eng.close()
+        return out
+    serial = run({"BOSSX_NO_OVERLAP": "1"})
+    aborted = run({"BOSSX_OVERLAP": "1", "BOSSX_OVERLAP_SELFTEST": "1"})
+    assert len(serial[-1]) > 1
+    for a, b in zip(serial, aborted):
+        assert len(a) == len(b) and a[0] == b[0]
+        for x, y in zip(a[1:], b[1:]):
+            assert np.array_equal(x, y)
