@@ -91,6 +91,9 @@ struct bossx_engine {
     int32_t pending_slot = -1;      // staged batch whose increments the next sweep applies
     double pending_emit = 0, pending_ops = 0;
     bool touched_dirty = false;     // the `touched` byte array holds flags the next sweep must read
+    bool full_sweep_needed = true;  // bin sums / bucket sums are not current everywhere (start, import, preload): sweep every tile
+    std::vector<int32_t> last_thr;  // dropout threshold each contig was last swept with
+    uint32_t *d_tile_cov = nullptr; // [nb][n_tiles] depth total of each tile at its last sweep
     uint32_t *d_tile_ref = nullptr;
     // device CIGAR walk (front_end.hip.inc): staging scratch shared by all slots
     char *h_paf_pin = nullptr; size_t paf_pin_cap = 0;        // PAF text, page-locked
@@ -221,7 +224,7 @@ SweepParams sweep_params(bossx_engine *h) {
         const bossx_engine::Staged &st = h->slots[size_t(h->pending_slot)];
         P.tiles = st.d_tilerefs; P.n_groups = uint32_t(st.pb.tiles.size()); P.segs = st.d_segs; P.ops = st.d_ops; P.blob = st.d_blob;
     }
-    P.ds = h->d_ds; P.bucket_sums = h->d_bucket_sums;
+    P.ds = h->d_ds; P.bucket_sums = h->d_bucket_sums; P.tile_cov = h->d_tile_cov; P.n_tiles = h->n_tiles;
     P.lut_score = h->d_lut_score; P.lut_ent = h->d_lut_ent; P.ct = table_of(h);
     P.Gp = h->Gp; P.B = h->B; P.NBK = h->NBK; P.nb = h->nb;
     P.score0 = h->score0; P.tiny = std::numeric_limits<double>::min();
@@ -327,7 +330,7 @@ void bossx_destroy(bossx_engine *h) {
     if (h->d_tile_order) hipFree(h->d_tile_order);
     void *ptrs[] = {h->d_cov, h->d_meta, h->d_touched, h->d_strat, h->d_bucket_on, h->d_entropy, h->d_ds,
                     h->d_benefit, h->d_lut_score, h->d_lut_ent, h->d_fhat, h->d_bucket_sums, h->d_drop_count,
-                    h->d_stats, h->d_tails /* base of the tails + result block */, h->d_tile_off, h->d_site_off, h->d_length, h->d_bin_off, h->d_row_off,
+                    h->d_stats, h->d_tile_cov, h->d_tails /* base of the tails + result block */, h->d_tile_off, h->d_site_off, h->d_length, h->d_bin_off, h->d_row_off,
                     h->d_strat_off, h->d_bucket_off, h->d_drop_thr, h->d_local, h->d_limbs,
                     h->d_strat_bits};
     for (void *p : ptrs) if (p) hipFree(p);
@@ -466,6 +469,7 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
     if ((rc = dev_alloc(h, &h->d_bucket_on, size_t(nb * h->NBK), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_bucket_sums, size_t(nb * h->NBK), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_drop_count, size_t(h->n_tiles), true))) return rc;
+    if ((rc = dev_alloc(h, &h->d_tile_cov, size_t(nb) * size_t(h->n_tiles > 0 ? h->n_tiles : 1), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_tile_ref, size_t(h->n_tiles), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_stats, size_t(BOSSX_HIST_BINS * 3 + 4 + 128), true))) return rc;
     // One allocation: [halo tails | control block | error flag | per-contig switches].  The tails sit
@@ -948,14 +952,38 @@ int launch_sweep(bossx_engine *h) {
         const double mean = double(c.cov_total) / double(c.length * int64_t(h->nb));
         thr[k] = (!c.remote && mean > 5) ? int32_t(mean / 8) : -1;
     }
+    const size_t n_groups = h->pending_slot >= 0 ? h->slots[size_t(h->pending_slot)].pb.tiles.size() : 0;
+    const size_t n_touched = h->pending_slot >= 0 ? h->slots[size_t(h->pending_slot)].pb.n_touched_tiles : 0;
+    // With several barcodes a touched tile costs nb scoring passes at the ingest variant's low
+    // occupancy (LDS staging, 4 blocks/CU): split the work instead — an ingest-only launch applies
+    // the increments and leaves `touched` flags, then the plain variant scores
+    // every tile.  (With one barcode the fused form is faster: 0.17 vs 0.36 ms for E. coli.)
+    const char *split_env = getenv("BOSSX_SPLIT_INGEST");
+    const bool split = n_groups > 0 && (split_env ? atoi(split_env) != 0 : h->nb >= 3);
+    // INCREMENTAL sweep.  A tile that receives no base keeps every value the sweep would recompute:
+    // scores are a function of (coverage, site state, dropout threshold of the contig), the bin sums
+    // and the bucket totals follow.  So when the batch touches a small part of the reference and no
+    // contig's dropout threshold moved (it is int(mean depth / 8), reference.py:174-176), only the
+    // touched tiles are swept; the others keep their bin sums, and the bucket sums are kept current
+    // by per-tile differences.  The reference recomputes everything every update (sequences.py:419,
+    // reference.py:157-161,196-199); the results are identical.  BOSSX_INCREMENTAL=0 / 1 forces it off /
+    // on whenever legal; by default it is used when fewer than 1/8 of the tiles are touched (above
+    // that the touched tiles dominate the sweep anyway).
+    if (h->last_thr.size() != thr.size()) h->last_thr.assign(thr.size(), INT32_MIN);
+    bool thr_changed = false;
+    for (size_t k = 0; k < thr.size(); ++k) thr_changed = thr_changed || thr[k] != h->last_thr[k];
+    const char *inc_env = getenv("BOSSX_INCREMENTAL");
+    const bool want_inc = inc_env ? atoi(inc_env) != 0 : n_touched * 8 < size_t(h->n_tiles);
+    const bool full = h->full_sweep_needed || h->touched_dirty || thr_changed || split || !want_inc;
     {
-        // one small launch clears the bucket sums and installs the thresholds.  The bin sums need no
-        // clearing: every bin of a local contig is rewritten by every sweep, the others stay zero.
+        // one small launch installs the thresholds and marks the tiles.  The bin sums need no
+        // clearing: every bin of a local contig is rewritten by every sweep of its tile, the others stay zero.
         PrepParams PR;
-        PR.bucket_sums = h->d_bucket_sums; PR.n_sums = h->nb * h->NBK;
         PR.drop_thr = h->d_drop_thr; PR.n_thr = 0;
         PR.max_bits = &h->d_ctrl->max_bits;
         PR.tiles = nullptr; PR.n_tiles = 0; PR.tile_ref = h->d_tile_ref;
+        PR.tile_done = h->d_tile_done; PR.n_all = h->n_tiles; PR.full = full ? 1 : 0;
+        PR.mark = (h->overlap_ok && h->host_armed) ? 1 : 0;      // = sweep_published below
         if (h->pending_slot >= 0) {
             const bossx_engine::Staged &st = h->slots[size_t(h->pending_slot)];
             PR.tiles = st.d_tilerefs; PR.n_tiles = uint32_t(st.pb.tiles.size());
@@ -966,7 +994,7 @@ int launch_sweep(bossx_engine *h) {
         } else {
             HIPCHK(hipMemcpyAsync(h->d_drop_thr, thr.data(), thr.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
         }
-        const int64_t blocks = std::min<int64_t>((std::max<int64_t>(PR.n_sums, int64_t(PR.n_tiles)) + 255) / 256, 1024);
+        const int64_t blocks = std::min<int64_t>((std::max<int64_t>(full ? h->n_tiles : 0, int64_t(PR.n_tiles)) + 255) / 256, 1024);
         h->max_bits_clear = true;
         hipLaunchKernelGGL(sweep_prep_kernel, dim3(uint32_t(std::max<int64_t>(blocks, 1))), dim3(256), 0, h->stream, PR);
         // everything up to here precedes a chain that update_benefit may put on stream2 next to
@@ -974,18 +1002,14 @@ int launch_sweep(bossx_engine *h) {
         HIPCHK(hipEventRecord(h->ev_begin, h->stream));
     }
     ++h->epoch;                                  // stamps the tile flags of this sweep
+    if (h->epoch == 0xffffffffu) h->epoch = 1;   // never the 'pending' value
     h->sweep_published = h->overlap_ok && h->host_armed;   // tiles are published only if a chain may run next to this sweep
     SweepParams P = sweep_params(h);
     time_begin(h, BOSSX_K_SWEEP);
-    const size_t n_groups = h->pending_slot >= 0 ? h->slots[size_t(h->pending_slot)].pb.tiles.size() : 0;
-    const size_t n_touched = h->pending_slot >= 0 ? h->slots[size_t(h->pending_slot)].pb.n_touched_tiles : 0;
-    // With several barcodes a touched tile costs nb scoring passes at the ingest variant's low
-    // occupancy (LDS staging, 4 blocks/CU): split the work instead — an ingest-only launch applies
-    // the increments and leaves `touched` flags, then the plain variant (8 waves/SIMD) scores
-    // every tile.  (With one barcode the fused form is faster: 0.17 vs 0.36 ms for E. coli.)
-    const char *split_env = getenv("BOSSX_SPLIT_INGEST");
-    const bool split = n_groups > 0 && (split_env ? atoi(split_env) != 0 : h->nb >= 3);
-    if (split) {
+    if (!full) {
+        // only the tiles that receive bases: one block per (tile, barcode) group, the first group of a tile does the tile
+        if (n_groups) LAUNCH_SWEEP(true, dim3(uint32_t(n_groups)), dim3(256), 0, h->stream, P);
+    } else if (split) {
         P.ingest_only = 1;
         LAUNCH_SWEEP(true, dim3(uint32_t(n_groups)), dim3(256), 0, h->stream, P);
         P.ingest_only = 0; P.tiles = nullptr; P.n_groups = 0; P.use_touched = 1;
@@ -1006,13 +1030,17 @@ int launch_sweep(bossx_engine *h) {
         if (n_groups)    // one block per (tile, barcode) group; the first group of a tile does the tile
             LAUNCH_SWEEP(true, dim3(uint32_t(n_groups)), dim3(256), 0, h->stream, P);
     }
+    h->last_thr = thr;
+    h->full_sweep_needed = false;
     // algorithmic bytes: per site*barcode 10 B counters + 1 B state read; per 100-site bin 8 B
     // downsampled score write; per ingested base 1 B read base + 2 B counter write-back, per
     // emit run 16 B (entropy / state write-backs of changed sites are data dependent and not
     // counted; the counter READ of an ingested base is already in the 10 B/site)
     double sites = 0;
     for (int32_t fi : h->filt) if (!h->contigs[size_t(fi)].remote) sites += double(h->contigs[size_t(fi)].length);
-    double bytes = sites * h->nb * 11.0 + double(h->B) * h->nb * 8.0;
+    double bins = double(h->B);
+    if (!full) { sites = double(n_touched) * kTileSites; bins = double(n_touched) * kTileBins; }   // incremental: the swept tiles only
+    double bytes = sites * h->nb * 11.0 + bins * h->nb * 8.0;
     if (h->touched_dirty || split) bytes += sites;
     if (h->pending_slot >= 0) bytes += 3.0 * h->pending_emit + 16.0 * h->pending_ops;
     time_end(h, BOSSX_K_SWEEP, bytes);
@@ -1100,6 +1128,7 @@ int fill_chain_params(bossx_engine *h, const int32_t *windows, const double *mul
     P.ds = h->d_ds; P.benefit = h->d_benefit; P.ctrl = h->d_ctrl; P.ct = table_of(h);
     P.B = h->B; P.nb = h->nb; P.ring = ring; P.gate = 0;
     P.tile_done = nullptr; P.epoch = h->epoch; P.wait_ticks = 200000000ll;   // 2 s
+    P.never_ready = 0;
     P.zero_stats = nullptr; P.n_zero = 0;
     P.probe = getenv("BOSSX_CHAIN_PROBE") ? reinterpret_cast<long long *>(h->d_stats + kStatWords + 8) : nullptr;
     P.max_limit = std::min<int64_t>(h->B, h->n_sites_all / kWindow);
@@ -1524,7 +1553,7 @@ int bossx_update_benefit(bossx_engine *h, const int32_t *windows, const double *
         HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_begin, 0));
         if (!h->max_bits_clear) HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream2));
         CP.tile_done = h->d_tile_done; CP.epoch = h->epoch;
-        if (getenv("BOSSX_OVERLAP_SELFTEST")) { CP.epoch = h->epoch + 1; CP.wait_ticks = 500000; }   // never satisfied: exercises the time-out path
+        if (getenv("BOSSX_OVERLAP_SELFTEST")) { CP.never_ready = 1; CP.wait_ticks = 500000; }   // never satisfied: exercises the time-out path
         launch_chain(h, CP, lds, h->stream2);
         HIPCHK(hipEventRecord(h->ev_chain, h->stream2));
         h->chain_on_stream2 = true;
@@ -1794,6 +1823,7 @@ int bossx_import(bossx_engine *h, int32_t contig, int32_t which, const void *src
     if (h->pending_slot >= 0 && (rc = flush_pending(h))) return rc;
     ContigInfo &c = h->contigs[size_t(contig)];
     const int64_t L = c.length, nb = h->nb;
+    h->full_sweep_needed = true;            // state changed behind the sweep's back: every tile again
     switch (which) {
         case 0: {
             if (src_bytes != size_t(nb * 5 * L) * 2) return fail(h, BOSSX_E_INVALID, "import size mismatch");
@@ -1878,6 +1908,7 @@ int bossx_preload_coverage(bossx_engine *h, double depth, uint64_t seed) {
     }
     HIPCHK(hipGetLastError());
     h->touched_dirty = true;
+    h->full_sweep_needed = true;
     return BOSSX_OK;
 }
 

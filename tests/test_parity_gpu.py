@@ -857,3 +857,61 @@ def test_stagewise_consumers_recover_from_a_timed_out_chain(in_tmp, monkeypatch)
         assert len(a) == len(b) and a[0] == b[0]
         for x, y in zip(a[1:], b[1:]):
             assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23, 24])
+def test_incremental_sweep_vs_oracle(in_tmp, monkeypatch, seed):
+    """Only the tiles a batch touches are swept when no contig's dropout threshold moved
+    (BOSSX_INCREMENTAL=1 forces it whenever legal): bin sums, bucket sums and masks of the untouched
+    tiles must stay exactly what a full sweep (and the oracle, which recomputes everything every
+    update) gives — through threshold changes, dropout activation, empty batches, sparse batches on
+    a few Mb, with the chain next to the sweep."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.runs import BossRuns
+    from oracle.pipeline import OracleRuns
+    monkeypatch.setenv("BOSSX_INCREMENTAL", "1")
+    monkeypatch.setenv("BOSSX_OVERLAP", "1")
+    rng = np.random.default_rng(seed)
+    lens = [int(rng.integers(600_000, 1_500_000)), int(rng.integers(100_000, 400_000))]
+    nb = int(rng.choice([1, 2]))
+    ploidy = int(rng.choice([1, 2]))
+    contigs = synth.make_reference(lens, seed=seed, names=["big", "small"])
+    strs = [(n, synth.codes_to_str(c)) for n, c in contigs]
+    args = BossConfig()
+    args.general.name = "inc%d" % seed
+    args.optional.ploidy = ploidy
+    args.optional.bucket_threshold = 1
+    if nb > 1:
+        args.general.barcodes = ["barcode%02d" % (i + 1) for i in range(nb)]
+    runs = BossRuns(args)
+    runs.init(contigs=strs)
+    o = OracleRuns(strs, ploidy=ploidy, nbarcodes=nb, bucket_threshold=1)
+    for b in range(9):
+        if b == 4:
+            batch = dict(paf="", seqs={}, barcodes={}, read_lengths={})                 # nothing new
+        else:
+            # mostly sparse batches (a few % of the tiles), one dense one that moves the dropout threshold
+            n_reads = 2500 if b == 2 else int(rng.integers(30, 200))
+            w = [1.0, 0.3] if b % 2 else [0.2, 2.0]
+            batch = synth.make_batch(contigs, n_reads, seed=seed * 100 + b, mean_len=5000.0, nbarcodes=nb, start_weights=w)
+        bcs = batch["barcodes"] if nb > 1 else None
+        o.process_batch(batch["paf"], batch["seqs"], read_lengths=batch["read_lengths"], barcodes=bcs)
+        runs.rl_dist.update(batch["read_lengths"])
+        runs.process_batch_paf(batch["paf"], batch["seqs"], barcodes=bcs)
+        assert runs.threshold == o.threshold, (seed, b)
+        for n, oc in o.contigs.items():
+            pc = runs.contigs[n]
+            assert np.array_equal(pc.coverage, oc.coverage), (seed, b, n)
+            assert np.array_equal(pc.scores, oc.scores), (seed, b, n)
+            assert np.array_equal(pc.bucket_switches, oc.bucket_switches), (seed, b, n)
+            assert np.array_equal(pc.strat, oc.strat), (seed, b, n)
+            if o.threshold is not None:
+                assert np.array_equal(pc.scores_ds, oc.scores_ds), (seed, b, n)
+                assert np.array_equal(pc.additional_benefit, oc.additional_benefit), (seed, b, n)
+            depth = oc.coverage.sum(axis=1, dtype=np.uint64)
+            bs = runs.engine.bucket_sums(pc.index)
+            nfull = oc.length // 20000
+            for k in range(nb):
+                assert np.array_equal(bs[k], depth[: nfull * 20000, k].reshape(-1, 20000).sum(axis=1)), (seed, b, n, k)
+    assert o.threshold is not None
