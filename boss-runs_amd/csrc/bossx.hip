@@ -34,7 +34,7 @@ struct bossx_engine {
     bool overlap_ok = false;           // decided at finalize (BOSSX_OVERLAP / BOSSX_NO_OVERLAP / size); cleared after a chain time-out
     bool host_armed = false;           // the host has seen ctrl.any_on set
     bool max_bits_clear = false;       // the sweep's prep launch zeroed ctrl.max_bits and no chain has run since
-    bool chain_lds_big = false;        // the live chain kernels were allowed 94 KB of dynamic LDS
+    int chain_ch = 256;                // bins per pipeline step of the chain kernel (fill_chain_params)
     bool sweep_published = false;      // the last sweep launch publishes its tiles (tile_done flags, agent-scope bin stores)
     bool sweep_in_flight = false;      // update_begin enqueued a sweep that no update has consumed yet
     bool chain_on_stream2 = false;     // update_benefit put the chain on stream2 (ev_chain pending)
@@ -1120,11 +1120,19 @@ int fill_chain_params(bossx_engine *h, const int32_t *windows, const double *mul
                 return fail(h, BOSSX_E_WINDOW, "Moving window (=" + std::to_string(windows[k]) + ") must between 1 and " +
                                                   std::to_string(c.T + 1) + ", inclusive");
     }
-    int32_t ring = 256;
-    while (ring < wmax + 2 * kChainChunk) ring <<= 1;
-    // static LDS of the chain kernel (difference / sum tiles) + the ring must fit 160 KiB
-    if (size_t(ring) * 8 + 2 * 2 * 16 * size_t(kChainPad) * 8 + 1024 > 160 * 1024)
-        return fail(h, BOSSX_E_WINDOW, "read-length window exceeds the LDS ring (reads longer than ~790 kb in the 95th percentile)");
+    // pipeline step: 256 bins when every chain block gets a CU of its own and the LDS allows, else 128
+    auto lds_need = [&](int ch, int32_t &ring_out) {
+        int32_t ring = 256;
+        while (ring < wmax + 2 * ch) ring <<= 1;
+        ring_out = ring;
+        return size_t(ring) * 8 + 2 * 2 * size_t(kChainRows) * size_t(ch + 2) * 8 + 1024;     // ring + difference / sum tiles
+    };
+    int32_t ring = 0;
+    const size_t n_blocks = h->filt.size() * size_t(h->nb) * 2;
+    h->chain_ch = 256;
+    if (n_blocks > 256 || getenv("BOSSX_CHAIN_128") || lds_need(256, ring) > 160 * 1024) h->chain_ch = 128;
+    if (lds_need(h->chain_ch, ring) > 160 * 1024)
+        return fail(h, BOSSX_E_WINDOW, "read-length window exceeds the LDS ring (reads longer than ~1 Mb in the 95th percentile)");
     P.ds = h->d_ds; P.benefit = h->d_benefit; P.ctrl = h->d_ctrl; P.ct = table_of(h);
     P.B = h->B; P.nb = h->nb; P.ring = ring; P.gate = 0;
     P.tile_done = nullptr; P.epoch = h->epoch; P.wait_ticks = 200000000ll;   // 2 s
@@ -1133,43 +1141,41 @@ int fill_chain_params(bossx_engine *h, const int32_t *windows, const double *mul
     P.probe = getenv("BOSSX_CHAIN_PROBE") ? reinterpret_cast<long long *>(h->d_stats + kStatWords + 8) : nullptr;
     P.max_limit = std::min<int64_t>(h->B, h->n_sites_all / kWindow);
     lds = size_t(ring) * sizeof(double);
-    if (lds > 32 * 1024) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_kernel<true, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_kernel<true, false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_kernel<false, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_kernel<false, false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-    }
     return BOSSX_OK;
 }
+
+extern "C++" {
+template <bool MATRIX, bool LIVE, int CH>
+void launch_chain_variant(dim3 grid, dim3 block, size_t lds, hipStream_t stream, const ChainParams &P) {
+    static size_t allowed = 0;                   // dynamic LDS this instantiation has been cleared for
+    if (lds > allowed) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_kernel<MATRIX, LIVE, CH>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        allowed = lds;
+    }
+    hipLaunchKernelGGL((benefit_chain_kernel<MATRIX, LIVE, CH>), grid, block, lds, stream, P);
+}
+}  // extern "C++"
 
 void launch_chain(bossx_engine *h, const ChainParams &P, size_t lds, hipStream_t stream = nullptr) {
     if (!stream) stream = h->stream;
     time_begin(h, BOSSX_K_BENEFIT, stream);
     const dim3 grid(uint32_t(h->filt.size() * size_t(h->nb) * 2)), block(kChainThreads);
     const bool live = P.tile_done != nullptr;
-    if (live && grid.x <= 8 && lds < size_t(94) * 1024) {
+    const int ch = h->chain_ch;
+    const size_t fixed = 2 * 2 * size_t(kChainRows) * size_t(ch + 2) * 8;     // static tiles of this instantiation
+    if (live && grid.x <= 8 && fixed + lds < size_t(140) * 1024) {
         // A few long chains next to a running sweep: ask for enough LDS that no sweep block fits on
-        // the chain's CU (65 KB static + 94 KB dynamic leave less than the smallest sweep block needs), otherwise the
+        // the chain's CU (less than the smallest sweep block's 22 KB stays free), otherwise the
         // sweep's waves share the chain wave's SIMD and slow the recurrence by ~6 % while they run.
-        lds = size_t(94) * 1024;
-        if (!h->chain_lds_big) {
-            hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_kernel<true, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-            hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_kernel<false, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-            h->chain_lds_big = true;
-        }
+        lds = size_t(140) * 1024 - fixed;
     }
     if (h->matrix_chain) {
-        if (live) hipLaunchKernelGGL((benefit_chain_kernel<true, true>), grid, block, lds, stream, P);
-        else hipLaunchKernelGGL((benefit_chain_kernel<true, false>), grid, block, lds, stream, P);
+        if (ch == 256) { if (live) launch_chain_variant<true, true, 256>(grid, block, lds, stream, P); else launch_chain_variant<true, false, 256>(grid, block, lds, stream, P); }
+        else { if (live) launch_chain_variant<true, true, 128>(grid, block, lds, stream, P); else launch_chain_variant<true, false, 128>(grid, block, lds, stream, P); }
     } else {
-        if (live) hipLaunchKernelGGL((benefit_chain_kernel<false, true>), grid, block, lds, stream, P);
-        else hipLaunchKernelGGL((benefit_chain_kernel<false, false>), grid, block, lds, stream, P);
+        if (ch == 256) { if (live) launch_chain_variant<false, true, 256>(grid, block, lds, stream, P); else launch_chain_variant<false, false, 256>(grid, block, lds, stream, P); }
+        else { if (live) launch_chain_variant<false, true, 128>(grid, block, lds, stream, P); else launch_chain_variant<false, false, 128>(grid, block, lds, stream, P); }
     }
     // algorithmic bytes: read the downsampled scores once per direction, write both strands
     time_end(h, BOSSX_K_BENEFIT, double(h->B) * h->nb * (2 * 8.0 + 2 * 8.0), stream);

@@ -61,7 +61,8 @@ class ReadStartDist:
             return
         w = np.minimum(x[keep] // ws, n[keep] - 1)
         key = (off[ci[keep]] + w) * 2 + rev[keep]
-        self._merged += np.bincount(key, minlength=2 * self._merged.shape[0]).reshape(-1, 2)
+        # O(batch), not O(windows): 1.5 M windows at 3.1 Gb
+        np.add.at(self._merged.reshape(-1), key, 1.0)
 
     def fhat_compact(self):
         """-> (fhat_c float64[n_windows, 2] already multiplied by the on-target normaliser,
