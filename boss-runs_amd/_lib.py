@@ -63,7 +63,7 @@ PROTOTYPES = {
                                     C.c_char_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                     C.POINTER(BatchSummary), C.POINTER(C.c_int32),
                                     C.POINTER(C.c_int64)]),
-    "bossx_stage_batch_ptrs": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p,
+    "bossx_stage_batch_ptrs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                          C.POINTER(BatchSummary), C.POINTER(C.c_int32),
                                          C.POINTER(C.c_int64)]),

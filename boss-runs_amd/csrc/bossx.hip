@@ -653,6 +653,7 @@ int check_device_walk(bossx_engine *h, bossx_engine::Staged &st, const ParseInpu
     ParseInput in = in0;
     std::vector<EmitOp> buf(ops_capacity_for(in.paf_len));
     in.ops_buf = buf.data(); in.ops_cap = buf.size(); in.device_walk = false;
+    in.extra_n = 0; in.extra_fn = nullptr; in.after_pass1 = nullptr;
     ParsedBatch pb;
     std::string err;
     int rc = parse_paf_batch(in, h->contigs, h->index, nullptr, pb, err);
@@ -689,11 +690,14 @@ int check_device_walk(bossx_engine *h, bossx_engine::Staged &st, const ParseInpu
     return BOSSX_OK;
 }
 
-// Parse + upload one batch into the selected slot.  `seqs` is the read blob (page-locked when it
-// comes from the gather of bossx_stage_batch_ptrs).
+// Parse + upload one batch into the selected slot.  `seqs` is the read blob; with `seq_ptrs` the
+// reads are still separate strings and are gathered into `seqs` (page-locked) here.  The gather, the
+// look for bytes other than A/C/G/T, the copy of the PAF text into page-locked memory and the line
+// parse are ONE parallel region; the uploads start as soon as it ends and overlap with the rest of
+// the host work.
 int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *names, const int64_t *name_off,
-               const char *seqs, const int64_t *seq_off, const int32_t *barcodes, int32_t n_reads, int32_t min_len,
-               bossx_batch_summary *summary, int32_t *n_rec, int64_t *aligned_bases) {
+               char *seqs, const int64_t *seq_off, const char *const *seq_ptrs, const int32_t *barcodes, int32_t n_reads,
+               int32_t min_len, bossx_batch_summary *summary, int32_t *n_rec, int64_t *aligned_bases) {
     const bool timing = getenv("BOSSX_STAGE_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     int rc;
@@ -713,40 +717,51 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
     if ((rc = grow_dev(h, &st.d_blob, &st.blob_cap, blob_bytes + 1024, 0))) return rc;
     ParseInput in{paf ? paf : "", paf ? paf_len : 0, names, name_off, seq_off, barcodes, n_reads, min_len, h->nb};
     in.seqs = seqs;
-    ParsedBatch pb;
     const bool host_walk = getenv("BOSSX_HOST_WALK") != nullptr;
-    if (host_walk) {
-        if (blob_bytes) HIPCHK(hipMemcpyAsync(st.d_blob, seqs, blob_bytes, hipMemcpyHostToDevice, h->stream));
-        if ((rc = stage_host_walk(h, st, in, summary, pb))) return rc;
-    } else {
-        // ---- uploads that do not wait for the parse: the read blob and the PAF text ------------
-        if (blob_bytes) HIPCHK(hipMemcpyAsync(st.d_blob, seqs, blob_bytes, hipMemcpyHostToDevice, h->stream));
+    if (!host_walk) {
         if ((rc = grow_pin(h, &h->h_paf_pin, &h->paf_pin_cap, in.paf_len + 64))) return rc;
         if ((rc = grow_dev(h, &h->d_paf, &h->d_paf_cap, in.paf_len + 64, 4096))) return rc;
-        {
-            const int nt = in.paf_len > (size_t(1) << 20) ? std::min(parse_threads(), 8) : 1;
-            run_threads(nt, [&](int t) {
-                const size_t lo = in.paf_len * size_t(t) / size_t(nt), hi = in.paf_len * size_t(t + 1) / size_t(nt);
-                memcpy(h->h_paf_pin + lo, in.paf + lo, hi - lo);
-            });
+    }
+    // ---- the caller's share of pass 1's parallel region --------------------------------------
+    h->read_dirty.assign(size_t(n_reads), 0);
+    const int n_g = blob_bytes > (size_t(1) << 20) ? parse_threads() : (n_reads > 0 ? 1 : 0);
+    const int n_c = host_walk ? 0 : (in.paf_len > (size_t(1) << 20) ? 4 : (in.paf_len ? 1 : 0));
+    in.extra_n = n_g + n_c;
+    in.extra_fn = [&, n_g, n_c](int t) {
+        if (t < n_g) {            // reads [b, e) of a byte-balanced slice: gather (if still scattered) and look at the bases
+            const size_t lo_b = blob_bytes * size_t(t) / size_t(n_g), hi_b = blob_bytes * size_t(t + 1) / size_t(n_g);
+            const int64_t *bp = std::lower_bound(seq_off, seq_off + n_reads, int64_t(lo_b));
+            const int64_t *ep = t + 1 == n_g ? seq_off + n_reads : std::lower_bound(seq_off, seq_off + n_reads, int64_t(hi_b));
+            for (int32_t i = int32_t(bp - seq_off), ie = int32_t(ep - seq_off); i < ie; ++i) {
+                const size_t len = size_t(seq_off[i + 1] - seq_off[i]);
+                if (seq_ptrs) memcpy(seqs + seq_off[i], seq_ptrs[i], len);
+                h->read_dirty[size_t(i)] = bytes_all_acgt(seqs + seq_off[i], len) ? 0 : 1;
+            }
+        } else {
+            const int c = t - n_g;
+            const size_t lo = in.paf_len * size_t(c) / size_t(n_c), hi = in.paf_len * size_t(c + 1) / size_t(n_c);
+            memcpy(h->h_paf_pin + lo, in.paf + lo, hi - lo);
         }
-        if (in.paf_len) HIPCHK(hipMemcpyAsync(h->d_paf, h->h_paf_pin, in.paf_len, hipMemcpyHostToDevice, h->stream));
+    };
+    hipError_t up_err = hipSuccess;
+    in.after_pass1 = [&]() {      // uploads that do not wait for the rest of the parse
+        if (blob_bytes) up_err = hipMemcpyAsync(st.d_blob, seqs, blob_bytes, hipMemcpyHostToDevice, h->stream);
+        if (!host_walk && in.paf_len && up_err == hipSuccess)
+            up_err = hipMemcpyAsync(h->d_paf, h->h_paf_pin, in.paf_len, hipMemcpyHostToDevice, h->stream);
+    };
+    ParsedBatch pb;
+    if (host_walk) {
+        if ((rc = stage_host_walk(h, st, in, summary, pb))) return rc;
+        HIPCHK(up_err);
+    } else {
         // ---- host: lines -> records -> best mapping per read -> plans + (tile, barcode) groups ----
-        if (h->read_dirty.size() != size_t(n_reads)) {       // blob handed in by the caller: look at it here
-            h->read_dirty.assign(size_t(n_reads), 0);
-            const int nt = blob_bytes > (size_t(1) << 20) ? parse_threads() : 1;
-            run_threads(nt, [&](int t) {
-                for (int32_t i = int32_t(int64_t(n_reads) * t / nt), e = int32_t(int64_t(n_reads) * (t + 1) / nt); i < e; ++i)
-                    h->read_dirty[size_t(i)] = bytes_all_acgt(seqs + seq_off[i], size_t(seq_off[i + 1] - seq_off[i])) ? 0 : 1;
-            });
-        }
         in.device_walk = true;
         in.read_dirty = h->read_dirty.data();
         in.n_tiles = h->n_tiles;
         std::string err;
         rc = parse_paf_batch(in, h->contigs, h->index, summary, pb, err);
-        h->read_dirty.clear();
-        if (rc) return fail(h, rc, err);
+        if (rc) { hipStreamSynchronize(h->stream); return fail(h, rc, err); }     // inputs are borrowed for the call only
+        HIPCHK(up_err);
         const auto t1 = std::chrono::steady_clock::now();
         const uint32_t n_plans = uint32_t(pb.plans.size()), n_groups = uint32_t(pb.tiles.size());
         uint32_t totals[4] = {0, 0, 0, 0};
@@ -831,8 +846,9 @@ int bossx_stage_batch(bossx_engine *h, const char *paf, size_t paf_len, const ch
     if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "stage_batch before finalize");
     if (n_reads < 0 || (n_reads > 0 && (!names || !name_off || !seqs || !seq_off))) return fail(h, BOSSX_E_INVALID, "bad batch arrays");
     HIPCHK(hipSetDevice(h->cfg.device));
-    h->read_dirty.clear();
-    return stage_core(h, paf, paf_len, names, name_off, seqs, seq_off, barcodes, n_reads, min_len, summary, n_rec, aligned_bases);
+    // (the blob is the caller's: it is only read)
+    return stage_core(h, paf, paf_len, names, name_off, const_cast<char *>(seqs), seq_off, nullptr, barcodes, n_reads, min_len,
+                      summary, n_rec, aligned_bases);
 }
 
 int bossx_stage_batch_ptrs(bossx_engine *h, const char *paf, size_t paf_len, const char *const *name_ptrs,
@@ -849,7 +865,8 @@ int bossx_stage_batch_ptrs(bossx_engine *h, const char *paf, size_t paf_len, con
     }
     std::string names(size_t(name_off[size_t(n_reads)]), '\0');
     for (int32_t i = 0; i < n_reads; ++i) memcpy(&names[size_t(name_off[size_t(i)])], name_ptrs[i], size_t(name_lens[i]));
-    // gather the sequences into pinned memory: one pass, and the H2D copy runs at full PCIe rate
+    // the sequences are gathered into pinned memory inside stage_core's parallel region: one pass,
+    // and the H2D copy runs at full PCIe rate
     const size_t blob_bytes = size_t(seq_off[size_t(n_reads)]);
     HIPCHK(hipStreamSynchronize(h->stream));           // the pinned buffer may still feed a copy
     if (blob_bytes + 64 > h->blob_pin_cap) {
@@ -859,28 +876,8 @@ int bossx_stage_batch_ptrs(bossx_engine *h, const char *paf, size_t paf_len, con
         HIPCHK(hipHostMalloc(&h->h_blob_pin, cap, hipHostMallocDefault));
         h->blob_pin_cap = cap;
     }
-    char *blob = static_cast<char *>(h->h_blob_pin);
-    const auto tg0 = std::chrono::steady_clock::now();
-    h->read_dirty.assign(size_t(n_reads), 0);
-    {
-        // parallel gather, ranges balanced by bytes; each read is looked at once for bytes other
-        // than A/C/G/T (only such reads get the per-run base check of the walk)
-        const int nt = (blob_bytes > (size_t(1) << 20)) ? parse_threads() : 1;
-        run_threads(nt, [&](int t) {
-            const size_t lo_b = blob_bytes * size_t(t) / size_t(nt), hi_b = blob_bytes * size_t(t + 1) / size_t(nt);
-            const int64_t *b = std::lower_bound(seq_off.data(), seq_off.data() + n_reads, int64_t(lo_b));
-            const int64_t *e = std::lower_bound(seq_off.data(), seq_off.data() + n_reads, int64_t(hi_b));
-            for (int32_t i = int32_t(b - seq_off.data()), ie = int32_t(e - seq_off.data()); i < ie; ++i) {
-                memcpy(blob + seq_off[size_t(i)], seq_ptrs[i], size_t(seq_lens[i]));
-                h->read_dirty[size_t(i)] = bytes_all_acgt(blob + seq_off[size_t(i)], size_t(seq_lens[i])) ? 0 : 1;
-            }
-        });
-    }
-    if (getenv("BOSSX_STAGE_TIMING"))
-        fprintf(stderr, "[bossx] stage_batch: gather %.2f ms\n",
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg0).count());
-    return stage_core(h, paf, paf_len, names.data(), name_off.data(), blob, seq_off.data(), barcodes, n_reads,
-                      min_len, summary, n_rec, aligned_bases);
+    return stage_core(h, paf, paf_len, names.data(), name_off.data(), static_cast<char *>(h->h_blob_pin), seq_off.data(), seq_ptrs,
+                      barcodes, n_reads, min_len, summary, n_rec, aligned_bases);
 }
 
 int bossx_paf_summary(bossx_engine *h, const char *paf, size_t paf_len, const char *const *name_ptrs,

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -143,7 +144,17 @@ struct ParseInput {
     bool device_walk = false;    // fill ParsedBatch::plans / groups only; the CIGAR walk runs on the GPU
     const uint8_t *read_dirty = nullptr;   // per read: 1 if it holds a byte other than A/C/G/T (null: unknown, assume 1)
     int64_t n_tiles = 0, paf_base = 0;     // device walk: tile count of the engine (group marking)
+    // Work of the caller that is independent of the line parse (gathering the reads into the upload
+    // buffer, copying the text) joins pass 1's parallel region as `extra_n` more tasks;
+    // `after_pass1` runs on the calling thread right after that region (start the uploads).
+    std::function<void(int)> extra_fn;
+    int extra_n = 0;
+    std::function<void()> after_pass1;
 };
+
+// Persistent worker threads for the host front end (creating 40 threads per batch cost more than
+// the parsing they did): runs fn(0) .. fn(n_tasks - 1), the caller takes part.
+void pool_run(int n_tasks, const std::function<void(int)> &fn);
 
 size_t ops_capacity_for(size_t paf_len);
 int parse_threads();             // BOSSX_PARSE_THREADS, default min(8, hardware threads)

@@ -16,6 +16,10 @@
 #include <cstring>
 #include <climits>
 #include <cstdint>
+#include <atomic>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <string_view>
 #include <thread>
 
@@ -300,6 +304,72 @@ void walk_plans(const ParseInput &in, const std::vector<ContigInfo> &contigs, co
 
 }  // namespace
 
+namespace {
+
+class WorkPool {
+  public:
+    struct Job {
+        const std::function<void(int)> *fn;
+        int n;
+        std::atomic<int> next{0}, pending{0};
+    };
+    static WorkPool &get() { static WorkPool p; return p; }
+    void run(int n, const std::function<void(int)> &fn) {
+        if (n <= 0) return;
+        ensure(n - 1);
+        if (n == 1 || threads_.empty()) { for (int i = 0; i < n; ++i) fn(i); return; }
+        auto job = std::make_shared<Job>();
+        job->fn = &fn; job->n = n; job->pending.store(n);
+        { std::lock_guard<std::mutex> lk(m_); job_ = job; ++gen_; }
+        gen_a_.fetch_add(1, std::memory_order_release);
+        cv_.notify_all();
+        work(*job);
+        while (job->pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+    }
+  private:
+    static void work(Job &j) {
+        int i;
+        while ((i = j.next.fetch_add(1)) < j.n) { (*j.fn)(i); j.pending.fetch_sub(1, std::memory_order_release); }
+    }
+    void ensure(int want) {
+        want = std::min(want, 63);
+        std::lock_guard<std::mutex> lk(m_);
+        while (int(threads_.size()) < want) threads_.emplace_back([this] { loop(); });
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            // a short spin first: the parallel regions of one batch follow each other within microseconds
+            for (int s = 0; s < 4000 && gen_a_.load(std::memory_order_acquire) == seen; ++s) __builtin_ia32_pause();
+            std::shared_ptr<Job> job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+                job = job_;
+            }
+            if (job) work(*job);
+        }
+    }
+    ~WorkPool() {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::vector<std::thread> threads_;
+    std::shared_ptr<Job> job_;
+    uint64_t gen_ = 0;
+    std::atomic<uint64_t> gen_a_{0};
+    bool stop_ = false;
+};
+
+}  // namespace
+
+void pool_run(int n_tasks, const std::function<void(int)> &fn) { WorkPool::get().run(n_tasks, fn); }
+
 size_t ops_capacity_for(size_t paf_len) { return paf_len / 2 + paf_len / 16 + 64; }
 
 int parse_threads() {
@@ -338,11 +408,12 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             cuts[size_t(t)] = nl ? nl + 1 : in.paf + in.paf_len;
         }
         std::vector<LineOut> los(static_cast<size_t>(nt));
-        auto work = [&](int t) { parse_lines(cuts[size_t(t)], cuts[size_t(t) + 1], in.min_len, los[size_t(t)]); };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
-        work(0);
-        for (auto &th : pool) th.join();
+        // one parallel region: the line ranges, plus whatever independent work the caller brought along
+        pool_run(nt + in.extra_n, [&](int t) {
+            if (t < nt) parse_lines(cuts[size_t(t)], cuts[size_t(t) + 1], in.min_len, los[size_t(t)]);
+            else in.extra_fn(t - nt);
+        });
+        if (in.after_pass1) in.after_pass1();
         int64_t line_base = 0;
         for (const LineOut &lo : los) {          // first failing line in file order
             if (lo.err_line) { err = "PAF line " + std::to_string(line_base + lo.err_line) + lo.err_msg; return BOSSX_E_PARSE; }
@@ -545,10 +616,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             EmitOp *base = in.ops_buf + (p0 < plans.size() ? plans[p0].ops_at : ops_at);
             walk_plans(in, contigs, plans, p0, p1, base, wos[size_t(t)]);
         };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
-        work(0);
-        for (auto &th : pool) th.join();
+        pool_run(nt, work);
     }
     PT(T3);
     // first failure in record order; the IndexError class only if nothing else failed (the

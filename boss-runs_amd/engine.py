@@ -169,7 +169,13 @@ class Engine:
         n = len(ids)
         nptr, nlen = self._str_pointers(ids)
         sptr, slen = self._str_pointers(vals)
-        paf = paf_text.encode() if isinstance(paf_text, str) else bytes(paf_text)
+        if isinstance(paf_text, str):
+            # the interpreter's own UTF-8 buffer of the str (for ASCII text: the string itself): no copy
+            pp, pl = self._str_pointers([paf_text])
+            paf, paf_len = int(pp[0]), int(pl[0])
+        else:
+            paf = bytes(paf_text)
+            paf_len = len(paf)
         bc = None
         if barcodes is not None:
             bc = np.ascontiguousarray([barcodes[i] for i in ids] if isinstance(barcodes, dict) else barcodes,
@@ -180,7 +186,7 @@ class Engine:
         summ = _lib.BatchSummary(*[s[k].ctypes.data for k in ("read_idx", "contig_idx", "rev", "tstart", "tend", "qlen")])
         n_rec = C.c_int32(0)
         aligned = C.c_int64(0)
-        self._ck(self.lib.bossx_stage_batch_ptrs(self.h, paf, len(paf), nptr.ctypes.data, nlen.ctypes.data,
+        self._ck(self.lib.bossx_stage_batch_ptrs(self.h, paf, paf_len, nptr.ctypes.data, nlen.ctypes.data,
                                                  sptr.ctypes.data, slen.ctypes.data,
                                                  None if bc is None else bc.ctypes.data, n, int(min_len),
                                                  C.byref(summ), C.byref(n_rec), C.byref(aligned)))
