@@ -52,5 +52,7 @@ for name, v in res["kernels"].items():
             if g(k) is not None:
                 v[k + "_frac_of_wave_cycles"] = g(k) / g("SQ_WAVE_CYCLES")
 json.dump(res, open(os.path.join(out, "%s_summary.json" % tag), "w"), indent=1)
-for k, v in sorted(res["kernels"].items(), key=lambda kv: -kv[1].get("total_ns", 0))[:12]:
-    print(k[:60], {a: (round(b, 3) if isinstance(b, float) else b) for a, b in v.items()})
+KEYS = ("calls", "avg_ns", "pct", "hbm_bytes_per_launch", "l2_hit_rate", "SQ_WAIT_ANY_frac_of_wave_cycles",
+        "SQ_ACTIVE_INST_VALU_frac_of_wave_cycles", "SQ_ACTIVE_INST_ANY_frac_of_wave_cycles")
+for k, v in sorted(res["kernels"].items(), key=lambda kv: -kv[1].get("total_ns", 0))[:8]:
+    print(k[:48], {a: (round(v[a], 3) if isinstance(v[a], float) else v[a]) for a in KEYS if a in v})
