@@ -972,6 +972,23 @@ int launch_sweep(bossx_engine *h) {
     const char *inc_env = getenv("BOSSX_INCREMENTAL");
     const bool want_inc = inc_env ? atoi(inc_env) != 0 : n_touched * 8 < size_t(h->n_tiles);
     const bool full = h->full_sweep_needed || h->touched_dirty || thr_changed || split || !want_inc;
+    // The chain of this update may run NEXT TO the sweep (second stream, tiles handed over as they
+    // are published) — worth it only where the sweep is long against the chain: the concurrent
+    // chain variant is ~10 % slower than the serial one (agent-scope loads, flag polling), which
+    // costs more than a 0.6 ms sweep hidden behind a 4 ms chain gives back (chr20+21: 6.57 vs
+    // 6.26 ms per update).  Estimates: 2.5 TB/s for the swept tiles, 5.6 ns per bin of the longest
+    // contig.  BOSSX_OVERLAP=1 forces it on, BOSSX_NO_OVERLAP=1 off.
+    bool publish = h->overlap_ok && h->host_armed;
+    if (publish && !getenv("BOSSX_OVERLAP")) {
+        int64_t longest = 0;
+        for (int32_t fi : h->filt) if (!h->contigs[size_t(fi)].remote) longest = std::max(longest, h->contigs[size_t(fi)].T + 1);
+        const double swept_tiles = full ? double(h->n_tiles) : double(n_touched);
+        const double tile_bytes = double(kTileSites) * h->nb * 11.0;
+        // (a tile that receives bases costs ~2.5 tiles, an ingested base ~3 ps on top)
+        const double sweep_ms = (swept_tiles + 1.5 * double(n_touched)) * tile_bytes / 2.5e9 + (h->pending_slot >= 0 ? h->pending_emit : 0.0) * 3e-9;
+        const double chain_ms = double(longest) * 5.6e-6;
+        publish = sweep_ms >= 0.3 * chain_ms;
+    }
     {
         // one small launch installs the thresholds and marks the tiles.  The bin sums need no
         // clearing: every bin of a local contig is rewritten by every sweep of its tile, the others stay zero.
@@ -980,7 +997,7 @@ int launch_sweep(bossx_engine *h) {
         PR.max_bits = &h->d_ctrl->max_bits;
         PR.tiles = nullptr; PR.n_tiles = 0; PR.tile_ref = h->d_tile_ref;
         PR.tile_done = h->d_tile_done; PR.n_all = h->n_tiles; PR.full = full ? 1 : 0;
-        PR.mark = (h->overlap_ok && h->host_armed) ? 1 : 0;      // = sweep_published below
+        PR.mark = publish ? 1 : 0;
         if (h->pending_slot >= 0) {
             const bossx_engine::Staged &st = h->slots[size_t(h->pending_slot)];
             PR.tiles = st.d_tilerefs; PR.n_tiles = uint32_t(st.pb.tiles.size());
@@ -1000,7 +1017,7 @@ int launch_sweep(bossx_engine *h) {
     }
     ++h->epoch;                                  // stamps the tile flags of this sweep
     if (h->epoch == 0xffffffffu) h->epoch = 1;   // never the 'pending' value
-    h->sweep_published = h->overlap_ok && h->host_armed;   // tiles are published only if a chain may run next to this sweep
+    h->sweep_published = publish;                // tiles are published only if a chain will run next to this sweep
     SweepParams P = sweep_params(h);
     time_begin(h, BOSSX_K_SWEEP);
     if (!full) {
@@ -1554,6 +1571,7 @@ int bossx_update_benefit(bossx_engine *h, const int32_t *windows, const double *
         // out from both contig ends and publishes each tile's bin sums (tile_done == epoch); the
         // chain's prefetch wave waits for the tiles of a chunk before reading it.
         HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_begin, 0));
+        if (getenv("BOSSX_LIVE_AFTER")) HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_sweep, 0));   // experiment: the live variant, but after the sweep
         if (!h->max_bits_clear) HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream2));
         CP.tile_done = h->d_tile_done; CP.epoch = h->epoch;
         if (getenv("BOSSX_OVERLAP_SELFTEST")) { CP.never_ready = 1; CP.wait_ticks = 500000; }   // never satisfied: exercises the time-out path
