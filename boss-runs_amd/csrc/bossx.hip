@@ -2,7 +2,10 @@
 // gfx950 only; no CPU fallback — every entry point needs the device.
 #include <hip/hip_runtime.h>
 
+#include <immintrin.h>
+
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -26,6 +29,8 @@ struct bossx_engine {
     bool own_stream = false;
     // second stream: the benefit chain of an update runs next to that update's sweep
     hipStream_t stream2 = nullptr;
+    hipStream_t stream_up = nullptr;   // slice-wise uploads of a batch being staged (issued by the worker threads)
+    hipEvent_t ev_up = nullptr;
     hipEvent_t ev_begin = nullptr, ev_chain = nullptr, ev_sweep = nullptr, ev_fhat = nullptr;
     double *h_fhat_pin = nullptr;      // page-locked staging of the compact f-hat
     uint32_t *d_tile_done = nullptr;   // [n_tiles] sweep -> chain hand-off flags (epoch stamped)
@@ -43,6 +48,8 @@ struct bossx_engine {
     bool lut_set = false;
     bool all_local = true;
     bool matrix_chain = false;      // FP64 matrix-core recurrence passed its start-up self-test
+    bool chain_flow = true;         // barrier-free chain kernel (benefit_chain_flow_kernel); cleared by BOSSX_CHAIN_BARRIER=1 or after it aborted
+    bool last_chain_live = false;   // the last chain launch ran next to its sweep
     int32_t nb = 1;
 
     std::vector<ContigInfo> contigs;                    // add order (rejected included)
@@ -311,7 +318,9 @@ int bossx_create(const bossx_config *cfg, bossx_engine **out) {
         hipEventCreateWithFlags(&h->ev_begin, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_sweep, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_fhat, hipEventDisableTiming) != hipSuccess) return BOSSX_E_HIP;
+        hipEventCreateWithFlags(&h->ev_fhat, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->stream_up, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming) != hipSuccess) return BOSSX_E_HIP;
     *out = e.release();
     return BOSSX_OK;
 }
@@ -321,6 +330,8 @@ void bossx_destroy(bossx_engine *h) {
     hipSetDevice(h->cfg.device);
     hipStreamSynchronize(h->stream);
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
+    if (h->stream_up) { hipStreamSynchronize(h->stream_up); hipStreamDestroy(h->stream_up); }
+    if (h->ev_up) hipEventDestroy(h->ev_up);
     if (h->ev_begin) hipEventDestroy(h->ev_begin);
     if (h->ev_chain) hipEventDestroy(h->ev_chain);
     if (h->ev_sweep) hipEventDestroy(h->ev_sweep);
@@ -466,6 +477,7 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
     // the chain is 5-10x longer than the sweep, -30 % at 50 Mb x 8 barcodes).
     // BOSSX_NO_OVERLAP=1 keeps them back to back.
     h->overlap_ok = getenv("BOSSX_NO_OVERLAP") == nullptr;
+    h->chain_flow = getenv("BOSSX_CHAIN_BARRIER") == nullptr;
     if ((rc = dev_alloc(h, &h->d_bucket_on, size_t(nb * h->NBK), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_bucket_sums, size_t(nb * h->NBK), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_drop_count, size_t(h->n_tiles), true))) return rc;
@@ -569,7 +581,29 @@ void run_threads(int nt, F &&fn) {
     for (auto &th : pool) th.join();
 }
 
-bool bytes_all_acgt(const char *p, size_t n) {       // vectorised by the compiler
+// 32 bytes per step: a byte is one of A C G T iff a 16-entry table indexed by its low nibble
+// (A = 0x41, C = 0x43, T = 0x54, G = 0x47) gives the byte back
+__attribute__((target("avx2"))) bool bytes_all_acgt_avx2(const char *p, size_t n) {
+    const __m256i lut = _mm256_setr_epi8(0, 0x41, 0, 0x43, 0x54, 0, 0, 0x47, 0, 0, 0, 0, 0, 0, 0, 0,
+                                         0, 0x41, 0, 0x43, 0x54, 0, 0, 0x47, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m256i low = _mm256_set1_epi8(0x0f);
+    __m256i ok = _mm256_set1_epi8(char(0xff));
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(p + i));
+        ok = _mm256_and_si256(ok, _mm256_cmpeq_epi8(_mm256_shuffle_epi8(lut, _mm256_and_si256(v, low)), v));
+    }
+    bool good = _mm256_movemask_epi8(ok) == -1;
+    for (; i < n; ++i) {
+        const unsigned char c = static_cast<unsigned char>(p[i]);
+        good = good && ((c == 'A') | (c == 'C') | (c == 'G') | (c == 'T'));
+    }
+    return good;
+}
+
+bool bytes_all_acgt(const char *p, size_t n) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) return bytes_all_acgt_avx2(p, n);
     unsigned bad = 0;
     for (size_t i = 0; i < n; ++i) {
         const unsigned char c = static_cast<unsigned char>(p[i]);
@@ -727,27 +761,39 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
     const int n_g = blob_bytes > (size_t(1) << 20) ? parse_threads() : (n_reads > 0 ? 1 : 0);
     const int n_c = host_walk ? 0 : (in.paf_len > (size_t(1) << 20) ? 4 : (in.paf_len ? 1 : 0));
     in.extra_n = n_g + n_c;
-    in.extra_fn = [&, n_g, n_c](int t) {
+    // Every slice goes up as soon as it is gathered (the worker that filled it issues the copy, on a
+    // stream of its own): the PCIe transfer of the 24 MB of reads overlaps with the gather instead
+    // of following it.
+    std::atomic<int> up_fail{0};
+    const int dev = h->cfg.device;
+    in.extra_fn = [&, n_g, n_c, dev](int t) {
+        static thread_local int dev_set = -1;
+        if (dev_set != dev) { if (hipSetDevice(dev) != hipSuccess) up_fail.store(1); dev_set = dev; }
         if (t < n_g) {            // reads [b, e) of a byte-balanced slice: gather (if still scattered) and look at the bases
             const size_t lo_b = blob_bytes * size_t(t) / size_t(n_g), hi_b = blob_bytes * size_t(t + 1) / size_t(n_g);
             const int64_t *bp = std::lower_bound(seq_off, seq_off + n_reads, int64_t(lo_b));
             const int64_t *ep = t + 1 == n_g ? seq_off + n_reads : std::lower_bound(seq_off, seq_off + n_reads, int64_t(hi_b));
-            for (int32_t i = int32_t(bp - seq_off), ie = int32_t(ep - seq_off); i < ie; ++i) {
+            const int32_t i0 = int32_t(bp - seq_off), i1 = int32_t(ep - seq_off);
+            for (int32_t i = i0; i < i1; ++i) {
                 const size_t len = size_t(seq_off[i + 1] - seq_off[i]);
                 if (seq_ptrs) memcpy(seqs + seq_off[i], seq_ptrs[i], len);
                 h->read_dirty[size_t(i)] = bytes_all_acgt(seqs + seq_off[i], len) ? 0 : 1;
             }
+            if (i1 > i0 && seq_off[i1] > seq_off[i0] &&
+                hipMemcpyAsync(st.d_blob + seq_off[i0], seqs + seq_off[i0], size_t(seq_off[i1] - seq_off[i0]), hipMemcpyHostToDevice, h->stream_up) != hipSuccess)
+                up_fail.store(1);
         } else {
             const int c = t - n_g;
             const size_t lo = in.paf_len * size_t(c) / size_t(n_c), hi = in.paf_len * size_t(c + 1) / size_t(n_c);
             memcpy(h->h_paf_pin + lo, in.paf + lo, hi - lo);
+            if (hi > lo && hipMemcpyAsync(h->d_paf + lo, h->h_paf_pin + lo, hi - lo, hipMemcpyHostToDevice, h->stream_up) != hipSuccess) up_fail.store(1);
         }
     };
     hipError_t up_err = hipSuccess;
-    in.after_pass1 = [&]() {      // uploads that do not wait for the rest of the parse
-        if (blob_bytes) up_err = hipMemcpyAsync(st.d_blob, seqs, blob_bytes, hipMemcpyHostToDevice, h->stream);
-        if (!host_walk && in.paf_len && up_err == hipSuccess)
-            up_err = hipMemcpyAsync(h->d_paf, h->h_paf_pin, in.paf_len, hipMemcpyHostToDevice, h->stream);
+    in.after_pass1 = [&]() {      // everything staged on the upload stream precedes what follows on the main one
+        if (up_fail.load()) { up_err = hipErrorUnknown; return; }
+        up_err = hipEventRecord(h->ev_up, h->stream_up);
+        if (up_err == hipSuccess) up_err = hipStreamWaitEvent(h->stream, h->ev_up, 0);
     };
     ParsedBatch pb;
     if (host_walk) {
@@ -1169,6 +1215,16 @@ void launch_chain_variant(dim3 grid, dim3 block, size_t lds, hipStream_t stream,
     }
     hipLaunchKernelGGL((benefit_chain_kernel<MATRIX, LIVE, CH>), grid, block, lds, stream, P);
 }
+template <bool LIVE, int CH>
+void launch_chain_flow(dim3 grid, dim3 block, size_t lds, hipStream_t stream, const ChainParams &P) {
+    static size_t allowed = 0;
+    if (lds > allowed) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_flow_kernel<LIVE, CH>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        allowed = lds;
+    }
+    hipLaunchKernelGGL((benefit_chain_flow_kernel<LIVE, CH>), grid, block, lds, stream, P);
+}
 }  // extern "C++"
 
 void launch_chain(bossx_engine *h, const ChainParams &P, size_t lds, hipStream_t stream = nullptr) {
@@ -1184,7 +1240,11 @@ void launch_chain(bossx_engine *h, const ChainParams &P, size_t lds, hipStream_t
         // sweep's waves share the chain wave's SIMD and slow the recurrence by ~6 % while they run.
         lds = size_t(140) * 1024 - fixed;
     }
-    if (h->matrix_chain) {
+    h->last_chain_live = live;
+    if (h->matrix_chain && h->chain_flow) {
+        if (ch == 256) { if (live) launch_chain_flow<true, 256>(grid, block, lds, stream, P); else launch_chain_flow<false, 256>(grid, block, lds, stream, P); }
+        else { if (live) launch_chain_flow<true, 128>(grid, block, lds, stream, P); else launch_chain_flow<false, 128>(grid, block, lds, stream, P); }
+    } else if (h->matrix_chain) {
         if (ch == 256) { if (live) launch_chain_variant<true, true, 256>(grid, block, lds, stream, P); else launch_chain_variant<true, false, 256>(grid, block, lds, stream, P); }
         else { if (live) launch_chain_variant<true, true, 128>(grid, block, lds, stream, P); else launch_chain_variant<true, false, 128>(grid, block, lds, stream, P); }
     } else {
@@ -1213,7 +1273,7 @@ int settle_chain(bossx_engine *h) {
     err &= ~4;
     HIPCHK(hipMemcpyAsync(&h->d_ctrl->err, &err, sizeof(err), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream));
-    h->overlap_ok = false;
+    if (h->last_chain_live) h->overlap_ok = false; else h->chain_flow = false;
     ChainParams CP = h->last_chain;
     CP.tile_done = nullptr;                 // the main stream is behind the sweep: no waiting
     launch_chain(h, CP, h->last_chain_lds);
@@ -1680,7 +1740,7 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
             const int32_t cleared = 0;      // also drops the pick kernel's 'empty' flag of the aborted attempt
             HIPCHK(hipMemcpyAsync(&h->d_ctrl->err, &cleared, sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
-            h->overlap_ok = false;
+            if (h->last_chain_live) h->overlap_ok = false; else h->chain_flow = false;
             chain_done = false;
             HIPCHK(hipStreamSynchronize(main_stream));
             h->stream = main_stream;       // rerun on the main stream, after the sweep

@@ -409,10 +409,26 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         }
         std::vector<LineOut> los(static_cast<size_t>(nt));
         // one parallel region: the line ranges, plus whatever independent work the caller brought along
+        static const bool trace = getenv("BOSSX_STAGE_TIMING") != nullptr;
+        std::vector<double> tb, te;
+        const auto r0 = std::chrono::steady_clock::now();
+        if (trace) { tb.assign(size_t(nt + in.extra_n), 0.0); te.assign(size_t(nt + in.extra_n), 0.0); }
         pool_run(nt + in.extra_n, [&](int t) {
+            if (trace) tb[size_t(t)] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count();
             if (t < nt) parse_lines(cuts[size_t(t)], cuts[size_t(t) + 1], in.min_len, los[size_t(t)]);
             else in.extra_fn(t - nt);
+            if (trace) te[size_t(t)] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count();
         });
+        if (trace) {
+            auto stat = [&](int a, int b, const char *what) {
+                if (b <= a) return;
+                double s0 = 1e9, e1 = 0, dsum = 0, dmax = 0;
+                for (int i = a; i < b; ++i) { s0 = std::min(s0, tb[size_t(i)]); e1 = std::max(e1, te[size_t(i)]); dsum += te[size_t(i)] - tb[size_t(i)]; dmax = std::max(dmax, te[size_t(i)] - tb[size_t(i)]); }
+                fprintf(stderr, "  [pass1] %-6s %2d tasks: first start %.3f, last end %.3f, mean %.3f, max %.3f ms\n", what, b - a, s0, e1, dsum / (b - a), dmax);
+            };
+            stat(0, nt, "parse"); stat(nt, nt + in.extra_n, "extra");
+            fprintf(stderr, "  [pass1] region %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count());
+        }
         if (in.after_pass1) in.after_pass1();
         int64_t line_base = 0;
         for (const LineOut &lo : los) {          // first failing line in file order

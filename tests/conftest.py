@@ -3,6 +3,15 @@ import sys
 
 import pytest
 
+# torch brings its own HIP runtime: it has to be loaded BEFORE libbossx.so pulls in the system one,
+# or torch.cuda finds no device in tests that use both (the nccl protocol tests).  Collecting the
+# whole directory does this by accident (test_parallel_gloo imports torch); make it explicit so
+# that any subset of the tests behaves the same.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (REPO, os.path.join(REPO, "tests")):
     if p not in sys.path:
