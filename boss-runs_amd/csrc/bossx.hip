@@ -582,10 +582,11 @@ void run_threads(int nt, F &&fn) {
 }
 
 // 32 bytes per step: a byte is one of A C G T iff a 16-entry table indexed by its low nibble
-// (A = 0x41, C = 0x43, T = 0x54, G = 0x47) gives the byte back
+// (A = 0x41, C = 0x43, T = 0x54, G = 0x47) gives the byte back; the other entries hold a byte
+// whose own low nibble differs from their index, so they can never match
 __attribute__((target("avx2"))) bool bytes_all_acgt_avx2(const char *p, size_t n) {
-    const __m256i lut = _mm256_setr_epi8(0, 0x41, 0, 0x43, 0x54, 0, 0, 0x47, 0, 0, 0, 0, 0, 0, 0, 0,
-                                         0, 0x41, 0, 0x43, 0x54, 0, 0, 0x47, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m256i lut = _mm256_setr_epi8(-1, 0x41, -1, 0x43, 0x54, -1, -1, 0x47, -1, -1, -1, -1, -1, -1, -1, 0,
+                                         -1, 0x41, -1, 0x43, 0x54, -1, -1, 0x47, -1, -1, -1, -1, -1, -1, -1, 0);
     const __m256i low = _mm256_set1_epi8(0x0f);
     __m256i ok = _mm256_set1_epi8(char(0xff));
     size_t i = 0;
@@ -850,9 +851,13 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
         }
         // ---- failures: the first ValueError / KeyError class one in record order; the IndexError
         // class (raised later in the reference, inside _effect_increments) only if nothing else failed
+        auto plan_name = [&](uint32_t i) {
+            const int32_t r = pb.plan_read[i];
+            return std::string(names + name_off[r], size_t(name_off[r + 1] - name_off[r]));
+        };
         for (uint32_t i = 0; i < uint32_t(walk_err.size()); ++i)
             if (walk_err[i] & kWalkParseMask)
-                return fail(h, BOSSX_E_PARSE, "read '" + pb.plan_names[i] + "': " + walk_message(walk_err[i] & kWalkParseMask));
+                return fail(h, BOSSX_E_PARSE, "read '" + plan_name(i) + "': " + walk_message(walk_err[i] & kWalkParseMask));
         if (pb.pre_code) return fail(h, pb.pre_code, pb.pre_msg);
         {
             int64_t best_gi = pb.pre_range_gi;
@@ -860,7 +865,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
             for (uint32_t i = 0; i < uint32_t(walk_err.size()); ++i)
                 if (walk_err[i] && (best_gi < 0 || pb.plan_gi[i] < best_gi)) {
                     best_gi = pb.plan_gi[i];
-                    msg = "read '" + pb.plan_names[i] + "': " + walk_message(walk_err[i]);
+                    msg = "read '" + plan_name(i) + "': " + walk_message(walk_err[i]);
                     break;
                 }
             if (best_gi >= 0) return fail(h, BOSSX_E_RANGE, msg);
@@ -874,7 +879,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                     n_plans, totals[0], totals[1], n_groups);
         }
         pb.plans.clear(); pb.plans.shrink_to_fit();
-        pb.plan_names.clear(); pb.plan_gi.clear();
+        pb.plan_read.clear(); pb.plan_gi.clear();
     }
     if (n_rec) *n_rec = pb.n_rec;
     if (aligned_bases) *aligned_bases = int64_t(pb.total_emit);
@@ -1190,7 +1195,10 @@ int fill_chain_params(bossx_engine *h, const int32_t *windows, const double *mul
     int32_t ring = 0;
     const size_t n_blocks = h->filt.size() * size_t(h->nb) * 2;
     h->chain_ch = 256;
-    if (n_blocks > 256 || getenv("BOSSX_CHAIN_128") || lds_need(256, ring) > 160 * 1024) h->chain_ch = 128;
+    // (the barrier kernel ran two 128-bin blocks per CU when more blocks than CUs were launched; the
+    // barrier-free one hands chunks over through LDS counters, whose latency 128-bin chunks do not amortise)
+    const bool flow = h->matrix_chain && h->chain_flow;
+    if ((n_blocks > 256 && !flow) || getenv("BOSSX_CHAIN_128") || lds_need(256, ring) > 160 * 1024) h->chain_ch = 128;
     if (lds_need(h->chain_ch, ring) > 160 * 1024)
         return fail(h, BOSSX_E_WINDOW, "read-length window exceeds the LDS ring (reads longer than ~1 Mb in the 95th percentile)");
     P.ds = h->d_ds; P.benefit = h->d_benefit; P.ctrl = h->d_ctrl; P.ct = table_of(h);

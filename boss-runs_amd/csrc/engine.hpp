@@ -121,7 +121,7 @@ struct ParsedBatch {
     // device walk: the host stops after the plan pre-pass; `tiles` holds the (tile, barcode) groups
     // with empty segment ranges, the emit runs and segments are produced on the device
     std::vector<MapPlan> plans;
-    std::vector<std::string> plan_names;   // read name per plan (error messages)
+    std::vector<int32_t> plan_read;        // batch index of the read per plan (error messages)
     std::vector<int64_t> plan_gi;          // record-order index per plan (error precedence)
     int pre_code = 0; std::string pre_msg; int64_t pre_gi = -1;      // first KeyError / ValueError class failure of the pre-pass
     int64_t pre_range_gi = -1; std::string pre_range_msg;            // first IndexError class failure of the pre-pass

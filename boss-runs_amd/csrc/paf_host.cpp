@@ -385,13 +385,15 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
     out = ParsedBatch();
     out.emitted_per_contig.assign(contigs.size(), 0);
 
-    // read id -> index in the batch
+    // read id -> index in the batch (built by one task of pass 1's parallel region)
     std::unordered_map<std::string_view, int32_t> read_index;
-    read_index.reserve(size_t(in.n_reads) * 2 + 1);
-    for (int32_t i = 0; i < in.n_reads; ++i) {
-        std::string_view nm(in.names + in.name_off[i], size_t(in.name_off[i + 1] - in.name_off[i]));
-        read_index[nm] = i;   // later duplicates win, like a dict
-    }
+    auto build_read_index = [&]() {
+        read_index.reserve(size_t(in.n_reads) * 2 + 1);
+        for (int32_t i = 0; i < in.n_reads; ++i) {
+            std::string_view nm(in.names + in.name_off[i], size_t(in.name_off[i + 1] - in.name_off[i]));
+            read_index[nm] = i;   // later duplicates win, like a dict
+        }
+    };
 
     // ---- pass 1 (threads over line ranges): lines -> filtered records, in line order; then the
     // best record per query name, groups in first-appearance order --------------------------
@@ -412,10 +414,11 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         static const bool trace = getenv("BOSSX_STAGE_TIMING") != nullptr;
         std::vector<double> tb, te;
         const auto r0 = std::chrono::steady_clock::now();
-        if (trace) { tb.assign(size_t(nt + in.extra_n), 0.0); te.assign(size_t(nt + in.extra_n), 0.0); }
-        pool_run(nt + in.extra_n, [&](int t) {
+        if (trace) { tb.assign(size_t(nt + in.extra_n + 1), 0.0); te.assign(size_t(nt + in.extra_n + 1), 0.0); }
+        pool_run(nt + in.extra_n + 1, [&](int t) {
             if (trace) tb[size_t(t)] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count();
             if (t < nt) parse_lines(cuts[size_t(t)], cuts[size_t(t) + 1], in.min_len, los[size_t(t)]);
+            else if (t == nt + in.extra_n) build_read_index();
             else in.extra_fn(t - nt);
             if (trace) te[size_t(t)] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count();
         });
@@ -426,7 +429,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
                 for (int i = a; i < b; ++i) { s0 = std::min(s0, tb[size_t(i)]); e1 = std::max(e1, te[size_t(i)]); dsum += te[size_t(i)] - tb[size_t(i)]; dmax = std::max(dmax, te[size_t(i)] - tb[size_t(i)]); }
                 fprintf(stderr, "  [pass1] %-6s %2d tasks: first start %.3f, last end %.3f, mean %.3f, max %.3f ms\n", what, b - a, s0, e1, dsum / (b - a), dmax);
             };
-            stat(0, nt, "parse"); stat(nt, nt + in.extra_n, "extra");
+            stat(0, nt, "parse"); stat(nt, nt + in.extra_n, "extra"); stat(nt + in.extra_n, nt + in.extra_n + 1, "index");
             fprintf(stderr, "  [pass1] region %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count());
         }
         if (in.after_pass1) in.after_pass1();
@@ -523,7 +526,8 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         const size_t n_keys = size_t(in.n_tiles) * size_t(in.nbarcodes);
         marks.assign((n_keys + 63) / 64, 0);
         out.plans.reserve(plans.size());
-        out.plan_names.reserve(plans.size());
+        out.plan_read.reserve(plans.size());
+        out.plan_gi.reserve(plans.size());
         size_t seg_cap = 0;
         for (const Plan &pl : plans) {
             if (pl.cidx < 0) continue;
@@ -575,7 +579,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             seg_cap += mp.seg_cap;
             out.emitted_per_contig[size_t(pl.cidx)] += uint64_t(thi - tlo);
             out.plans.push_back(mp);
-            out.plan_names.push_back(r.qname);
+            out.plan_read.push_back(pl.read);
             out.plan_gi.push_back(pl.gi);
         }
         if (cur_emit >= (1ull << 32) - kEmitTile) {

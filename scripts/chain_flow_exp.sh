@@ -3,6 +3,7 @@
 # (gpurun -- bash scripts/chain_flow_exp.sh)
 mkdir -p gpurun_out/flow
 ./scripts/mfma_chain_floor.bin
+
 timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -q --durations=5 > gpurun_out/flow/pytest.log 2>&1
 echo "pytest rc=$?" | tee -a gpurun_out/flow/pytest.log
 tail -4 gpurun_out/flow/pytest.log
@@ -17,4 +18,4 @@ d=json.loads(sys.stdin.read())
 print('ms_per_step %.3f kernels_only %.3f chain %.3f sweep %.3f ns/bin %.2f stage %.3f' % (d['ms_per_step'], d['kernels_only_ms'], d['kernels']['benefit_chain']['avg_ms'], d['kernels']['site_sweep']['avg_ms'], d['chain_latency']['ns_per_bin_longest'], d['host']['stage_batch_ms_mean']))"
 done
 done
-BOSSX_STAGE_TIMING=1 timeout 300 python3 scripts/front_end_timing.py chr20_21 2>&1 | grep -E "pass1|stage_batch" | tail -24
+

@@ -1,7 +1,8 @@
 // Floor of the move_sum recurrence on the FP64 matrix core (gfx950): cycles per 4-bin step of
 //   (a) a dependent chain of v_mfma_f64_4x4x4_4b_f64 alone,
 //   (b) the chain kernel's pair: CARRY op on the chain + PREFIX op hanging off the previous carry,
-//   (c) the pair plus one ds_read_b64 and one ds_write_b64 per step (the kernel's whole step).
+//   (c) the pair plus one ds_read_b64 and one ds_write_b64 per step (the barrier kernel's whole step),
+//   (d) ONE op per step plus the operand read and the carry store (the flow kernel's chain wave).
 // Prints shader cycles (s_memtime) and wall time (s_memrealtime, 100 MHz) per step.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off scripts/mfma_chain_floor.hip -o scripts/mfma_chain_floor.bin
 #include <hip/hip_runtime.h>
@@ -17,8 +18,8 @@ __global__ __launch_bounds__(64) void floor_kernel(double *out, long long *t, in
     __syncthreads();
     double acc = 1.0 + lane * 1e-3, keep = 0.0;
     const double bm = (lane >> 4) <= (lane & 3) ? 1.0 : 0.0;
-    const long long c0 = clock64(), w0 = wall_clock64();
-    for (int i = 0; i < iters; ++i) {
+    long long c0 = clock64(), w0 = wall_clock64();
+    for (int i = 0; i < (MODE == 3 ? 0 : iters); ++i) {
         double av[64];
         if (MODE == 2) {
 #pragma unroll
@@ -43,6 +44,24 @@ __global__ __launch_bounds__(64) void floor_kernel(double *out, long long *t, in
         }
         if (MODE == 2) s_o[63 * 64 + lane] = prev;
     }
+    if (MODE == 3) {
+        acc = 1.0 + lane * 1e-3;
+        for (int i = 0; i < iters; ++i) {
+            double av[64];
+#pragma unroll
+            for (int u = 0; u < 12; ++u) av[u] = s_a[u * 64 + lane];
+            double prev = 0.0;
+#pragma unroll
+            for (int u = 0; u < 64; ++u) {
+                acc = __builtin_amdgcn_mfma_f64_4x4x4f64(av[u], 1.0, acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (u + 12 < 64) av[u + 12] = s_a[(u + 12) * 64 + lane];
+                s_o[u * 64 + lane] = prev;
+                __builtin_amdgcn_sched_barrier(0);
+                prev = acc;
+            }
+        }
+    }
     const long long c1 = clock64(), w1 = wall_clock64();
     out[lane] = acc + keep + s_o[lane];
     if (lane == 0) { t[0] = c1 - c0; t[1] = w1 - w0; }
@@ -52,11 +71,12 @@ int main() {
     double *out; long long *t;
     hipMalloc(&out, 64 * 8); hipMalloc(&t, 16);
     const int iters = 2000;
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {
         for (int rep = 0; rep < 2; ++rep) {
             if (mode == 0) hipLaunchKernelGGL(floor_kernel<0>, dim3(1), dim3(64), 0, 0, out, t, iters);
             if (mode == 1) hipLaunchKernelGGL(floor_kernel<1>, dim3(1), dim3(64), 0, 0, out, t, iters);
             if (mode == 2) hipLaunchKernelGGL(floor_kernel<2>, dim3(1), dim3(64), 0, 0, out, t, iters);
+            if (mode == 3) hipLaunchKernelGGL(floor_kernel<3>, dim3(1), dim3(64), 0, 0, out, t, iters);
             hipDeviceSynchronize();
         }
         long long h[2]; hipMemcpy(h, t, 16, hipMemcpyDeviceToHost);
