@@ -50,6 +50,7 @@ struct bossx_engine {
     bool matrix_chain = false;      // FP64 matrix-core recurrence passed its start-up self-test
     bool chain_flow = true;         // barrier-free chain kernel (benefit_chain_flow_kernel); cleared by BOSSX_CHAIN_BARRIER=1 or after it aborted
     bool last_chain_live = false;   // the last chain launch ran next to its sweep
+    bool chain_flow_fits = true;    // its LDS (four buffers + the ring for the current windows) fits a CU
     int32_t nb = 1;
 
     std::vector<ContigInfo> contigs;                    // add order (rejected included)
@@ -1197,7 +1198,10 @@ int fill_chain_params(bossx_engine *h, const int32_t *windows, const double *mul
     h->chain_ch = 256;
     // (the barrier kernel ran two 128-bin blocks per CU when more blocks than CUs were launched; the
     // barrier-free one hands chunks over through LDS counters, whose latency 128-bin chunks do not amortise)
-    const bool flow = h->matrix_chain && h->chain_flow;
+    // static LDS of the barrier-free kernel: four difference buffers, four carry buffers, flags
+    const size_t flow_static = size_t(kFlowBufs) * kChainRows * (256 + 2) * 8 + size_t(kFlowBufs) * kChainRows * (256 / 4 / 2 + 2) * 8 + 2048;
+    { int32_t r256 = 0; lds_need(256, r256); h->chain_flow_fits = flow_static + size_t(r256) * 8 <= size_t(160) * 1024; }
+    const bool flow = h->matrix_chain && h->chain_flow && h->chain_flow_fits && !getenv("BOSSX_CHAIN_128");
     if ((n_blocks > 256 && !flow) || getenv("BOSSX_CHAIN_128") || lds_need(256, ring) > 160 * 1024) h->chain_ch = 128;
     if (lds_need(h->chain_ch, ring) > 160 * 1024)
         return fail(h, BOSSX_E_WINDOW, "read-length window exceeds the LDS ring (reads longer than ~1 Mb in the 95th percentile)");
@@ -1223,15 +1227,15 @@ void launch_chain_variant(dim3 grid, dim3 block, size_t lds, hipStream_t stream,
     }
     hipLaunchKernelGGL((benefit_chain_kernel<MATRIX, LIVE, CH>), grid, block, lds, stream, P);
 }
-template <bool LIVE, int CH>
+template <bool LIVE, int CH, int CE>
 void launch_chain_flow(dim3 grid, dim3 block, size_t lds, hipStream_t stream, const ChainParams &P) {
     static size_t allowed = 0;
     if (lds > allowed) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_flow_kernel<LIVE, CH>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_flow_kernel<LIVE, CH, CE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         allowed = lds;
     }
-    hipLaunchKernelGGL((benefit_chain_flow_kernel<LIVE, CH>), grid, block, lds, stream, P);
+    hipLaunchKernelGGL((benefit_chain_flow_kernel<LIVE, CH, CE>), grid, block, lds, stream, P);
 }
 }  // extern "C++"
 
@@ -1241,7 +1245,9 @@ void launch_chain(bossx_engine *h, const ChainParams &P, size_t lds, hipStream_t
     const dim3 grid(uint32_t(h->filt.size() * size_t(h->nb) * 2)), block(kChainThreads);
     const bool live = P.tile_done != nullptr;
     const int ch = h->chain_ch;
-    const size_t fixed = 2 * 2 * size_t(kChainRows) * size_t(ch + 2) * 8;     // static tiles of this instantiation
+    const bool use_flow = h->matrix_chain && h->chain_flow && ch == 256 && h->chain_flow_fits;
+    const size_t fixed = use_flow ? size_t(kFlowBufs) * kChainRows * (256 + 2) * 8 + size_t(kFlowBufs) * kChainRows * (256 / 4 / 2 + 2) * 8 + 2048
+                                  : 2 * 2 * size_t(kChainRows) * size_t(ch + 2) * 8;     // static tiles of this instantiation
     if (live && grid.x <= 8 && fixed + lds < size_t(140) * 1024) {
         // A few long chains next to a running sweep: ask for enough LDS that no sweep block fits on
         // the chain's CU (less than the smallest sweep block's 22 KB stays free), otherwise the
@@ -1249,9 +1255,10 @@ void launch_chain(bossx_engine *h, const ChainParams &P, size_t lds, hipStream_t
         lds = size_t(140) * 1024 - fixed;
     }
     h->last_chain_live = live;
-    if (h->matrix_chain && h->chain_flow) {
-        if (ch == 256) { if (live) launch_chain_flow<true, 256>(grid, block, lds, stream, P); else launch_chain_flow<false, 256>(grid, block, lds, stream, P); }
-        else { if (live) launch_chain_flow<true, 128>(grid, block, lds, stream, P); else launch_chain_flow<false, 128>(grid, block, lds, stream, P); }
+    if (h->matrix_chain && h->chain_flow && ch == 256 && h->chain_flow_fits) {
+        static const bool ce4 = getenv("BOSSX_FLOW_CE4") != nullptr;     // a carry every 4th step instead of every 2nd
+        if (ce4) { if (live) launch_chain_flow<true, 256, 4>(grid, block, lds, stream, P); else launch_chain_flow<false, 256, 4>(grid, block, lds, stream, P); }
+        else { if (live) launch_chain_flow<true, 256, 2>(grid, block, lds, stream, P); else launch_chain_flow<false, 256, 2>(grid, block, lds, stream, P); }
     } else if (h->matrix_chain) {
         if (ch == 256) { if (live) launch_chain_variant<true, true, 256>(grid, block, lds, stream, P); else launch_chain_variant<true, false, 256>(grid, block, lds, stream, P); }
         else { if (live) launch_chain_variant<true, true, 128>(grid, block, lds, stream, P); else launch_chain_variant<true, false, 128>(grid, block, lds, stream, P); }

@@ -80,6 +80,7 @@ std::string_view strip(std::string_view s) {
 struct Group {
     Rec best;
     int64_t key_q, key_dp;
+    int32_t read = -1;       // index of the read in the batch (-1: the name is not in the batch)
 };
 
 struct CigarTable {
@@ -438,19 +439,31 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             if (lo.err_line) { err = "PAF line " + std::to_string(line_base + lo.err_line) + lo.err_msg; return BOSSX_E_PARSE; }
             line_base += lo.n_lines;
         }
-        std::unordered_map<std::string_view, int32_t> group_of;
+        // best record per query name, groups in first-appearance order.  Names are resolved to batch
+        // indices here (one hash lookup per record); only names that are NOT in the batch — a KeyError
+        // for the reference — need a map of their own
+        std::vector<int32_t> group_of_read(size_t(in.n_reads), -1);
+        std::unordered_map<std::string_view, int32_t> group_of_unknown;
         size_t n_recs = 0;
         for (const LineOut &lo : los) n_recs += lo.recs.size();
-        group_of.reserve(n_recs * 2 + 1);
         groups.reserve(n_recs);
         for (LineOut &lo : los) {
             for (Rec &r : lo.recs) {
-                auto it = group_of.find(std::string_view(r.qname));
-                if (it == group_of.end()) {
-                    groups.push_back(Group{std::move(r), r.mapq, r.as});
-                    group_of.emplace(std::string_view(groups.back().best.qname), int32_t(groups.size() - 1));
+                const auto ri = read_index.find(std::string_view(r.qname));
+                int32_t *slot = nullptr;
+                int32_t unknown_slot = -1;
+                if (ri != read_index.end()) slot = &group_of_read[size_t(ri->second)];
+                else {
+                    auto it = group_of_unknown.find(std::string_view(r.qname));
+                    if (it != group_of_unknown.end()) unknown_slot = it->second;
+                    slot = &unknown_slot;
+                }
+                if (*slot < 0) {
+                    groups.push_back(Group{std::move(r), r.mapq, r.as, ri != read_index.end() ? ri->second : -1});
+                    if (ri != read_index.end()) *slot = int32_t(groups.size() - 1);
+                    else group_of_unknown.emplace(std::string_view(groups.back().best.qname), int32_t(groups.size() - 1));
                 } else {
-                    Group &g = groups[size_t(it->second)];
+                    Group &g = groups[size_t(*slot)];
                     // argsort by (mapq, AS), last element wins; stable for ties (paf.py:716-721)
                     if (r.mapq > g.key_q || (r.mapq == g.key_q && r.as >= g.key_dp)) {
                         g.key_q = r.mapq; g.key_dp = r.as;
@@ -477,12 +490,11 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
     for (size_t gi = 0; gi < groups.size(); ++gi) {
         const Rec &r = groups[gi].best;
         auto pre_fail = [&](int code, std::string msg) { pre_err.group = int64_t(gi); pre_err.code = code; pre_err.msg = std::move(msg); };
-        auto ri = read_index.find(std::string_view(r.qname));
-        if (ri == read_index.end()) {
+        if (groups[gi].read < 0) {
             pre_fail(BOSSX_E_KEY, "read '" + r.qname + "' is mapped in the PAF but absent from the batch");
             break;                      // seqs[rec.qname], sequences.py:708/713
         }
-        const int32_t read = ri->second;
+        const int32_t read = groups[gi].read;
         int32_t cidx = -1;
         auto ci = contig_index.find(r.tname);
         if (ci != contig_index.end()) cidx = ci->second;
