@@ -32,7 +32,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 GPU_CLOCK_GHZ = 2.4         # MI355X_MICROARCH.md: peak engine clock
-CHAIN_FLOOR_CYCLES = 13.0   # one dependent FP64 matrix op (52 cycles) per 4 recurrence steps: scripts/mfma_f64_probe.hip
+CHAIN_FLOOR_CYCLES = 5.1    # one dependent FP64 matrix op (20.4 cycles with accumulate forwarding) per 4 recurrence steps: scripts/mfma_chain_floor.hip
 
 WORKLOADS = {
     # name: (contig lengths, names, ploidy, nbarcodes, reject, preload depth)
@@ -573,7 +573,7 @@ def main():
                            "ms_per_step = decision-update wall-clock, PAF text in host memory -> masks in host memory",
             "kernels": kern, "kernels_resident_loop": kern_res, "dominant_kernel_by_time": dom,
             # the chain is a serial FP64 recurrence (1 % of the data): its bound is the dependent
-            # matrix-op latency, not HBM — 52 cycles per 4 bins measured (scripts/mfma_f64_probe.hip)
+            # matrix-op latency, not HBM — 20.4 cycles per 4 bins measured (scripts/mfma_chain_floor.hip)
             "chain_latency": {"kernel": "benefit_chain", "bound": "dependent-op latency",
                               "bins_total": int(eng.merged_bins), "bins_longest_contig": int(longest_bins),
                               "ns_per_bin_longest": 1e6 * kern["benefit_chain"]["avg_ms"] / max(longest_bins, 1),
@@ -582,7 +582,9 @@ def main():
                               "on_fp64_matrix_core": eng.matrix_chain,
                               "runs_next_to_sweep": not os.environ.get("BOSSX_NO_OVERLAP"),
                               "note": "exact serial recurrence (bottleneck.move_sum): an update cannot be shorter than "
-                                      "chain_floor_ms = bins of the longest contig x 13 cycles / 2.4 GHz on any GPU count"},
+                                      "chain_floor_ms = bins of the longest contig x 5.1 cycles / 2.4 GHz on any GPU count (the "
+                                      "dependent-op latency alone; feeding operands and taking the carries out of the chain "
+                                      "wave costs 6.5 cycles per bin at best, scripts/mfma_chain_groups.hip)"},
             "host": {"stage_batch_ms_mean": 1e3 * float(np.mean(t_stage)),
                      "batch_generation_s": t_gen,
                      "note": "stage_batch = native PAF/CIGAR parse + upload of one batch (inside ms_per_step)"},

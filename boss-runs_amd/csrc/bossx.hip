@@ -1199,7 +1199,7 @@ int fill_chain_params(bossx_engine *h, const int32_t *windows, const double *mul
     // (the barrier kernel ran two 128-bin blocks per CU when more blocks than CUs were launched; the
     // barrier-free one hands chunks over through LDS counters, whose latency 128-bin chunks do not amortise)
     // static LDS of the barrier-free kernel: four difference buffers, four carry buffers, flags
-    const size_t flow_static = size_t(kFlowBufs) * kChainRows * (256 + 2) * 8 + size_t(kFlowBufs) * kChainRows * (256 / 4 / 2 + 2) * 8 + 2048;
+    const size_t flow_static = size_t(kFlowBufs) * kChainRows * (256 + 256 / 4 + 2) * 8 + size_t(kFlowBufs) * kChainRows * (256 / 4 / 2 + 2) * 8 + 2048;
     { int32_t r256 = 0; lds_need(256, r256); h->chain_flow_fits = flow_static + size_t(r256) * 8 <= size_t(160) * 1024; }
     const bool flow = h->matrix_chain && h->chain_flow && h->chain_flow_fits && !getenv("BOSSX_CHAIN_128");
     if ((n_blocks > 256 && !flow) || getenv("BOSSX_CHAIN_128") || lds_need(256, ring) > 160 * 1024) h->chain_ch = 128;
@@ -1209,6 +1209,7 @@ int fill_chain_params(bossx_engine *h, const int32_t *windows, const double *mul
     P.B = h->B; P.nb = h->nb; P.ring = ring; P.gate = 0;
     P.tile_done = nullptr; P.epoch = h->epoch; P.wait_ticks = 200000000ll;   // 2 s
     P.never_ready = 0;
+    { const char *dbg = getenv("BOSSX_FLOW_DEBUG"); P.debug = dbg ? atoi(dbg) : 0; }
     P.zero_stats = nullptr; P.n_zero = 0;
     P.probe = getenv("BOSSX_CHAIN_PROBE") ? reinterpret_cast<long long *>(h->d_stats + kStatWords + 8) : nullptr;
     P.max_limit = std::min<int64_t>(h->B, h->n_sites_all / kWindow);
@@ -1246,7 +1247,7 @@ void launch_chain(bossx_engine *h, const ChainParams &P, size_t lds, hipStream_t
     const bool live = P.tile_done != nullptr;
     const int ch = h->chain_ch;
     const bool use_flow = h->matrix_chain && h->chain_flow && ch == 256 && h->chain_flow_fits;
-    const size_t fixed = use_flow ? size_t(kFlowBufs) * kChainRows * (256 + 2) * 8 + size_t(kFlowBufs) * kChainRows * (256 / 4 / 2 + 2) * 8 + 2048
+    const size_t fixed = use_flow ? size_t(kFlowBufs) * kChainRows * (256 + 256 / 4 + 2) * 8 + size_t(kFlowBufs) * kChainRows * (256 / 4 / 2 + 2) * 8 + 2048
                                   : 2 * 2 * size_t(kChainRows) * size_t(ch + 2) * 8;     // static tiles of this instantiation
     if (live && grid.x <= 8 && fixed + lds < size_t(140) * 1024) {
         // A few long chains next to a running sweep: ask for enough LDS that no sweep block fits on
