@@ -517,6 +517,13 @@ def main():
     base2 = eng.kernel_stats()
     elapsed_res = timed(barrier, lambda: [R.step_resident(i, b, s) for i, (b, s) in enumerate(zip(sel, summ))])
     kern_res = kernel_table(eng.kernel_stats(), base2)
+    # ---- and once more with every tile swept at every update (BOSSX_INCREMENTAL=0): the streaming form
+    # of the sweep kernel on this workload, for the roofline of the kernel as opposed to the update
+    os.environ["BOSSX_INCREMENTAL"] = "0"
+    base3 = eng.kernel_stats()
+    timed(barrier, lambda: [R.step_resident(i, b, s) for i, (b, s) in enumerate(zip(sel, summ))])
+    kern_full = kernel_table(eng.kernel_stats(), base3)
+    os.environ.pop("BOSSX_INCREMENTAL", None)
     eng.enable_timing(False)
     # event overhead check: the resident loop once more without events
     elapsed_res_noev = timed(barrier, lambda: [R.step_resident(i, b, s) for i, (b, s) in enumerate(zip(sel, summ))])
@@ -566,9 +573,14 @@ def main():
                          "traffic_source": traffic_src, "traffic_commit": traffic_commit,
                          "traffic_same_commit": bool(commit and traffic_commit and commit[:12] == str(traffic_commit)[:12]),
                          "algorithmic_bytes": kern[roof_k]["bytes"], "avg_launch_ms": kern[roof_k]["avg_ms"],
+                         "full_sweep": {"avg_launch_ms": kern_full[roof_k]["avg_ms"], "algorithmic_bytes": kern_full[roof_k]["bytes"],
+                                        "achieved": kern_full[roof_k]["gbs"], "frac": (kern_full[roof_k]["gbs"] or 0.0) / HBM_PEAK_GBS,
+                                        "note": "the same batches with every tile swept (BOSSX_INCREMENTAL=0), resident loop"},
                          "note": "site_sweep = the sweep launches of one update (fused CIGAR expansion + coverage "
-                                 "increment + scoring + bin sums); HIP events on the engine stream over the timed region; "
-                                 "roofline_large = the same kernel on an HBM-sized working set"},
+                                 "increment + scoring + bin sums) as they ran in the timed region — only the tiles that "
+                                 "receive bases when fewer than half do (the others keep their bin sums; algorithmic bytes "
+                                 "count the swept tiles only); HIP events on the engine stream; full_sweep = every tile "
+                                 "swept; roofline_large = the same kernel on an HBM-sized working set"},
             "metric_note": "value = Mbp scored/s (reference positions brought up to date per second); "
                            "ms_per_step = decision-update wall-clock, PAF text in host memory -> masks in host memory",
             "kernels": kern, "kernels_resident_loop": kern_res, "dominant_kernel_by_time": dom,

@@ -1016,13 +1016,13 @@ int launch_sweep(bossx_engine *h) {
     // touched tiles are swept; the others keep their bin sums, and the bucket sums are kept current
     // by per-tile differences.  The reference recomputes everything every update (sequences.py:419,
     // reference.py:157-161,196-199); the results are identical.  BOSSX_INCREMENTAL=0 / 1 forces it off /
-    // on whenever legal; by default it is used when fewer than 1/8 of the tiles are touched (above
-    // that the touched tiles dominate the sweep anyway).
+    // on whenever legal; by default it is used when fewer than half of the tiles are touched (above
+    // that the one dense launch over all tiles is used: chr20+21, 29 % touched, 0.59 -> 0.28 ms).
     if (h->last_thr.size() != thr.size()) h->last_thr.assign(thr.size(), INT32_MIN);
     bool thr_changed = false;
     for (size_t k = 0; k < thr.size(); ++k) thr_changed = thr_changed || thr[k] != h->last_thr[k];
     const char *inc_env = getenv("BOSSX_INCREMENTAL");
-    const bool want_inc = inc_env ? atoi(inc_env) != 0 : n_touched * 8 < size_t(h->n_tiles);
+    const bool want_inc = inc_env ? atoi(inc_env) != 0 : n_touched * 2 < size_t(h->n_tiles);
     const bool full = h->full_sweep_needed || h->touched_dirty || thr_changed || split || !want_inc;
     // The chain of this update may run NEXT TO the sweep (second stream, tiles handed over as they
     // are published) — worth it only where the sweep is long against the chain: the concurrent
@@ -1199,7 +1199,7 @@ int fill_chain_params(bossx_engine *h, const int32_t *windows, const double *mul
     // (the barrier kernel ran two 128-bin blocks per CU when more blocks than CUs were launched; the
     // barrier-free one hands chunks over through LDS counters, whose latency 128-bin chunks do not amortise)
     // static LDS of the barrier-free kernel: four difference buffers, four carry buffers, flags
-    const size_t flow_static = size_t(kFlowBufs) * kChainRows * (256 + 256 / 4 + 2) * 8 + size_t(kFlowBufs) * kChainRows * (256 / 4 / 2 + 2) * 8 + 2048;
+    const size_t flow_static = size_t(3) * kChainRows * (256 + 2) * 8 + size_t(3) * kChainRows * (256 / 4 + 2) * 8 + 2048;
     { int32_t r256 = 0; lds_need(256, r256); h->chain_flow_fits = flow_static + size_t(r256) * 8 <= size_t(160) * 1024; }
     const bool flow = h->matrix_chain && h->chain_flow && h->chain_flow_fits && !getenv("BOSSX_CHAIN_128");
     if ((n_blocks > 256 && !flow) || getenv("BOSSX_CHAIN_128") || lds_need(256, ring) > 160 * 1024) h->chain_ch = 128;
@@ -1228,15 +1228,15 @@ void launch_chain_variant(dim3 grid, dim3 block, size_t lds, hipStream_t stream,
     }
     hipLaunchKernelGGL((benefit_chain_kernel<MATRIX, LIVE, CH>), grid, block, lds, stream, P);
 }
-template <bool LIVE, int CH, int CE>
+template <bool LIVE, int CH>
 void launch_chain_flow(dim3 grid, dim3 block, size_t lds, hipStream_t stream, const ChainParams &P) {
     static size_t allowed = 0;
     if (lds > allowed) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_flow_kernel<LIVE, CH, CE>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_flow_kernel<LIVE, CH>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         allowed = lds;
     }
-    hipLaunchKernelGGL((benefit_chain_flow_kernel<LIVE, CH, CE>), grid, block, lds, stream, P);
+    hipLaunchKernelGGL((benefit_chain_flow_kernel<LIVE, CH>), grid, block, lds, stream, P);
 }
 }  // extern "C++"
 
@@ -1247,7 +1247,7 @@ void launch_chain(bossx_engine *h, const ChainParams &P, size_t lds, hipStream_t
     const bool live = P.tile_done != nullptr;
     const int ch = h->chain_ch;
     const bool use_flow = h->matrix_chain && h->chain_flow && ch == 256 && h->chain_flow_fits;
-    const size_t fixed = use_flow ? size_t(kFlowBufs) * kChainRows * (256 + 256 / 4 + 2) * 8 + size_t(kFlowBufs) * kChainRows * (256 / 4 / 2 + 2) * 8 + 2048
+    const size_t fixed = use_flow ? size_t(3) * kChainRows * (256 + 2) * 8 + size_t(3) * kChainRows * (256 / 4 + 2) * 8 + 2048
                                   : 2 * 2 * size_t(kChainRows) * size_t(ch + 2) * 8;     // static tiles of this instantiation
     if (live && grid.x <= 8 && fixed + lds < size_t(140) * 1024) {
         // A few long chains next to a running sweep: ask for enough LDS that no sweep block fits on
@@ -1257,9 +1257,7 @@ void launch_chain(bossx_engine *h, const ChainParams &P, size_t lds, hipStream_t
     }
     h->last_chain_live = live;
     if (h->matrix_chain && h->chain_flow && ch == 256 && h->chain_flow_fits) {
-        static const bool ce4 = getenv("BOSSX_FLOW_CE4") != nullptr;     // a carry every 4th step instead of every 2nd
-        if (ce4) { if (live) launch_chain_flow<true, 256, 4>(grid, block, lds, stream, P); else launch_chain_flow<false, 256, 4>(grid, block, lds, stream, P); }
-        else { if (live) launch_chain_flow<true, 256, 2>(grid, block, lds, stream, P); else launch_chain_flow<false, 256, 2>(grid, block, lds, stream, P); }
+        if (live) launch_chain_flow<true, 256>(grid, block, lds, stream, P); else launch_chain_flow<false, 256>(grid, block, lds, stream, P);
     } else if (h->matrix_chain) {
         if (ch == 256) { if (live) launch_chain_variant<true, true, 256>(grid, block, lds, stream, P); else launch_chain_variant<true, false, 256>(grid, block, lds, stream, P); }
         else { if (live) launch_chain_variant<true, true, 128>(grid, block, lds, stream, P); else launch_chain_variant<true, false, 128>(grid, block, lds, stream, P); }

@@ -8,9 +8,9 @@ timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -q --durations=5 > 
 echo "pytest rc=$?" | tee -a gpurun_out/flow/pytest.log
 tail -4 gpurun_out/flow/pytest.log
 grep -q "failed" gpurun_out/flow/pytest.log && grep "FAILED" gpurun_out/flow/pytest.log
-timeout 120 python3 scripts/probe_chain.py 2>&1 | tail -19; BOSSX_FLOW_CE4=1 timeout 120 python3 scripts/probe_chain.py 2>&1 | tail -19
+timeout 120 python3 scripts/probe_chain.py 2>&1 | tail -19
 for wl in chr20_21 ecoli; do
-for env in "X=1" "BOSSX_CHAIN_BARRIER=1" "BOSSX_OVERLAP=1" "BOSSX_NO_OVERLAP=1" "BOSSX_INCREMENTAL=1" "BOSSX_FLOW_CE4=1"; do
+for env in "X=1" "BOSSX_CHAIN_BARRIER=1" "BOSSX_OVERLAP=1" "BOSSX_NO_OVERLAP=1" "BOSSX_INCREMENTAL=1"; do
   echo "== $wl $env"
   env $env timeout 600 python bench.py --workload $wl --no-cpu-baseline --no-others --no-large 2>/dev/null | python3 -c "
 import json,sys
