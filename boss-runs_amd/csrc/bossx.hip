@@ -50,7 +50,8 @@ struct bossx_engine {
     bool matrix_chain = false;      // FP64 matrix-core recurrence passed its start-up self-test
     bool chain_flow = true;         // barrier-free chain kernel (benefit_chain_flow_kernel); cleared by BOSSX_CHAIN_BARRIER=1 or after it aborted
     bool last_chain_live = false;   // the last chain launch ran next to its sweep
-    bool chain_flow_fits = true;    // its LDS (four buffers + the ring for the current windows) fits a CU
+    bool chain_flow_fits = true;    // its LDS (buffers + the ring for the current windows) fits a CU
+    int chain_flow_bufs = 4;        // difference buffers it is launched with (5 when the LDS allows)
     int32_t nb = 1;
 
     std::vector<ContigInfo> contigs;                    // add order (rejected included)
@@ -1028,7 +1029,7 @@ int launch_sweep(bossx_engine *h) {
     // are published) — worth it only where the sweep is long against the chain: the concurrent
     // chain variant is ~10 % slower than the serial one (agent-scope loads, flag polling), which
     // costs more than a 0.6 ms sweep hidden behind a 4 ms chain gives back (chr20+21: 6.57 vs
-    // 6.26 ms per update).  Estimates: 2.5 TB/s for the swept tiles, 5.6 ns per bin of the longest
+    // 6.26 ms per update).  Estimates: 2.5 TB/s for the swept tiles, 4.4 ns per bin of the longest
     // contig.  BOSSX_OVERLAP=1 forces it on, BOSSX_NO_OVERLAP=1 off.
     bool publish = h->overlap_ok && h->host_armed;
     if (publish && !getenv("BOSSX_OVERLAP")) {
@@ -1038,7 +1039,7 @@ int launch_sweep(bossx_engine *h) {
         const double tile_bytes = double(kTileSites) * h->nb * 11.0;
         // (a tile that receives bases costs ~2.5 tiles, an ingested base ~3 ps on top)
         const double sweep_ms = (swept_tiles + 1.5 * double(n_touched)) * tile_bytes / 2.5e9 + (h->pending_slot >= 0 ? h->pending_emit : 0.0) * 3e-9;
-        const double chain_ms = double(longest) * 5.6e-6;
+        const double chain_ms = double(longest) * 4.4e-6;
         publish = sweep_ms >= 0.3 * chain_ms;
     }
     {
@@ -1198,9 +1199,15 @@ int fill_chain_params(bossx_engine *h, const int32_t *windows, const double *mul
     h->chain_ch = 256;
     // (the barrier kernel ran two 128-bin blocks per CU when more blocks than CUs were launched; the
     // barrier-free one hands chunks over through LDS counters, whose latency 128-bin chunks do not amortise)
-    // static LDS of the barrier-free kernel: four difference buffers, four carry buffers, flags
-    const size_t flow_static = size_t(3) * kChainRows * (256 + 2) * 8 + size_t(3) * kChainRows * (256 / 4 + 2) * 8 + 2048;
-    { int32_t r256 = 0; lds_need(256, r256); h->chain_flow_fits = flow_static + size_t(r256) * 8 <= size_t(160) * 1024; }
+    // static LDS of the barrier-free kernel: NBD difference buffers, NBD-1 carry buffers, flags
+    auto flow_static = [](int nbd) { return size_t(nbd) * kChainRows * (256 + 2) * 8 + size_t(nbd - 1) * kChainRows * (256 / 4 + 2) * 8 + 2048; };
+    {
+        int32_t r256 = 0; lds_need(256, r256);
+        const size_t cap = size_t(160) * 1024;
+        // (five buffers measured the same as four at 111 Mb: four leave more room for the ring of long-read windows)
+        h->chain_flow_bufs = flow_static(5) + size_t(r256) * 8 <= cap && getenv("BOSSX_FLOW_BUFS5") ? 5 : 4;
+        h->chain_flow_fits = flow_static(4) + size_t(r256) * 8 <= cap;
+    }
     const bool flow = h->matrix_chain && h->chain_flow && h->chain_flow_fits && !getenv("BOSSX_CHAIN_128");
     if ((n_blocks > 256 && !flow) || getenv("BOSSX_CHAIN_128") || lds_need(256, ring) > 160 * 1024) h->chain_ch = 128;
     if (lds_need(h->chain_ch, ring) > 160 * 1024)
@@ -1228,15 +1235,15 @@ void launch_chain_variant(dim3 grid, dim3 block, size_t lds, hipStream_t stream,
     }
     hipLaunchKernelGGL((benefit_chain_kernel<MATRIX, LIVE, CH>), grid, block, lds, stream, P);
 }
-template <bool LIVE, int CH>
+template <bool LIVE, int CH, int NBD>
 void launch_chain_flow(dim3 grid, dim3 block, size_t lds, hipStream_t stream, const ChainParams &P) {
     static size_t allowed = 0;
     if (lds > allowed) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_flow_kernel<LIVE, CH>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_flow_kernel<LIVE, CH, NBD>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         allowed = lds;
     }
-    hipLaunchKernelGGL((benefit_chain_flow_kernel<LIVE, CH>), grid, block, lds, stream, P);
+    hipLaunchKernelGGL((benefit_chain_flow_kernel<LIVE, CH, NBD>), grid, block, lds, stream, P);
 }
 }  // extern "C++"
 
@@ -1247,7 +1254,7 @@ void launch_chain(bossx_engine *h, const ChainParams &P, size_t lds, hipStream_t
     const bool live = P.tile_done != nullptr;
     const int ch = h->chain_ch;
     const bool use_flow = h->matrix_chain && h->chain_flow && ch == 256 && h->chain_flow_fits;
-    const size_t fixed = use_flow ? size_t(3) * kChainRows * (256 + 2) * 8 + size_t(3) * kChainRows * (256 / 4 + 2) * 8 + 2048
+    const size_t fixed = use_flow ? size_t(h->chain_flow_bufs) * kChainRows * (256 + 2) * 8 + size_t(h->chain_flow_bufs - 1) * kChainRows * (256 / 4 + 2) * 8 + 2048
                                   : 2 * 2 * size_t(kChainRows) * size_t(ch + 2) * 8;     // static tiles of this instantiation
     if (live && grid.x <= 8 && fixed + lds < size_t(140) * 1024) {
         // A few long chains next to a running sweep: ask for enough LDS that no sweep block fits on
@@ -1257,7 +1264,9 @@ void launch_chain(bossx_engine *h, const ChainParams &P, size_t lds, hipStream_t
     }
     h->last_chain_live = live;
     if (h->matrix_chain && h->chain_flow && ch == 256 && h->chain_flow_fits) {
-        if (live) launch_chain_flow<true, 256>(grid, block, lds, stream, P); else launch_chain_flow<false, 256>(grid, block, lds, stream, P);
+        // as many buffers between the stages as the LDS holds next to the ring of the current windows
+        if (h->chain_flow_bufs == 5) { if (live) launch_chain_flow<true, 256, 5>(grid, block, lds, stream, P); else launch_chain_flow<false, 256, 5>(grid, block, lds, stream, P); }
+        else { if (live) launch_chain_flow<true, 256, 4>(grid, block, lds, stream, P); else launch_chain_flow<false, 256, 4>(grid, block, lds, stream, P); }
     } else if (h->matrix_chain) {
         if (ch == 256) { if (live) launch_chain_variant<true, true, 256>(grid, block, lds, stream, P); else launch_chain_variant<true, false, 256>(grid, block, lds, stream, P); }
         else { if (live) launch_chain_variant<true, true, 128>(grid, block, lds, stream, P); else launch_chain_variant<true, false, 128>(grid, block, lds, stream, P); }
