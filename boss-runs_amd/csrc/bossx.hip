@@ -799,6 +799,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
         if (up_err == hipSuccess) up_err = hipStreamWaitEvent(h->stream, h->ev_up, 0);
     };
     ParsedBatch pb;
+    const auto t_pre = std::chrono::steady_clock::now();
     if (host_walk) {
         if ((rc = stage_host_walk(h, st, in, summary, pb))) return rc;
         HIPCHK(up_err);
@@ -812,6 +813,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
         if (rc) { hipStreamSynchronize(h->stream); return fail(h, rc, err); }     // inputs are borrowed for the call only
         HIPCHK(up_err);
         const auto t1 = std::chrono::steady_clock::now();
+        auto t_launched = t1;
         const uint32_t n_plans = uint32_t(pb.plans.size()), n_groups = uint32_t(pb.tiles.size());
         uint32_t totals[4] = {0, 0, 0, 0};
         std::vector<uint32_t> walk_err;
@@ -840,6 +842,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
             hipLaunchKernelGGL(walk_scan_kernel, dim3(1), dim3(1024), 0, h->stream, W);
             hipLaunchKernelGGL(cigar_walk_kernel<true>, grid, block, 0, h->stream, W);
             HIPCHK(hipGetLastError());
+            t_launched = std::chrono::steady_clock::now();
             uint32_t *back = reinterpret_cast<uint32_t *>(h->h_plan_pin + plan_bytes + group_bytes);
             HIPCHK(hipMemcpyAsync(back, W.totals, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
@@ -876,8 +879,9 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
         if (getenv("BOSSX_CHECK_DEVICE_WALK") && (rc = check_device_walk(h, st, in, pb, totals[1]))) return rc;
         if (timing) {
             const auto t2 = std::chrono::steady_clock::now();
-            fprintf(stderr, "[bossx] stage_batch: host parse %.2f ms, device walk + uploads %.2f ms (%u mappings, %u runs, %u segments, %u groups)\n",
-                    std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(),
+            fprintf(stderr, "[bossx] stage_batch: before the parse %.2f, host parse %.2f ms, plan upload + launches %.2f, waiting for uploads + device walk %.2f ms (%u mappings, %u runs, %u segments, %u groups)\n",
+                    std::chrono::duration<double, std::milli>(t_pre - t0).count(), std::chrono::duration<double, std::milli>(t1 - t_pre).count(),
+                    std::chrono::duration<double, std::milli>(t_launched - t1).count(), std::chrono::duration<double, std::milli>(t2 - t_launched).count(),
                     n_plans, totals[0], totals[1], n_groups);
         }
         pb.plans.clear(); pb.plans.shrink_to_fit();
@@ -1026,13 +1030,17 @@ int launch_sweep(bossx_engine *h) {
     const bool want_inc = inc_env ? atoi(inc_env) != 0 : n_touched * 2 < size_t(h->n_tiles);
     const bool full = h->full_sweep_needed || h->touched_dirty || thr_changed || split || !want_inc;
     // The chain of this update may run NEXT TO the sweep (second stream, tiles handed over as they
-    // are published) — worth it only where the sweep is long against the chain: the concurrent
-    // chain variant is ~10 % slower than the serial one (agent-scope loads, flag polling), which
-    // costs more than a 0.6 ms sweep hidden behind a 4 ms chain gives back (chr20+21: 6.57 vs
-    // 6.26 ms per update).  Estimates: 2.5 TB/s for the swept tiles, 4.4 ns per bin of the longest
-    // contig.  BOSSX_OVERLAP=1 forces it on, BOSSX_NO_OVERLAP=1 off.
-    bool publish = h->overlap_ok && h->host_armed;
-    if (publish && !getenv("BOSSX_OVERLAP")) {
+    // are published).  Measured on MI355X it no longer pays by default: the concurrent chain variant
+    // is ~8 % slower than the serial one (agent-scope loads, flag polling), a publishing sweep is
+    // slower than a plain one (ordered tile hand-out, write-through bin stores), chain blocks take
+    // CUs (LDS) from the sweep, and the incremental sweep has shrunk what there is to hide — E. coli
+    // 0.42 vs 0.47 ms of kernels, chr20+21 3.26 vs 3.32, but 10 x 5 Mb x 8 barcodes 2.3 vs 2.0 the
+    // other way.  So: off unless BOSSX_OVERLAP=1 (always) or BOSSX_OVERLAP=auto (where the sweep
+    // is estimated at >= 0.3 of the chain: 2.5 TB/s for the swept tiles, 4.4 ns per bin of the longest
+    // contig).  BOSSX_NO_OVERLAP=1 rules it out.
+    const char *ov_env = getenv("BOSSX_OVERLAP");
+    bool publish = h->overlap_ok && h->host_armed && ov_env != nullptr;
+    if (publish && !strcmp(ov_env, "auto")) {
         int64_t longest = 0;
         for (int32_t fi : h->filt) if (!h->contigs[size_t(fi)].remote) longest = std::max(longest, h->contigs[size_t(fi)].T + 1);
         const double swept_tiles = full ? double(h->n_tiles) : double(n_touched);

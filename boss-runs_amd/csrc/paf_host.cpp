@@ -23,16 +23,12 @@
 #include <string_view>
 #include <thread>
 
-#ifdef BOSSX_PARSE_TIMING
 #include <chrono>
 #include <cstdio>
+// phase times of parse_paf_batch, printed when BOSSX_STAGE_TIMING is set
 #define PT(x) auto x = std::chrono::steady_clock::now()
 #define PTMS(a, b) std::chrono::duration<double, std::milli>(b - a).count()
-#define PTREPORT() fprintf(stderr, "index+pass1 %.2f  plan %.2f  walk %.2f  merge %.2f ms\n", PTMS(T0, T1), PTMS(T1, T2), PTMS(T2, T3), PTMS(T3, T4))
-#else
-#define PT(x)
-#define PTREPORT()
-#endif
+#define PTREPORT() do { if (getenv("BOSSX_STAGE_TIMING")) fprintf(stderr, "  [parse] names+pass1+groups %.3f  plan %.3f  walk/plans %.3f  merge %.3f ms\n", PTMS(T0, T1), PTMS(T1, T2), PTMS(T2, T3), PTMS(T3, T4)); } while (0)
 
 namespace bossx {
 namespace {

@@ -574,8 +574,9 @@ def test_chain_next_to_sweep_equals_serial(in_tmp):
 
 
 def test_default_schedule_at_40mb_equals_serial(in_tmp):
-    """At >= 32 Mb the chain runs next to the sweep by default (and with 4 barcodes the sweep is
-    the split ingest-only + plain form).  Five updates on a 36 Mb + 6 Mb reference with deep
+    """With BOSSX_OVERLAP=auto the chain runs next to the sweep where the engine estimates the sweep
+    to be long against the chain (here it is: 4 barcodes, the split ingest-only + plain form of
+    the sweep).  Five updates on a 36 Mb + 6 Mb reference with deep
     preloaded coverage must give bit-identical bin sums, benefits, thresholds and masks to the
     serial schedule (BOSSX_NO_OVERLAP=1) — the hand-off is exercised while the sweep is really
     busy, and the chain's L1 is warm from the previous update."""
@@ -616,7 +617,7 @@ def test_default_schedule_at_40mb_equals_serial(in_tmp):
                 if v is not None:
                     os.environ[k] = v
     serial = run("sched_serial", {"BOSSX_NO_OVERLAP": "1"})
-    default = run("sched_default", {})
+    default = run("sched_default", {"BOSSX_OVERLAP": "auto"})       # the engine's own estimate decides per update
     assert serial[-1][0] is not None
     for k, (a, b) in enumerate(zip(serial, default)):
         assert a[0] == b[0] and a[1] == b[1], k
