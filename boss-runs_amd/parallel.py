@@ -22,7 +22,7 @@ import logging
 import numpy as np
 
 from . import _lib
-from .runs import BossRuns, MULT, FX_SHIFT, choose_threshold
+from .runs import BossRuns, MULT, FX_SHIFT, choose_threshold, ubar_to_float
 
 
 def partition_contigs(weights, world):
@@ -385,7 +385,7 @@ class DistributedBossRuns(BossRuns):
         fgrid = np.zeros(counts.shape[0], dtype=np.float64)
         occ = np.nonzero(counts)[0]                      # only occupied bins need the big-int conversion
         fgrid[occ] = limbs_to_float(packed[occ, 1:])
-        ubar0 = float(limbs_to_float(packed[-1, 1:]))
+        ubar0 = ubar_to_float(float(limbs_to_float(packed[-1, 1:])), normaliser)
         threshold, size, uniq = choose_threshold(normaliser, counts, fgrid, ubar0, self.rl_dist.time_cost)
         self.threshold = threshold
         self.last_stats = dict(normaliser=normaliser, exponents=uniq, counts=counts[uniq],

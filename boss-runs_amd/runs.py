@@ -32,6 +32,14 @@ def fx_to_float(lo, hi):
     return ((int(hi) << 64) + int(lo)) / (1 << FX_SHIFT)
 
 
+def ubar_to_float(scaled, normaliser):
+    """The engine accumulates ubar0 = sum(fhat * benefit) scaled by 2^-E, E = frexp exponent of the
+    normaliser (kernels.hip.inc: ubar_scale), so that its fixed point resolves the sum at any
+    magnitude of the scores; this undoes the (exact, power-of-two) scaling."""
+    import math
+    return math.ldexp(scaled, math.frexp(normaliser)[1]) if normaliser > 0 else scaled
+
+
 def choose_threshold(normaliser, counts_all, fgrid_all, ubar0, time_cost):
     """The host tail of Scoring.find_strat_thread (sequences.py:607-646) from the binned
     statistics.  Returns (threshold, strat_size, exponents_unique)."""
@@ -315,7 +323,7 @@ class BossRuns(Boss):
         target = self.ref.n_sites // 100
         counts, fg, ub = self.engine.histogram(normaliser, fhat_c, target_rs, target)
         fgrid = np.array([fx_to_float(lo, hi) for lo, hi in fg])
-        ubar0 = fx_to_float(ub[0], ub[1])
+        ubar0 = ubar_to_float(fx_to_float(ub[0], ub[1]), normaliser)
         threshold, size, uniq = choose_threshold(normaliser, counts, fgrid, ubar0, self.rl_dist.time_cost)
         self.threshold = threshold
         self.last_stats = dict(normaliser=normaliser, exponents=uniq, counts=counts[uniq],

@@ -2,6 +2,8 @@
 INFRASTRUCTURE).  It lets the multi-rank protocol in `boss_runs_amd.parallel` run on CPUs
 (gloo, world_size 2) where no HIP device exists: same stage-wise interface, same ownership
 rules for remote contigs, same exact 128-bit statistics."""
+import math
+
 import numpy as np
 
 from oracle.contig import OContig
@@ -158,6 +160,7 @@ class FakeEngine:
         counts = np.zeros(1088, dtype=np.int64)
         fg = [0] * 1088
         ub = 0
+        norm_e = math.frexp(float(normaliser))[1]
         fexp = fhat_c.shape[0] * 20
         d1 = max(target_rs - fexp, 0)
         d2 = max(target - target_rs, 0)
@@ -178,7 +181,7 @@ class FakeEngine:
                 fh = float(fhat_c[g2 // 20, s])
                 for b in range(self.nb):
                     x = float(c.additional_benefit[src - self.bin_off[k], s, b])
-                    ub += _fx(fh * x)
+                    ub += _fx(math.ldexp(fh * x, -norm_e))      # the engine's convention: relative to the normaliser's binade
                     if x != 0.0:
                         e = abs(int(np.frexp(x / normaliser)[1]))
                         counts[e] += 1

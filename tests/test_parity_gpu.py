@@ -246,6 +246,35 @@ def test_deep_coverage_and_long_reads_vs_oracle(in_tmp):
     assert int(o.contigs["deepA"].coverage.sum(axis=(1, 2)).max()) >= 100    # ~100x over the 8 barcodes
 
 
+def test_saturated_coverage_vs_oracle(in_tmp):
+    """(Nearly) every site capped at depth 30, their scores equal to `tiny`: benefits of ~1e-300.
+    The engine's exact ubar0 accumulator is scaled to the normaliser's binade, so its fixed point
+    still resolves the sum (with an absolute 2^-100 granularity the sum vanished and the threshold
+    came out one bin off the reference's — found at E. coli after ~60 batches)."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.runs import BossRuns
+    from oracle.pipeline import OracleRuns
+    contigs = synth.make_reference([130_000, 101_000], seed=21, names=["satA", "satB"])
+    strs = [(n, synth.codes_to_str(c)) for n, c in contigs]
+    args = BossConfig()
+    args.general.name = "sat"
+    runs = BossRuns(args)
+    runs.init(contigs=strs)
+    o = OracleRuns(strs)
+    for b in range(4):
+        batch = synth.make_batch(contigs, 2500, seed=700 + b, mean_len=9000.0, max_len=30000)
+        o.process_batch(batch["paf"], batch["seqs"], read_lengths=batch["read_lengths"])
+        runs.rl_dist.update(batch["read_lengths"])
+        runs.process_batch_paf(batch["paf"], batch["seqs"])
+        assert runs.threshold == o.threshold, b
+        for n, oc in o.contigs.items():
+            assert np.array_equal(runs.contigs[n].strat, oc.strat), (b, n)
+    # the regime was reached: a threshold far below anything a scored site produces
+    assert float(np.median(o.contigs["satA"].coverage.sum(axis=(1, 2)))) >= 30
+    assert o.threshold < 1e-200
+
+
 def test_full_size_ecoli_properties(in_tmp):
     """BASELINE configs[1] at full size (4.64 Mb, 4000-read batches) through size-independent
     properties: conservation of ingested bases, bucket sums = coverage sums, idempotence of an
@@ -813,7 +842,7 @@ def test_stagewise_consumers_recover_from_a_timed_out_chain(in_tmp, monkeypatch)
     not the aborted one.  Reference values: the same update on an engine that never overlaps."""
     from boss_runs_amd import synth
     from boss_runs_amd.config import BossConfig
-    from boss_runs_amd.runs import BossRuns, MULT, choose_threshold, fx_to_float
+    from boss_runs_amd.runs import BossRuns, MULT, choose_threshold, fx_to_float, ubar_to_float
     contigs = synth.make_reference([300_700, 123_400], seed=31, names=["s1", "s2"])
     strs = [(n, synth.codes_to_str(c)) for n, c in contigs]
     batches = [synth.make_batch(contigs, 1200, seed=950 + b, mean_len=4000.0) for b in range(3)]
@@ -843,7 +872,7 @@ def test_stagewise_consumers_recover_from_a_timed_out_chain(in_tmp, monkeypatch)
                 fh, trs = r.read_starts.fhat_compact()
                 counts, fg, ub = eng.histogram(mx, fh, trs, r.ref.n_sites // 100)
                 fgrid = np.array([fx_to_float(lo, hi) for lo, hi in fg])
-                thr, size, uniq = choose_threshold(mx, counts, fgrid, fx_to_float(ub[0], ub[1]), r.rl_dist.time_cost)
+                thr, size, uniq = choose_threshold(mx, counts, fgrid, ubar_to_float(fx_to_float(ub[0], ub[1]), mx), r.rl_dist.time_cost)
                 eng.apply_threshold(thr)
                 out.append((mx, thr, counts.copy(), eng.export(0, "benefit"), eng.get_strat(0), eng.get_strat(1)))
             else:
