@@ -41,7 +41,9 @@ class FhatDesc(C.Structure):
 class UpdateParams(C.Structure):
     _fields_ = [("windows", C.c_int32 * NWIN), ("flags", C.c_int32), ("mult", C.c_double * 10),
                 ("tc", C.c_double), ("bucket_threshold", C.c_double), ("fhat_c", C.c_void_p),
-                ("n_windows", C.c_int64), ("target_rs", C.c_int64)]
+                ("n_windows", C.c_int64), ("target_rs", C.c_int64),
+                ("fhat_alpha", C.c_double), ("fhat_den", C.c_double), ("fhat_expected", C.c_double),
+                ("fhat_on_target", C.c_double)]
 
 
 class UpdateResult(C.Structure):
@@ -91,6 +93,8 @@ PROTOTYPES = {
     "bossx_get_bucket_sums": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "bossx_set_bucket_switches": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "bossx_benefit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    "bossx_fhat_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "bossx_fhat_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "bossx_histogram": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(FhatDesc), C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
     "bossx_apply_threshold": (C.c_int, [C.c_void_p, C.c_double]),

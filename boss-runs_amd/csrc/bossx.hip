@@ -33,6 +33,9 @@ struct bossx_engine {
     hipEvent_t ev_up = nullptr;
     hipEvent_t ev_begin = nullptr, ev_chain = nullptr, ev_sweep = nullptr, ev_fhat = nullptr;
     double *h_fhat_pin = nullptr;      // page-locked staging of the compact f-hat
+    double *d_rs_counts = nullptr; int64_t rs_windows = 0;     // read-start counts resident in HBM (bossx_fhat_reset / _add)
+    int64_t *d_rs_keys = nullptr; size_t rs_keys_cap = 0;
+    unsigned long long *d_rs_sums = nullptr;
     uint32_t *d_tile_done = nullptr;   // [n_tiles] sweep -> chain hand-off flags (epoch stamped)
     uint32_t *d_tile_order = nullptr;  // [n_tiles] block -> tile for publishing launches: every contig's two ends first
     uint32_t epoch = 0;
@@ -339,6 +342,9 @@ void bossx_destroy(bossx_engine *h) {
     if (h->ev_sweep) hipEventDestroy(h->ev_sweep);
     if (h->ev_fhat) hipEventDestroy(h->ev_fhat);
     if (h->h_fhat_pin) hipHostFree(h->h_fhat_pin);
+    if (h->d_rs_counts) hipFree(h->d_rs_counts);
+    if (h->d_rs_keys) hipFree(h->d_rs_keys);
+    if (h->d_rs_sums) hipFree(h->d_rs_sums);
     if (h->d_tile_done) hipFree(h->d_tile_done);
     if (h->d_tile_order) hipFree(h->d_tile_order);
     void *ptrs[] = {h->d_cov, h->d_meta, h->d_touched, h->d_strat, h->d_bucket_on, h->d_entropy, h->d_ds,
@@ -1369,6 +1375,32 @@ int upload_fhat(bossx_engine *h, const bossx_fhat_desc *fh) {
     return BOSSX_OK;
 }
 
+// BOSSX_UPDATE_FHAT_RESIDENT: the posterior from the resident counts, straight into d_fhat
+int build_fhat(bossx_engine *h, const bossx_update_params *up) {
+    if (!h->d_rs_counts || h->rs_windows != up->n_windows) return fail(h, BOSSX_E_INVALID, "resident f-hat: bossx_fhat_reset has not installed counts for this many windows");
+    int rc;
+    if (up->n_windows * 2 > h->fhat_cap) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->d_fhat) HIPCHK(hipFree(h->d_fhat));
+        if (h->h_fhat_pin) HIPCHK(hipHostFree(h->h_fhat_pin));
+        h->h_fhat_pin = nullptr;
+        h->fhat_cap = up->n_windows * 2 + 64;
+        if ((rc = dev_alloc(h, &h->d_fhat, size_t(h->fhat_cap)))) return rc;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->h_fhat_pin), size_t(h->fhat_cap) * sizeof(double), hipHostMallocDefault));
+    }
+    FhatParams P;
+    P.counts = h->d_rs_counts; P.fhat = h->d_fhat; P.sums = h->d_rs_sums;
+    P.n = up->n_windows; P.rep = 20; P.d = up->target_rs - 20 * up->n_windows;
+    P.alpha = up->fhat_alpha; P.den = up->fhat_den; P.expected = up->fhat_expected; P.on_target = up->fhat_on_target;
+    HIPCHK(hipMemsetAsync(h->d_rs_sums, 0, 6 * sizeof(unsigned long long), h->stream));
+    const uint32_t blocks = uint32_t(std::min<int64_t>((up->n_windows * 2 + 255) / 256, 2048));
+    hipLaunchKernelGGL(fhat_terms_kernel, dim3(std::max(blocks, 1u)), dim3(256), 0, h->stream, P);
+    hipLaunchKernelGGL(fhat_scale_kernel, dim3(std::max(blocks, 1u)), dim3(256), 0, h->stream, P);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev_fhat, h->stream));
+    return BOSSX_OK;
+}
+
 int launch_hist(bossx_engine *h, const bossx_fhat_desc *fh, int gate, bool clear = true) {
     const int64_t target = h->n_sites_all / kWindow;
     if (clear) HIPCHK(hipMemsetAsync(h->d_stats, 0, kStatWords * sizeof(unsigned long long), h->stream));
@@ -1412,6 +1444,46 @@ int launch_mask(bossx_engine *h, int gate, bool with_tails = false, const PickPa
 }
 
 }  // namespace
+
+int bossx_fhat_reset(bossx_engine *h, const double *counts, int64_t n_windows) {
+    if (!h || !h->finalized || n_windows < 0) return fail(h, BOSSX_E_INVALID, "bad fhat_reset call");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int rc;
+    if (n_windows != h->rs_windows || !h->d_rs_counts) {
+        if (h->d_rs_counts) HIPCHK(hipFree(h->d_rs_counts));
+        h->d_rs_counts = nullptr; h->rs_windows = 0;
+        if ((rc = dev_alloc(h, &h->d_rs_counts, size_t(std::max<int64_t>(n_windows * 2, 1))))) return rc;
+        h->rs_windows = n_windows;
+    }
+    if (!h->d_rs_sums && (rc = dev_alloc(h, &h->d_rs_sums, size_t(8)))) return rc;
+    const size_t bytes = size_t(n_windows) * 2 * sizeof(double);
+    if (counts) HIPCHK(hipMemcpy(h->d_rs_counts, counts, bytes, hipMemcpyHostToDevice));
+    else if (bytes) HIPCHK(hipMemset(h->d_rs_counts, 0, bytes));
+    return BOSSX_OK;
+}
+
+int bossx_fhat_add(bossx_engine *h, const int64_t *keys, int32_t n_keys) {
+    if (!h || !h->finalized || n_keys < 0 || (n_keys > 0 && !keys)) return fail(h, BOSSX_E_INVALID, "bad fhat_add call");
+    if (!h->d_rs_counts) return fail(h, BOSSX_E_INVALID, "fhat_add before fhat_reset");
+    if (n_keys == 0) return BOSSX_OK;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int rc;
+    if (size_t(n_keys) > h->rs_keys_cap) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->d_rs_keys) HIPCHK(hipFree(h->d_rs_keys));
+        h->d_rs_keys = nullptr; h->rs_keys_cap = 0;
+        const size_t cap = size_t(n_keys) * 2 + 1024;
+        if ((rc = dev_alloc(h, &h->d_rs_keys, cap))) return rc;
+        h->rs_keys_cap = cap;
+    }
+    // (a small pageable copy: the keys of one batch, <= 32 KB; the call returns once they are staged)
+    HIPCHK(hipMemcpyAsync(h->d_rs_keys, keys, size_t(n_keys) * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(fhat_add_kernel, dim3(uint32_t((n_keys + 255) / 256)), dim3(256), 0, h->stream,
+                       h->d_rs_counts, h->d_rs_keys, n_keys, h->rs_windows * 2);
+    HIPCHK(hipGetLastError());
+    return BOSSX_OK;
+}
 
 int bossx_histogram(bossx_engine *h, double normaliser, const bossx_fhat_desc *fh, int64_t *counts,
                     uint64_t *fgrid_fx, uint64_t *ubar0_fx) {
@@ -1691,7 +1763,8 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
     bossx_fhat_desc fh{up->fhat_c, up->n_windows, 20, up->target_rs, h->n_sites_all / kWindow};
     ChainParams CP;
     size_t lds = 0;
-    const bool have_strategy_inputs = up->fhat_c != nullptr;
+    const bool fhat_resident = (up->flags & BOSSX_UPDATE_FHAT_RESIDENT) != 0 && up->fhat_c == nullptr;
+    const bool have_strategy_inputs = up->fhat_c != nullptr || fhat_resident;
     if (have_strategy_inputs) {
         if ((rc = fill_chain_params(h, up->windows, up->mult, CP, lds))) return rc;
     }
@@ -1715,7 +1788,7 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
     hipStream_t const main_stream = h->stream;
     struct Restore { bossx_engine *h; hipStream_t s; ~Restore() { h->stream = s; } } restore{h, main_stream};
     // f-hat goes up on the (idle) main stream right away, while the chain still runs
-    if (have_strategy_inputs && (rc = upload_fhat(h, &fh))) return rc;
+    if (have_strategy_inputs && (rc = fhat_resident ? build_fhat(h, up) : upload_fhat(h, &fh))) return rc;
     if (have_strategy_inputs && chain_done && h->chain_on_stream2 && (up->flags & BOSSX_UPDATE_SWEEP_DONE)) {
         // ev_fhat was recorded on the main stream behind the sweep and the bucket switches of this
         // update, so it covers them as well: one (long signalled) cross-queue dependency

@@ -318,8 +318,22 @@ class Engine:
         self._ck(self.lib.bossx_get_max(self.h, C.byref(mx)))
         return mx.value
 
+    # ---- read-start counts resident in HBM (readstartdist.py:24-82) --------------------------------
+    fhat_resident = True        # update() accepts `fhat_model` instead of the host-built posterior
+
+    def fhat_reset(self, counts, n_windows):
+        """bossx_fhat_reset: install counts float64[n_windows, 2] (None: zeros)."""
+        c = None if counts is None else np.ascontiguousarray(counts, dtype=np.float64)
+        self._ck(self.lib.bossx_fhat_reset(self.h, None if c is None else c.ctypes.data, int(n_windows)))
+
+    def fhat_add(self, keys):
+        """bossx_fhat_add: one read start at every flat index (window * 2 + strand) of `keys`."""
+        k = np.ascontiguousarray(keys, dtype=np.int64)
+        if k.size:
+            self._ck(self.lib.bossx_fhat_add(self.h, k.ctypes.data, int(k.size)))
+
     def update(self, bucket_threshold, windows=None, mult=None, tc=0.0, fhat_c=None, target_rs=0,
-               want_stats=False, bits=False):
+               want_stats=False, bits=False, fhat_model=None):
         """bossx_update: one fused decision update.  Without `fhat_c` only the sweep and the
         bucket switches run.  Returns dict(updated, any_on, threshold, normaliser, ubar0,
         strat_size, n_bins, contig_on[, counts, fgrid_fx, ubar_fx]); masks land in
@@ -327,6 +341,19 @@ class Engine:
         packed 8:1 in `self.strat_bits` (bossx_get_strat_bits layout)."""
         up = _lib.UpdateParams()
         f = None
+        if fhat_model is not None and fhat_c is None:
+            # the posterior is rebuilt on the device from the resident counts (BOSSX_UPDATE_FHAT_RESIDENT)
+            w = np.ascontiguousarray(windows, dtype=np.int32)
+            m = np.ascontiguousarray(mult, dtype=np.float64)
+            assert w.shape == (_lib.NWIN,) and m.shape == (10,)
+            for i in range(_lib.NWIN):
+                up.windows[i] = int(w[i])
+            for i in range(10):
+                up.mult[i] = float(m[i])
+            up.n_windows = int(fhat_model["n_windows"])
+            up.target_rs = int(fhat_model["target_rs"])
+            up.fhat_alpha = float(fhat_model["alpha"]); up.fhat_den = float(fhat_model["den"])
+            up.fhat_expected = float(fhat_model["expected"]); up.fhat_on_target = float(fhat_model["on_target"])
         if fhat_c is not None:
             w = np.ascontiguousarray(windows, dtype=np.int32)
             m = np.ascontiguousarray(mult, dtype=np.float64)
@@ -342,8 +369,10 @@ class Engine:
         up.tc = float(tc)
         up.bucket_threshold = float(bucket_threshold)
         up.flags = 1 if getattr(self, "_sweep_done", False) else 0
+        if fhat_model is not None and fhat_c is None:
+            up.flags |= 8
         done = getattr(self, "_benefit_done", None)
-        if done is not None and fhat_c is not None and done == tuple(int(x) for x in windows):
+        if done is not None and (fhat_c is not None or fhat_model is not None) and done == tuple(int(x) for x in windows):
             up.flags |= 2
         self._sweep_done = False
         self._benefit_done = None

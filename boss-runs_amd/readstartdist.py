@@ -33,6 +33,33 @@ class ReadStartDist:
         self.total_len = int(np.sum([a.shape[0] for a in self.read_starts.values()]))
         self.target_size = int(np.sum([c.length for c in contigs.values()]) // 100)
         self.on_target = 1
+        self._engine = None          # attach_engine: the counts are mirrored in HBM, a batch adds its starts there too
+        self._csum = 0.0
+
+    def attach_engine(self, engine):
+        """Keep the counts resident on the device as well (bossx_fhat_reset / bossx_fhat_add): the
+        fused update then rebuilds the posterior there from the O(1) part of the model
+        (`fhat_model`), without the O(windows) host pass and upload of `fhat_compact`."""
+        self._engine = engine
+        self.resync_engine()
+
+    def resync_engine(self):
+        """After the host arrays were written directly (checkpoint restore)."""
+        self._csum = float(np.sum(self._merged))
+        if self._engine is not None:
+            self._engine.fhat_reset(self._merged, self._merged.shape[0])
+
+    def fhat_model(self):
+        """The scalars of update_f_pointmass (readstartdist.py:95-117) for the device build."""
+        n = self._merged.shape[0]
+        csum = self._csum
+        rhs = (self.alpha / (2 * n * self.alpha + csum))
+        beta_num = np.exp(betaln(self.alpha, ((2 * n - 1) * self.alpha + csum)))
+        beta_denom = np.exp(betaln(self.alpha, ((2 * n - 1) * self.alpha))) or 1e-20
+        p0_bit = self.p0 / (self.p0 + (1 - self.p0))
+        expected = (1 - p0_bit * (beta_num / beta_denom)) * rhs
+        return dict(n_windows=n, target_rs=self.target_size, alpha=self.alpha, den=2 * n * self.alpha + csum,
+                    expected=float(expected), on_target=self.on_target)
 
     def merge(self):
         return self._merged
@@ -63,6 +90,9 @@ class ReadStartDist:
         key = (off[ci[keep]] + w) * 2 + rev[keep]
         # O(batch), not O(windows): 1.5 M windows at 3.1 Gb
         np.add.at(self._merged.reshape(-1), key, 1.0)
+        self._csum += float(key.size)
+        if self._engine is not None:
+            self._engine.fhat_add(key)
 
     def fhat_compact(self):
         """-> (fhat_c float64[n_windows, 2] already multiplied by the on-target normaliser,

@@ -9,6 +9,7 @@ hold the PAF text (simulations, tests, benchmarks).  Without the HIP extension o
 class raises at `init()`; there is no numpy fallback.
 """
 import logging
+import os
 import time
 from pathlib import Path
 
@@ -147,6 +148,8 @@ class BossRuns(Boss):
         self.engine.finalize(score0=haploid.score0[0], ent0=haploid.ent0[0])
         score, entropy = self.scoring.tables()
         self.engine.set_lut(score, entropy)
+        if getattr(self.engine, "fhat_resident", False) and not os.environ.get("BOSSX_HOST_FHAT"):
+            self.read_starts.attach_engine(self.engine)       # read-start counts mirrored in HBM (readstartdist.py)
         self.threshold = None
         self.last_stats = {}
         self.write_masks = True
@@ -260,13 +263,18 @@ class BossRuns(Boss):
         # Before anything is switched on the strategy stages are skipped on the device as well;
         # they are still enqueued (gated) so that the update in which the first bucket flips
         # produces masks, as in the reference.
-        fhat_c, target_rs = self.read_starts.fhat_compact()
         have_rl = hasattr(self.rl_dist, "time_cost")
         use_bits = self._fused and self.mask_format != "npz"   # masks come back packed 8:1 (masks.py)
         if have_rl:
             windows = np.concatenate(([400 // 100], self.rl_dist.approx_ccl // 100)).astype(np.int32)
-            res = eng.update(thr, windows, MULT, tc=self.rl_dist.time_cost // 100, fhat_c=fhat_c,
-                             target_rs=target_rs, want_stats=self.keep_stats, bits=use_bits)
+            if self.read_starts._engine is not None:
+                # update_f_pointmass on the device, from the counts resident there
+                res = eng.update(thr, windows, MULT, tc=self.rl_dist.time_cost // 100,
+                                 fhat_model=self.read_starts.fhat_model(), want_stats=self.keep_stats, bits=use_bits)
+            else:
+                fhat_c, target_rs = self.read_starts.fhat_compact()
+                res = eng.update(thr, windows, MULT, tc=self.rl_dist.time_cost // 100, fhat_c=fhat_c,
+                                 target_rs=target_rs, want_stats=self.keep_stats, bits=use_bits)
         else:
             res = eng.update(thr)
         for cname, cont in self.contigs_filt.items():
@@ -381,4 +389,5 @@ class BossRuns(Boss):
             c.strat = z["strat_" + n].astype(bool)
             c.switched_on[:] = z["on_" + n]
             self.read_starts.read_starts[n][:] = z["starts_" + n]
+        self.read_starts.resync_engine()
 

@@ -209,6 +209,13 @@ typedef struct bossx_fhat_desc {
     int64_t target;            /* Reference.n_sites // 100                                    */
 } bossx_fhat_desc;
 
+/* Read-start counts resident in HBM (ReadStartDist.read_starts merged over the non-rejected
+ * contigs, readstartdist.py:24-41): bossx_fhat_reset installs `counts` float64[n_windows][2]
+ * (NULL: zeros); bossx_fhat_add adds one start at each flat index of `keys`
+ * (count_read_starts / update_read_starts, readstartdist.py:43-82).                            */
+int bossx_fhat_reset(bossx_engine *h, const double *counts, int64_t n_windows);
+int bossx_fhat_add(bossx_engine *h, const int64_t *keys, int32_t n_keys);
+
 int bossx_histogram(bossx_engine *h, double normaliser, const bossx_fhat_desc *fh,
                     int64_t *counts, uint64_t *fgrid_fx, uint64_t *ubar0_fx);
 
@@ -227,6 +234,8 @@ int bossx_apply_threshold(bossx_engine *h, double threshold);
 #define BOSSX_UPDATE_SWEEP_DONE   1  /* bossx_update_begin already enqueued sweep + bucket switches */
 #define BOSSX_UPDATE_BENEFIT_DONE 2  /* bossx_update_benefit already enqueued the move_sum chain     */
 #define BOSSX_UPDATE_STRAT_BITS   4  /* `strat_all` receives the masks packed 8:1 (bossx_get_strat_bits) */
+#define BOSSX_UPDATE_FHAT_RESIDENT 8 /* fhat_c is NULL: the posterior is rebuilt on the device from the resident
+                                      * read-start counts (bossx_fhat_reset / bossx_fhat_add) and the fhat_* scalars */
 typedef struct bossx_update_params {
     int32_t windows[BOSSX_NWIN];
     int32_t flags;
@@ -236,6 +245,12 @@ typedef struct bossx_update_params {
     const double *fhat_c;       /* as bossx_fhat_desc                                           */
     int64_t n_windows;
     int64_t target_rs;
+    /* BOSSX_UPDATE_FHAT_RESIDENT: ReadStartDist.update_f_pointmass (readstartdist.py:86-152) on the
+     * device; the O(1) part of the model comes from the host                                     */
+    double  fhat_alpha;         /* prior alpha                                                   */
+    double  fhat_den;           /* 2 N alpha + sum(counts)                                       */
+    double  fhat_expected;      /* point-mass expectation of a window without read starts (:104-117) */
+    double  fhat_on_target;     /* ReadStartDist.on_target                                       */
 } bossx_update_params;
 
 typedef struct bossx_update_result {
