@@ -384,11 +384,13 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
 
     // read id -> index in the batch (built by one task of pass 1's parallel region)
     std::unordered_map<std::string_view, int32_t> read_index;
+    bool dup_names = false;
+    auto read_name = [&](int32_t i) { return std::string_view(in.names + in.name_off[i], size_t(in.name_off[i + 1] - in.name_off[i])); };
     auto build_read_index = [&]() {
         read_index.reserve(size_t(in.n_reads) * 2 + 1);
         for (int32_t i = 0; i < in.n_reads; ++i) {
-            std::string_view nm(in.names + in.name_off[i], size_t(in.name_off[i + 1] - in.name_off[i]));
-            read_index[nm] = i;   // later duplicates win, like a dict
+            auto ins = read_index.insert_or_assign(read_name(i), i);   // later duplicates win, like a dict
+            if (!ins.second) dup_names = true;
         }
     };
 
@@ -443,20 +445,33 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         size_t n_recs = 0;
         for (const LineOut &lo : los) n_recs += lo.recs.size();
         groups.reserve(n_recs);
+        // A mapper reports its hits read by read, in the order the reads were handed over: the read
+        // of a record is the previous record's or the next one in the batch far more often than not,
+        // and comparing two names is much cheaper than hashing one.  (Not with duplicate names in
+        // the batch: a dict keeps the last one.)
+        int32_t cursor = -1;
         for (LineOut &lo : los) {
             for (Rec &r : lo.recs) {
-                const auto ri = read_index.find(std::string_view(r.qname));
+                int32_t read = -1;
+                const std::string_view qn(r.qname);
+                if (!dup_names && cursor >= 0 && read_name(cursor) == qn) read = cursor;
+                else if (!dup_names && cursor + 1 < in.n_reads && read_name(cursor + 1) == qn) read = cursor + 1;
+                else {
+                    const auto ri = read_index.find(qn);
+                    if (ri != read_index.end()) read = ri->second;
+                }
+                if (read >= 0) cursor = read;
                 int32_t *slot = nullptr;
                 int32_t unknown_slot = -1;
-                if (ri != read_index.end()) slot = &group_of_read[size_t(ri->second)];
+                if (read >= 0) slot = &group_of_read[size_t(read)];
                 else {
-                    auto it = group_of_unknown.find(std::string_view(r.qname));
+                    auto it = group_of_unknown.find(qn);
                     if (it != group_of_unknown.end()) unknown_slot = it->second;
                     slot = &unknown_slot;
                 }
                 if (*slot < 0) {
-                    groups.push_back(Group{std::move(r), r.mapq, r.as, ri != read_index.end() ? ri->second : -1});
-                    if (ri != read_index.end()) *slot = int32_t(groups.size() - 1);
+                    groups.push_back(Group{std::move(r), r.mapq, r.as, read});
+                    if (read >= 0) *slot = int32_t(groups.size() - 1);
                     else group_of_unknown.emplace(std::string_view(groups.back().best.qname), int32_t(groups.size() - 1));
                 } else {
                     Group &g = groups[size_t(*slot)];
