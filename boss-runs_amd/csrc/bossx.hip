@@ -1230,7 +1230,6 @@ int fill_chain_params(bossx_engine *h, const int32_t *windows, const double *mul
     P.B = h->B; P.nb = h->nb; P.ring = ring; P.gate = 0;
     P.tile_done = nullptr; P.epoch = h->epoch; P.wait_ticks = 200000000ll;   // 2 s
     P.never_ready = 0;
-    { const char *dbg = getenv("BOSSX_FLOW_DEBUG"); P.debug = dbg ? atoi(dbg) : 0; }
     P.zero_stats = nullptr; P.n_zero = 0;
     P.probe = getenv("BOSSX_CHAIN_PROBE") ? reinterpret_cast<long long *>(h->d_stats + kStatWords + 8) : nullptr;
     P.max_limit = std::min<int64_t>(h->B, h->n_sites_all / kWindow);
@@ -1734,7 +1733,6 @@ int bossx_update_benefit(bossx_engine *h, const int32_t *windows, const double *
         // out from both contig ends and publishes each tile's bin sums (tile_done == epoch); the
         // chain's prefetch wave waits for the tiles of a chunk before reading it.
         HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_begin, 0));
-        if (getenv("BOSSX_LIVE_AFTER")) HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_sweep, 0));   // experiment: the live variant, but after the sweep
         if (!h->max_bits_clear) HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream2));
         CP.tile_done = h->d_tile_done; CP.epoch = h->epoch;
         if (getenv("BOSSX_OVERLAP_SELFTEST")) { CP.never_ready = 1; CP.wait_ticks = 500000; }   // never satisfied: exercises the time-out path
