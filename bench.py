@@ -55,6 +55,8 @@ def parse_args():
                     help="skip the extra sweep-kernel measurement on a 200 Mb contig (HBM-sized working set)")
     ap.add_argument("--no-others", action="store_true",
                     help="skip the short runs of the other single-GPU workloads (`workloads` object)")
+    ap.add_argument("--prepare-only", action="store_true",
+                    help="generate the batches (into BOSSX_BATCH_CACHE) and exit: no GPU is touched")
     ap.add_argument("--track-entropy", action="store_true",
                     help="keep the reference's per-site entropy array current (dead state on the strategy path)")
     return ap.parse_args()
@@ -74,13 +76,27 @@ def _gen_one(job):
 
 
 def generate_batches(jobs):
-    """jobs: list of (reference key, seed, n_reads, nbarcodes) -> list of batches, in order."""
+    """jobs: list of (reference key, seed, n_reads, nbarcodes) -> list of batches, in order.
+    BOSSX_BATCH_CACHE=<dir>: batches are kept there as pickles and reused — the profiling script
+    fills it in a run of its own, so that no process is forked under rocprofv3 (a pool child's
+    exit handler inside the profiler's preloaded tool has hung a counter pass for 46 minutes)."""
     import multiprocessing as mp
+    import pickle
+    cache = os.environ.get("BOSSX_BATCH_CACHE")
+    paths = [os.path.join(cache, "batch_%s_%d_%d_%d.pkl" % j) for j in jobs] if cache else []
+    if cache and all(os.path.exists(p) for p in paths):
+        return [pickle.load(open(p, "rb")) for p in paths]
     n = min(len(jobs), max(1, min(32, (os.cpu_count() or 1))))
     if n <= 1:
-        return [_gen_one(j) for j in jobs]
-    with mp.get_context("fork").Pool(n) as pool:
-        return pool.map(_gen_one, jobs, chunksize=1)
+        out = [_gen_one(j) for j in jobs]
+    else:
+        with mp.get_context("fork").Pool(n) as pool:
+            out = pool.map(_gen_one, jobs, chunksize=1)
+    if cache:
+        os.makedirs(cache, exist_ok=True)
+        for p, b in zip(paths, out):
+            pickle.dump(b, open(p, "wb"), protocol=4)
+    return out
 
 
 def make_reference(workload, rank):
@@ -473,6 +489,8 @@ def main():
     t0 = time.perf_counter()
     allb = generate_batches(jobs)
     t_gen = time.perf_counter() - t0
+    if a.prepare_only:
+        return
     batches, extra = allb[:n_b], allb[n_b]
     other_batches, off = {}, n_b + 1
     for w in others:

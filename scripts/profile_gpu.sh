@@ -13,12 +13,16 @@ mkdir -p "$OUT"
 COMMIT=$(cat "$ROOT/.bossx_commit" 2>/dev/null)
 cd /tmp && export TMPDIR=/tmp
 ARGS="--workload $W --no-cpu-baseline --no-large --no-others --steps 10 --warmup 3 $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o "$W" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_trace.log" 2>&1
+# the batches are generated once, outside the profiler (forked workers + the profiler's preloaded tool
+# have deadlocked at exit); every pass below loads them from the cache
+export BOSSX_BATCH_CACHE=/tmp/bossx_batches_$W
+python3 "$ROOT/bench.py" $ARGS --prepare-only
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o "$W" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_trace.log" 2>&1
 # counter collection serialises kernels: keep the chain after the sweep (it would time out and fall back anyway)
 export BOSSX_NO_OVERLAP=1
 pass() {   # name, counters...
     local name=$1; shift
-    rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -o "$W" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_$name.log" 2>&1 \
+    timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -o "$W" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_$name.log" 2>&1 \
         || echo "counter pass $name failed (see bench_$name.log)"
 }
 pass fetch FETCH_SIZE
