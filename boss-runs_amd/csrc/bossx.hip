@@ -1392,7 +1392,8 @@ int build_fhat(bossx_engine *h, const bossx_update_params *up) {
     P.n = up->n_windows; P.rep = 20; P.d = up->target_rs - 20 * up->n_windows;
     P.alpha = up->fhat_alpha; P.den = up->fhat_den; P.expected = up->fhat_expected; P.on_target = up->fhat_on_target;
     HIPCHK(hipMemsetAsync(h->d_rs_sums, 0, 6 * sizeof(unsigned long long), h->stream));
-    const uint32_t blocks = uint32_t(std::min<int64_t>((up->n_windows * 2 + 255) / 256, 2048));
+    // (few blocks: every wave ends with atomics on the same three accumulators — 2048 blocks spent 45 us queueing there)
+    const uint32_t blocks = uint32_t(std::min<int64_t>((up->n_windows * 2 + 255) / 256, 128));
     hipLaunchKernelGGL(fhat_terms_kernel, dim3(std::max(blocks, 1u)), dim3(256), 0, h->stream, P);
     hipLaunchKernelGGL(fhat_scale_kernel, dim3(std::max(blocks, 1u)), dim3(256), 0, h->stream, P);
     HIPCHK(hipGetLastError());
