@@ -144,7 +144,7 @@ def make_runs(workload, mine, rank, world, device, track_entropy):
     return runs, nb
 
 
-def pmc_traffic(workload, kernel_substr):
+def pmc_traffic(workload, kernel_substr, only=None):
     """HBM bytes per launch of `kernel_substr` from the newest committed rocprofv3 PMC summary
     of this workload (profiles/rNN_<workload>_rocprof_summary.json: FETCH_SIZE and WRITE_SIZE
     from separate --pmc passes, in KB; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).
@@ -156,6 +156,8 @@ def pmc_traffic(workload, kernel_substr):
     d = json.load(open(files[-1]))
     tot, found = 0.0, False
     for name, v in d.get("kernels", {}).items():
+        if only is not None and only not in name:
+            continue
         if kernel_substr in name and "FETCH_SIZE_avg_per_launch" in v and "WRITE_SIZE_avg_per_launch" in v:
             # launches of the variants per update differ (plain + ingest): weight by launches per update
             per_update = v.get("launches_per_update", 1.0)
@@ -570,7 +572,11 @@ def main():
         dom = max(kern, key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"])
         roof_k = "site_sweep"    # the HBM-streaming kernel the roofline is quoted on
         achieved = kern[roof_k]["gbs"] or 0.0
-        traffic, traffic_src, traffic_commit = pmc_traffic(workload, "site_sweep_kernel")
+        # (the profiled run also holds the every-tile sweeps of the full_sweep loop: when the timed region
+        # swept only the tiles that receive bases, its traffic is that of the ingesting launches alone)
+        incremental = kern[roof_k]["bytes"] < 0.99 * kern_full[roof_k]["bytes"]
+        traffic, traffic_src, traffic_commit = pmc_traffic(workload, "site_sweep_kernel",
+                                                           only="site_sweep_kernel<true" if incremental else None)
         commit = current_commit()
         longest_bins = max(c.length // 100 + 1 for c in runs.contigs_filt.values())
         out = {
