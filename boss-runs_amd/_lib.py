@@ -95,6 +95,7 @@ PROTOTYPES = {
     "bossx_benefit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "bossx_fhat_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "bossx_fhat_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "bossx_fhat_build": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double]),
     "bossx_histogram": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(FhatDesc), C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
     "bossx_apply_threshold": (C.c_int, [C.c_void_p, C.c_double]),

@@ -1375,7 +1375,8 @@ int upload_fhat(bossx_engine *h, const bossx_fhat_desc *fh) {
 }
 
 // BOSSX_UPDATE_FHAT_RESIDENT: the posterior from the resident counts, straight into d_fhat
-int build_fhat(bossx_engine *h, const bossx_update_params *up) {
+struct FhatModel { int64_t n_windows, target_rs; double alpha, den, expected, on_target; };
+int build_fhat(bossx_engine *h, const FhatModel *up) {
     if (!h->d_rs_counts || h->rs_windows != up->n_windows) return fail(h, BOSSX_E_INVALID, "resident f-hat: bossx_fhat_reset has not installed counts for this many windows");
     int rc;
     if (up->n_windows * 2 > h->fhat_cap) {
@@ -1390,7 +1391,7 @@ int build_fhat(bossx_engine *h, const bossx_update_params *up) {
     FhatParams P;
     P.counts = h->d_rs_counts; P.fhat = h->d_fhat; P.sums = h->d_rs_sums;
     P.n = up->n_windows; P.rep = 20; P.d = up->target_rs - 20 * up->n_windows;
-    P.alpha = up->fhat_alpha; P.den = up->fhat_den; P.expected = up->fhat_expected; P.on_target = up->fhat_on_target;
+    P.alpha = up->alpha; P.den = up->den; P.expected = up->expected; P.on_target = up->on_target;
     HIPCHK(hipMemsetAsync(h->d_rs_sums, 0, 6 * sizeof(unsigned long long), h->stream));
     // (few blocks: every wave ends with atomics on the same three accumulators — 2048 blocks spent 45 us queueing there)
     const uint32_t blocks = uint32_t(std::min<int64_t>((up->n_windows * 2 + 255) / 256, 128));
@@ -1561,11 +1562,20 @@ static void launch_tails(bossx_engine *h) {
     hipLaunchKernelGGL(export_tails_kernel, dim3(64), dim3(256), 0, h->stream, P, h->d_tails);
 }
 
+int bossx_fhat_build(bossx_engine *h, int64_t n_windows, int64_t target_rs, double alpha, double den, double expected, double on_target) {
+    if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "bad fhat_build call");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const FhatModel fm{n_windows, target_rs, alpha, den, expected, on_target};
+    return build_fhat(h, &fm);
+}
+
 int bossx_dist_hist(bossx_engine *h, const bossx_fhat_desc *fh) {
-    if (!h || !h->finalized || !fh || !fh->fhat_c) return fail(h, BOSSX_E_INVALID, "bad dist_hist call");
+    if (!h || !h->finalized || !fh) return fail(h, BOSSX_E_INVALID, "bad dist_hist call");
     HIPCHK(hipSetDevice(h->cfg.device));
     { int jrc = settle_chain(h); if (jrc) return jrc; }
-    int rc = upload_fhat(h, fh);
+    int rc = BOSSX_OK;
+    if (fh->fhat_c) rc = upload_fhat(h, fh);         // NULL: the posterior bossx_fhat_build left in HBM
+    else if (!h->d_fhat || fh->n_windows * 2 > h->fhat_cap) rc = fail(h, BOSSX_E_INVALID, "dist_hist without f-hat: call bossx_fhat_build first");
     if (rc) return rc;
     if ((rc = launch_hist(h, fh, 1))) return rc;
     hipLaunchKernelGGL(stats_to_limbs_kernel, dim3((BOSSX_HIST_BINS + 1 + 255) / 256), dim3(256), 0, h->stream, h->d_stats,
@@ -1787,7 +1797,8 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
     hipStream_t const main_stream = h->stream;
     struct Restore { bossx_engine *h; hipStream_t s; ~Restore() { h->stream = s; } } restore{h, main_stream};
     // f-hat goes up on the (idle) main stream right away, while the chain still runs
-    if (have_strategy_inputs && (rc = fhat_resident ? build_fhat(h, up) : upload_fhat(h, &fh))) return rc;
+    const FhatModel fm{up->n_windows, up->target_rs, up->fhat_alpha, up->fhat_den, up->fhat_expected, up->fhat_on_target};
+    if (have_strategy_inputs && (rc = fhat_resident ? build_fhat(h, &fm) : upload_fhat(h, &fh))) return rc;
     if (have_strategy_inputs && chain_done && h->chain_on_stream2 && (up->flags & BOSSX_UPDATE_SWEEP_DONE)) {
         // ev_fhat was recorded on the main stream behind the sweep and the bucket switches of this
         // update, so it covers them as well: one (long signalled) cross-queue dependency

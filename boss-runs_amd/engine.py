@@ -280,10 +280,19 @@ class Engine:
         self._ck(self.lib.bossx_device_ptr(self.h, int(which), C.byref(ptr), C.byref(nbytes)))
         return ptr.value, nbytes.value
 
-    def dist_hist(self, fhat_c, target_rs, target):
-        f = np.ascontiguousarray(fhat_c, dtype=np.float64)
-        desc = _lib.FhatDesc(f.ctypes.data, f.shape[0], 20, int(target_rs), int(target))
-        self._keep = f                       # the upload is asynchronous
+    def fhat_build(self, model):
+        """bossx_fhat_build: the posterior from the resident counts, in-stream (`model`: ReadStartDist.fhat_model())."""
+        self._ck(self.lib.bossx_fhat_build(self.h, int(model["n_windows"]), int(model["target_rs"]), float(model["alpha"]),
+                                           float(model["den"]), float(model["expected"]), float(model["on_target"])))
+
+    def dist_hist(self, fhat_c, target_rs, target, n_windows=None):
+        """`fhat_c` None: the posterior built by fhat_build (n_windows required)."""
+        if fhat_c is None:
+            desc = _lib.FhatDesc(None, int(n_windows), 20, int(target_rs), int(target))
+        else:
+            f = np.ascontiguousarray(fhat_c, dtype=np.float64)
+            desc = _lib.FhatDesc(f.ctypes.data, f.shape[0], 20, int(target_rs), int(target))
+            self._keep = f                       # the upload is asynchronous
         self._ck(self.lib.bossx_dist_hist(self.h, C.byref(desc)))
 
     def dist_tails(self):

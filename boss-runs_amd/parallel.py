@@ -312,8 +312,14 @@ class DistributedBossRuns(BossRuns):
                     eng.update_benefit(windows, MULT)            # gated on the (now global) flag
                 eng.dist_tails()                                 # halo rows + normaliser in one buffer
                 dist.all_reduce(self.t_tails, op=MAXOP)          # non-negative, one contributor each: exact
-                fhat_c, target_rs = self.read_starts.fhat_compact()
-                eng.dist_hist(fhat_c, target_rs, self.ref.n_sites // 100)
+                if self.read_starts._engine is not None:
+                    # every rank holds the global read-start counts in HBM: the posterior is rebuilt there
+                    fm = self.read_starts.fhat_model()
+                    eng.fhat_build(fm)
+                    eng.dist_hist(None, fm["target_rs"], self.ref.n_sites // 100, n_windows=fm["n_windows"])
+                else:
+                    fhat_c, target_rs = self.read_starts.fhat_compact()
+                    eng.dist_hist(fhat_c, target_rs, self.ref.n_sites // 100)
                 dist.all_reduce(self.t_limbs, op=SUMOP)
                 eng.dist_pick(self.rl_dist.time_cost // 100)
                 self.comm.n_collectives += 2

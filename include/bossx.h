@@ -215,6 +215,11 @@ typedef struct bossx_fhat_desc {
  * (count_read_starts / update_read_starts, readstartdist.py:43-82).                            */
 int bossx_fhat_reset(bossx_engine *h, const double *counts, int64_t n_windows);
 int bossx_fhat_add(bossx_engine *h, const int64_t *keys, int32_t n_keys);
+/* Rebuild the posterior of update_f_pointmass (readstartdist.py:86-152) in HBM from the resident
+ * counts, asynchronously on the engine's stream (what BOSSX_UPDATE_FHAT_RESIDENT does inside
+ * bossx_update); bossx_dist_hist then takes a descriptor whose fhat_c is NULL.                  */
+int bossx_fhat_build(bossx_engine *h, int64_t n_windows, int64_t target_rs, double alpha, double den,
+                     double expected, double on_target);
 
 int bossx_histogram(bossx_engine *h, double normaliser, const bossx_fhat_desc *fh,
                     int64_t *counts, uint64_t *fgrid_fx, uint64_t *ubar0_fx);
