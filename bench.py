@@ -391,7 +391,10 @@ def run_grch38(a, rank, world, local_rank, steps=None, warmup=None):
     args.gpu.track_entropy = bool(a.track_entropy)
     args.gpu.mask_format = "bits"      # 62 MB of mask bytes per update at 3.1 Gb: the packed form (masks.py) is what leaves the GPU
     contig_arg = [(n, acgt[codes[n]].tobytes() if n in codes else L) for n, L in allc]
-    if world == 1:
+    # (BOSSX_FORCE_COLLECTIVES=1 with the torchrun variables set: the multi-GPU protocol on ONE rank —
+    # what every rank of an N-GPU run executes, measurable on a single GPU)
+    distributed = world > 1 or bool(os.environ.get("BOSSX_FORCE_COLLECTIVES") and dist.is_initialized())
+    if not distributed:
         runs = BossRuns(args)
         runs.init(contigs=contig_arg)
     else:
@@ -401,7 +404,7 @@ def run_grch38(a, rank, world, local_rank, steps=None, warmup=None):
     runs.write_masks = False
     runs.log_fractions = False
     runs.engine.preload_coverage(8.0, seed=17 + rank)
-    R = Runner("grch38", runs, 1, batches, world > 1)
+    R = Runner("grch38", runs, 1, batches, distributed)
     eng = runs.engine
 
     def barrier():
@@ -441,14 +444,35 @@ def run_grch38(a, rank, world, local_rank, steps=None, warmup=None):
                "chain_floor_ms": longest * CHAIN_FLOOR_CYCLES / GPU_CLOCK_GHZ * 1e-6,
                "note": "the update cannot be shorter than the exact move_sum chain of chr1 (chain_floor_ms) on any GPU "
                        "count: strong scaling of this path is chr1-bound by design",
-               "collectives_per_update": (runs.comm.n_collectives / max(n_b, 1)) if world > 1 else 0,
+               "collectives_per_update": (runs.comm.n_collectives / max(n_b, 1)) if distributed else 0,
                "generation_s": t_gen}
     eng.close()
     return out
 
 
+_REAL_STDOUT = None
+
+
+def own_stdout():
+    """Libraries print to file descriptor 1 (RCCL's version banner at init does): keep the real
+    stdout for the ONE JSON line and point descriptor 1 at stderr for everything else."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit_json(obj):
+    out = _REAL_STDOUT or sys.stdout
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
 def main():
     a = parse_args()
+    if not a.prepare_only:
+        own_stdout()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -459,7 +483,7 @@ def main():
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the decision-update path has no CPU fallback")
         torch.cuda.set_device(local_rank)
-        if world > 1:
+        if world > 1 or (os.environ.get("BOSSX_FORCE_COLLECTIVES") and "RANK" in os.environ):
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         os.chdir(tempfile.mkdtemp(prefix="bossx_bench_"))
@@ -470,7 +494,7 @@ def main():
                     "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                     "dtype": "u16+f64", "data": "synthetic", "config": {"workload": res["workload"]}, "commit": current_commit(),
                     "grch38": res}
-            print(json.dumps(line))
+            emit_json(line)
         if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
@@ -665,7 +689,7 @@ def main():
         if rank == 0:
             out["grch38_strong"] = res
     if rank == 0:
-        print(json.dumps(out))
+        emit_json(out)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
