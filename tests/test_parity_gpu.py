@@ -587,6 +587,26 @@ def _run_updates(in_tmp, name, n_batches, env=None):
                 os.environ[k] = v
 
 
+def test_resident_fhat_and_chain_kernels_agree(in_tmp):
+    """The read-start posterior rebuilt on the device from the resident counts (default) against the
+    host-built one (BOSSX_HOST_FHAT=1), and the barrier-free chain kernel (default) against the
+    barrier kernel (BOSSX_CHAIN_BARRIER=1): same thresholds, benefits and masks in every update;
+    the posterior itself equal to the host's to the last bit or two (its normalising sum is
+    rounded once from an exact sum on the device, from extended precision on the host)."""
+    dev, r_dev = _run_updates(in_tmp, "fh_dev", 6)
+    host, r_host = _run_updates(in_tmp, "fh_host", 6, env={"BOSSX_HOST_FHAT": "1", "BOSSX_CHAIN_BARRIER": "1"})
+    assert r_dev.read_starts._engine is not None and r_host.read_starts._engine is None
+    assert dev[-1][0] is not None
+    for k, (a, b) in enumerate(zip(dev, host)):
+        assert a[0] == b[0], k
+        for x, y in zip(a[1], b[1]):
+            assert np.array_equal(x, y), k          # benefits: the two chain kernels
+        for x, y in zip(a[3], b[3]):
+            assert np.array_equal(x, y), k          # masks
+    assert np.array_equal(r_dev.read_starts.merge(), r_host.read_starts.merge())
+    r_dev.engine.close(); r_host.engine.close()
+
+
 def test_chain_next_to_sweep_equals_serial(in_tmp):
     """Once the strategy is on, the benefit chain runs on a second stream NEXT TO the sweep of the
     same update (tile flags, agent-scope stores/loads).  Every update must be bit-identical to the
