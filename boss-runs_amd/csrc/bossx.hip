@@ -35,6 +35,7 @@ struct bossx_engine {
     double *h_fhat_pin = nullptr;      // page-locked staging of the compact f-hat
     double *d_rs_counts = nullptr; int64_t rs_windows = 0;     // read-start counts resident in HBM (bossx_fhat_reset / _add)
     int64_t *d_rs_keys = nullptr; size_t rs_keys_cap = 0;
+    int64_t *h_rs_keys_pin = nullptr; hipEvent_t ev_rs_keys = nullptr;   // page-locked staging of a batch's keys
     unsigned long long *d_rs_sums = nullptr;
     uint32_t *d_tile_done = nullptr;   // [n_tiles] sweep -> chain hand-off flags (epoch stamped)
     uint32_t *d_tile_order = nullptr;  // [n_tiles] block -> tile for publishing launches: every contig's two ends first
@@ -344,6 +345,8 @@ void bossx_destroy(bossx_engine *h) {
     if (h->h_fhat_pin) hipHostFree(h->h_fhat_pin);
     if (h->d_rs_counts) hipFree(h->d_rs_counts);
     if (h->d_rs_keys) hipFree(h->d_rs_keys);
+    if (h->h_rs_keys_pin) hipHostFree(h->h_rs_keys_pin);
+    if (h->ev_rs_keys) hipEventDestroy(h->ev_rs_keys);
     if (h->d_rs_sums) hipFree(h->d_rs_sums);
     if (h->d_tile_done) hipFree(h->d_tile_done);
     if (h->d_tile_order) hipFree(h->d_tile_order);
@@ -1470,16 +1473,23 @@ int bossx_fhat_add(bossx_engine *h, const int64_t *keys, int32_t n_keys) {
     if (n_keys == 0) return BOSSX_OK;
     HIPCHK(hipSetDevice(h->cfg.device));
     int rc;
+    if (!h->ev_rs_keys) HIPCHK(hipEventCreateWithFlags(&h->ev_rs_keys, hipEventDisableTiming));
     if (size_t(n_keys) > h->rs_keys_cap) {
         HIPCHK(hipStreamSynchronize(h->stream));
         if (h->d_rs_keys) HIPCHK(hipFree(h->d_rs_keys));
-        h->d_rs_keys = nullptr; h->rs_keys_cap = 0;
+        if (h->h_rs_keys_pin) HIPCHK(hipHostFree(h->h_rs_keys_pin));
+        h->d_rs_keys = nullptr; h->h_rs_keys_pin = nullptr; h->rs_keys_cap = 0;
         const size_t cap = size_t(n_keys) * 2 + 1024;
         if ((rc = dev_alloc(h, &h->d_rs_keys, cap))) return rc;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->h_rs_keys_pin), cap * sizeof(int64_t), hipHostMallocDefault));
         h->rs_keys_cap = cap;
     }
-    // (a small pageable copy: the keys of one batch, <= 32 KB; the call returns once they are staged)
-    HIPCHK(hipMemcpyAsync(h->d_rs_keys, keys, size_t(n_keys) * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    // the caller's array is only borrowed for the call: the keys go through page-locked staging
+    // (the previous batch's copy has left it: the event is long signalled in practice)
+    HIPCHK(hipEventSynchronize(h->ev_rs_keys));
+    memcpy(h->h_rs_keys_pin, keys, size_t(n_keys) * sizeof(int64_t));
+    HIPCHK(hipMemcpyAsync(h->d_rs_keys, h->h_rs_keys_pin, size_t(n_keys) * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipEventRecord(h->ev_rs_keys, h->stream));
     hipLaunchKernelGGL(fhat_add_kernel, dim3(uint32_t((n_keys + 255) / 256)), dim3(256), 0, h->stream,
                        h->d_rs_counts, h->d_rs_keys, n_keys, h->rs_windows * 2);
     HIPCHK(hipGetLastError());
