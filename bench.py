@@ -46,7 +46,7 @@ WORKLOADS = {
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)      # (0.25 s of timed region at chr20+21; the driver passes its own K)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS) + ["grch38"])
     ap.add_argument("--reads", type=int, default=4000)
