@@ -8,7 +8,7 @@ profiles)
   ;;
 bench)
   mkdir -p gpurun_out/bench
-  timeout 400 python bench.py > gpurun_out/bench/default.json 2> gpurun_out/bench/default.err
+  timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench/default.json 2> gpurun_out/bench/default.err     # the driver's command
   timeout 300 python bench.py --workload ecoli --no-others --no-large > gpurun_out/bench/ecoli.json 2> gpurun_out/bench/ecoli.err
   timeout 300 python bench.py --workload barcoded --no-others --no-large > gpurun_out/bench/barcoded.json 2> gpurun_out/bench/barcoded.err
   timeout 300 python bench.py --workload grch38 --steps 8 --warmup 3 > gpurun_out/bench/grch38.json 2> gpurun_out/bench/grch38.err
