@@ -305,28 +305,49 @@ namespace {
 
 class WorkPool {
   public:
+    // Tasks [0, n_first) come first; the caller may go on once THEY are done (wait_first) while the
+    // workers finish the rest, and collects the whole job later (wait_all).
     struct Job {
         const std::function<void(int)> *fn;
-        int n;
-        std::atomic<int> next{0}, pending{0};
+        int n, n_first;
+        std::atomic<int> next_first{0}, next_rest{0}, pending_first{0}, pending{0};
     };
     static WorkPool &get() { static WorkPool p; return p; }
     void run(int n, const std::function<void(int)> &fn) {
-        if (n <= 0) return;
+        auto job = start(n, n, fn);
+        if (job) wait_all(*job);
+    }
+    // Starts the job and returns once the first n_first tasks are done (the calling thread works on
+    // those only); null when everything already ran inline.
+    std::shared_ptr<Job> start(int n, int n_first, const std::function<void(int)> &fn) {
+        if (n <= 0) return nullptr;
         ensure(n - 1);
-        if (n == 1 || threads_.empty()) { for (int i = 0; i < n; ++i) fn(i); return; }
+        if (n == 1 || threads_.empty()) { for (int i = 0; i < n; ++i) fn(i); return nullptr; }
         auto job = std::make_shared<Job>();
-        job->fn = &fn; job->n = n; job->pending.store(n);
+        job->fn = &fn; job->n = n; job->n_first = std::min(n_first, n);
+        job->next_rest.store(job->n_first);
+        job->pending.store(n); job->pending_first.store(job->n_first);
         { std::lock_guard<std::mutex> lk(m_); job_ = job; ++gen_; }
         gen_a_.fetch_add(1, std::memory_order_release);
         cv_.notify_all();
-        work(*job);
-        while (job->pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+        work(*job, /*first_only=*/job->n_first < n);
+        while (job->pending_first.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
+        return job;
+    }
+    static void wait_all(Job &job) {
+        work(job, false);                                  // lend a hand with what is left
+        while (job.pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
     }
   private:
-    static void work(Job &j) {
+    static void work(Job &j, bool first_only = false) {
         int i;
-        while ((i = j.next.fetch_add(1)) < j.n) { (*j.fn)(i); j.pending.fetch_sub(1, std::memory_order_release); }
+        while ((i = j.next_first.fetch_add(1)) < j.n_first) {
+            (*j.fn)(i);
+            j.pending_first.fetch_sub(1, std::memory_order_release);
+            j.pending.fetch_sub(1, std::memory_order_release);
+        }
+        if (first_only) return;
+        while ((i = j.next_rest.fetch_add(1)) < j.n) { (*j.fn)(i); j.pending.fetch_sub(1, std::memory_order_release); }
     }
     void ensure(int want) {
         want = std::min(want, 63);
@@ -367,6 +388,15 @@ class WorkPool {
 
 void pool_run(int n_tasks, const std::function<void(int)> &fn) { WorkPool::get().run(n_tasks, fn); }
 
+namespace {
+// collects a two-phase job on every way out of the scope that started it
+struct JobGuard {
+    std::shared_ptr<WorkPool::Job> job;
+    void finish() { if (job) { WorkPool::wait_all(*job); job.reset(); } }
+    ~JobGuard() { finish(); }
+};
+}  // namespace
+
 size_t ops_capacity_for(size_t paf_len) { return paf_len / 2 + paf_len / 16 + 64; }
 
 int parse_threads() {
@@ -396,31 +426,37 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
 
     // ---- pass 1 (threads over line ranges): lines -> filtered records, in line order; then the
     // best record per query name, groups in first-appearance order --------------------------
+    // One two-phase job: the line ranges and the read-name index first — the calling thread goes on
+    // with the grouping and the plans as soon as THOSE are done — then whatever independent work the
+    // caller brought along (gathering the reads, copying the text, their uploads), which the workers
+    // finish meanwhile and which is collected before the device walk is launched.
     std::vector<Group> groups;
-    {
-        int nt = in.n_threads > 0 ? in.n_threads : parse_threads();
-        if (in.paf_len < (size_t(1) << 16)) nt = 1;
-        std::vector<const char *> cuts(size_t(nt) + 1, in.paf + in.paf_len);
-        cuts[0] = in.paf;
-        for (int t = 1; t < nt; ++t) {
-            const char *c = in.paf + in.paf_len * size_t(t) / size_t(nt);
-            if (c < cuts[size_t(t) - 1]) c = cuts[size_t(t) - 1];
-            const char *nl = static_cast<const char *>(memchr(c, '\n', size_t(in.paf + in.paf_len - c)));
-            cuts[size_t(t)] = nl ? nl + 1 : in.paf + in.paf_len;
-        }
-        std::vector<LineOut> los(static_cast<size_t>(nt));
-        // one parallel region: the line ranges, plus whatever independent work the caller brought along
-        static const bool trace = getenv("BOSSX_STAGE_TIMING") != nullptr;
-        std::vector<double> tb, te;
-        const auto r0 = std::chrono::steady_clock::now();
-        if (trace) { tb.assign(size_t(nt + in.extra_n + 1), 0.0); te.assign(size_t(nt + in.extra_n + 1), 0.0); }
-        pool_run(nt + in.extra_n + 1, [&](int t) {
-            if (trace) tb[size_t(t)] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count();
-            if (t < nt) parse_lines(cuts[size_t(t)], cuts[size_t(t) + 1], in.min_len, los[size_t(t)]);
-            else if (t == nt + in.extra_n) build_read_index();
-            else in.extra_fn(t - nt);
-            if (trace) te[size_t(t)] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count();
-        });
+    int nt = in.n_threads > 0 ? in.n_threads : parse_threads();
+    if (in.paf_len < (size_t(1) << 16)) nt = 1;
+    std::vector<const char *> cuts(size_t(nt) + 1, in.paf + in.paf_len);
+    cuts[0] = in.paf;
+    for (int t = 1; t < nt; ++t) {
+        const char *c = in.paf + in.paf_len * size_t(t) / size_t(nt);
+        if (c < cuts[size_t(t) - 1]) c = cuts[size_t(t) - 1];
+        const char *nl = static_cast<const char *>(memchr(c, '\n', size_t(in.paf + in.paf_len - c)));
+        cuts[size_t(t)] = nl ? nl + 1 : in.paf + in.paf_len;
+    }
+    std::vector<LineOut> los(static_cast<size_t>(nt));
+    static const bool trace = getenv("BOSSX_STAGE_TIMING") != nullptr;
+    std::vector<double> tb, te;
+    const auto r0 = std::chrono::steady_clock::now();
+    const int n_tasks = nt + 1 + in.extra_n;
+    if (trace) { tb.assign(size_t(n_tasks), 0.0); te.assign(size_t(n_tasks), 0.0); }
+    const std::function<void(int)> pass1_fn = [&](int t) {
+        if (trace) tb[size_t(t)] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count();
+        if (t < nt) parse_lines(cuts[size_t(t)], cuts[size_t(t) + 1], in.min_len, los[size_t(t)]);
+        else if (t == nt) build_read_index();
+        else in.extra_fn(t - nt - 1);
+        if (trace) te[size_t(t)] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count();
+    };
+    JobGuard pass1;                        // (declared after everything its tasks touch: collected first on every way out)
+    auto collect_pass1 = [&]() {
+        pass1.finish();
         if (trace) {
             auto stat = [&](int a, int b, const char *what) {
                 if (b <= a) return;
@@ -428,10 +464,15 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
                 for (int i = a; i < b; ++i) { s0 = std::min(s0, tb[size_t(i)]); e1 = std::max(e1, te[size_t(i)]); dsum += te[size_t(i)] - tb[size_t(i)]; dmax = std::max(dmax, te[size_t(i)] - tb[size_t(i)]); }
                 fprintf(stderr, "  [pass1] %-6s %2d tasks: first start %.3f, last end %.3f, mean %.3f, max %.3f ms\n", what, b - a, s0, e1, dsum / (b - a), dmax);
             };
-            stat(0, nt, "parse"); stat(nt, nt + in.extra_n, "extra"); stat(nt + in.extra_n, nt + in.extra_n + 1, "index");
-            fprintf(stderr, "  [pass1] region %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count());
+            stat(0, nt, "parse"); stat(nt, nt + 1, "index"); stat(nt + 1, n_tasks, "extra");
+            fprintf(stderr, "  [pass1] all tasks collected after %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count());
         }
         if (in.after_pass1) in.after_pass1();
+    };
+    pass1.job = WorkPool::get().start(n_tasks, nt + 1, pass1_fn);
+    if (trace) fprintf(stderr, "  [pass1] lines + name index done after %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count());
+    if (!in.device_walk || in.summary_only) collect_pass1();     // nothing to overlap with on these paths
+    {
         int64_t line_base = 0;
         for (const LineOut &lo : los) {          // first failing line in file order
             if (lo.err_line) { err = "PAF line " + std::to_string(line_base + lo.err_line) + lo.err_msg; return BOSSX_E_PARSE; }
@@ -584,8 +625,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             const int64_t room = c.length - tlo;
             mp.room = uint32_t(room < 0 ? 0 : (room > int64_t(UINT32_MAX) ? int64_t(UINT32_MAX) : room));
             mp.ops_cap = uint32_t(r.cg_len / 2 + 1);
-            const bool dirty = in.read_dirty ? in.read_dirty[pl.read] != 0 : true;
-            mp.flags = uint32_t(pl.bc & 0xff) | (r.rev ? kPlanRev : 0u) | (dirty ? kPlanCheckBases : 0u);
+            mp.flags = uint32_t(pl.bc & 0xff) | (r.rev ? kPlanRev : 0u);      // (kPlanCheckBases: below, once the reads have been looked at)
             // groups: every sweep tile the stretch [site0, site0 + span) touches, for this barcode.
             // A stretch that runs past its contig (an IndexError reported by the device walk) is
             // clipped here so that no key outside the table is marked.
@@ -621,6 +661,10 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
                 out.tiles.push_back(TileRef{t, 0u, 0u, bc});
             }
         }
+        // the caller's tasks (gather + base check + uploads) have had the grouping and the plans to finish
+        collect_pass1();
+        for (size_t i = 0; i < out.plans.size(); ++i)
+            if (!in.read_dirty || in.read_dirty[out.plan_read[i]]) out.plans[i].flags |= kPlanCheckBases;
         out.ops_cap = ops_at + 1;
         out.segs_cap = seg_cap + 1;
         out.total_emit = cur_emit;
