@@ -31,6 +31,8 @@ struct bossx_engine {
     hipStream_t stream2 = nullptr;
     hipStream_t stream_up = nullptr;   // slice-wise uploads of a batch being staged (issued by the worker threads)
     hipEvent_t ev_up = nullptr;
+    hipStream_t stream_txt = nullptr;  // the PAF text goes up on its own: the device walk needs nothing else
+    hipEvent_t ev_txt = nullptr;
     hipEvent_t ev_begin = nullptr, ev_chain = nullptr, ev_sweep = nullptr, ev_fhat = nullptr;
     double *h_fhat_pin = nullptr;      // page-locked staging of the compact f-hat
     double *d_rs_counts = nullptr; int64_t rs_windows = 0;     // read-start counts resident in HBM (bossx_fhat_reset / _add)
@@ -326,7 +328,9 @@ int bossx_create(const bossx_config *cfg, bossx_engine **out) {
         hipEventCreateWithFlags(&h->ev_sweep, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fhat, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&h->stream_up, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming) != hipSuccess) return BOSSX_E_HIP;
+        hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->stream_txt, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_txt, hipEventDisableTiming) != hipSuccess) return BOSSX_E_HIP;
     *out = e.release();
     return BOSSX_OK;
 }
@@ -338,6 +342,8 @@ void bossx_destroy(bossx_engine *h) {
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
     if (h->stream_up) { hipStreamSynchronize(h->stream_up); hipStreamDestroy(h->stream_up); }
     if (h->ev_up) hipEventDestroy(h->ev_up);
+    if (h->stream_txt) { hipStreamSynchronize(h->stream_txt); hipStreamDestroy(h->stream_txt); }
+    if (h->ev_txt) hipEventDestroy(h->ev_txt);
     if (h->ev_begin) hipEventDestroy(h->ev_begin);
     if (h->ev_chain) hipEventDestroy(h->ev_chain);
     if (h->ev_sweep) hipEventDestroy(h->ev_sweep);
@@ -775,37 +781,54 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
     in.extra_n = n_g + n_c;
     // Every slice goes up as soon as it is gathered (the worker that filled it issues the copy, on a
     // stream of its own): the PCIe transfer of the 24 MB of reads overlaps with the gather instead
-    // of following it.
-    std::atomic<int> up_fail{0};
+    // of following it.  The text slices come first and travel on a third stream: the device walk
+    // waits for THEM only (it reads the bases of a mapping only where the host saw a byte other
+    // than A/C/G/T in the read), the sweep that applies the batch for the reads.
+    std::atomic<int> up_fail{0}, any_dirty{0};
     const int dev = h->cfg.device;
     in.extra_fn = [&, n_g, n_c, dev](int t) {
         static thread_local int dev_set = -1;
         if (dev_set != dev) { if (hipSetDevice(dev) != hipSuccess) up_fail.store(1); dev_set = dev; }
-        if (t < n_g) {            // reads [b, e) of a byte-balanced slice: gather (if still scattered) and look at the bases
-            const size_t lo_b = blob_bytes * size_t(t) / size_t(n_g), hi_b = blob_bytes * size_t(t + 1) / size_t(n_g);
+        if (t < n_c) {
+            const size_t lo = in.paf_len * size_t(t) / size_t(n_c), hi = in.paf_len * size_t(t + 1) / size_t(n_c);
+            memcpy(h->h_paf_pin + lo, in.paf + lo, hi - lo);
+            if (hi > lo && hipMemcpyAsync(h->d_paf + lo, h->h_paf_pin + lo, hi - lo, hipMemcpyHostToDevice, h->stream_txt) != hipSuccess) up_fail.store(1);
+        } else {                  // reads [b, e) of a byte-balanced slice: gather (if still scattered) and look at the bases
+            const int g = t - n_c;
+            const size_t lo_b = blob_bytes * size_t(g) / size_t(n_g), hi_b = blob_bytes * size_t(g + 1) / size_t(n_g);
             const int64_t *bp = std::lower_bound(seq_off, seq_off + n_reads, int64_t(lo_b));
-            const int64_t *ep = t + 1 == n_g ? seq_off + n_reads : std::lower_bound(seq_off, seq_off + n_reads, int64_t(hi_b));
+            const int64_t *ep = g + 1 == n_g ? seq_off + n_reads : std::lower_bound(seq_off, seq_off + n_reads, int64_t(hi_b));
             const int32_t i0 = int32_t(bp - seq_off), i1 = int32_t(ep - seq_off);
+            bool dirty = false;
             for (int32_t i = i0; i < i1; ++i) {
                 const size_t len = size_t(seq_off[i + 1] - seq_off[i]);
                 if (seq_ptrs) memcpy(seqs + seq_off[i], seq_ptrs[i], len);
-                h->read_dirty[size_t(i)] = bytes_all_acgt(seqs + seq_off[i], len) ? 0 : 1;
+                const bool d = !bytes_all_acgt(seqs + seq_off[i], len);
+                h->read_dirty[size_t(i)] = d ? 1 : 0;
+                dirty |= d;
             }
+            if (dirty) any_dirty.store(1, std::memory_order_relaxed);
             if (i1 > i0 && seq_off[i1] > seq_off[i0] &&
                 hipMemcpyAsync(st.d_blob + seq_off[i0], seqs + seq_off[i0], size_t(seq_off[i1] - seq_off[i0]), hipMemcpyHostToDevice, h->stream_up) != hipSuccess)
                 up_fail.store(1);
-        } else {
-            const int c = t - n_g;
-            const size_t lo = in.paf_len * size_t(c) / size_t(n_c), hi = in.paf_len * size_t(c + 1) / size_t(n_c);
-            memcpy(h->h_paf_pin + lo, in.paf + lo, hi - lo);
-            if (hi > lo && hipMemcpyAsync(h->d_paf + lo, h->h_paf_pin + lo, hi - lo, hipMemcpyHostToDevice, h->stream_up) != hipSuccess) up_fail.store(1);
         }
     };
     hipError_t up_err = hipSuccess;
-    in.after_pass1 = [&]() {      // everything staged on the upload stream precedes what follows on the main one
+    // The reads may still be on their way when the walk runs — unless it has bases to look at, or the
+    // blob is the caller's own memory (borrowed for the call only) rather than our page-locked copy.
+    bool reads_awaited = false;
+    auto await_reads = [&]() {
+        if (reads_awaited || up_err != hipSuccess) return;
+        up_err = hipStreamWaitEvent(h->stream, h->ev_up, 0);
+        reads_awaited = true;
+    };
+    const bool defer_reads = seq_ptrs != nullptr && !host_walk && !getenv("BOSSX_NO_DEFER_READS");
+    in.after_pass1 = [&]() {      // everything staged on the upload streams precedes what follows on the main one
         if (up_fail.load()) { up_err = hipErrorUnknown; return; }
-        up_err = hipEventRecord(h->ev_up, h->stream_up);
-        if (up_err == hipSuccess) up_err = hipStreamWaitEvent(h->stream, h->ev_up, 0);
+        up_err = hipEventRecord(h->ev_txt, h->stream_txt);
+        if (up_err == hipSuccess) up_err = hipStreamWaitEvent(h->stream, h->ev_txt, 0);
+        if (up_err == hipSuccess) up_err = hipEventRecord(h->ev_up, h->stream_up);
+        if (!defer_reads || any_dirty.load()) await_reads();
     };
     ParsedBatch pb;
     const auto t_pre = std::chrono::steady_clock::now();
@@ -819,7 +842,10 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
         in.n_tiles = h->n_tiles;
         std::string err;
         rc = parse_paf_batch(in, h->contigs, h->index, summary, pb, err);
-        if (rc) { hipStreamSynchronize(h->stream); return fail(h, rc, err); }     // inputs are borrowed for the call only
+        if (rc) {                                          // inputs are borrowed for the call only
+            hipStreamSynchronize(h->stream_txt); hipStreamSynchronize(h->stream_up); hipStreamSynchronize(h->stream);
+            return fail(h, rc, err);
+        }
         HIPCHK(up_err);
         const auto t1 = std::chrono::steady_clock::now();
         auto t_launched = t1;
@@ -856,11 +882,13 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
             HIPCHK(hipMemcpyAsync(back, W.totals, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
             memcpy(totals, back, sizeof(totals));
+            await_reads(); HIPCHK(up_err);                 // (ordered before the sweep that applies the batch)
             if (totals[2]) {
                 walk_err.resize(n_plans);
                 HIPCHK(hipMemcpy(walk_err.data(), W.walk_err, size_t(n_plans) * sizeof(uint32_t), hipMemcpyDeviceToHost));
             }
         } else {
+            await_reads(); HIPCHK(up_err);
             HIPCHK(hipStreamSynchronize(h->stream));
         }
         // ---- failures: the first ValueError / KeyError class one in record order; the IndexError
