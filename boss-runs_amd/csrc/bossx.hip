@@ -58,6 +58,7 @@ struct bossx_engine {
     bool last_chain_live = false;   // the last chain launch ran next to its sweep
     bool chain_flow_fits = true;    // its LDS (buffers + the ring for the current windows) fits a CU
     int chain_flow_bufs = 4;        // difference buffers it is launched with (5 when the LDS allows)
+    int chain_flow_ce = 2;          // the chain wave stores the carry into every CE-th step, the tail waves rebuild the others (BOSSX_FLOW_CE=1: all of them)
     int32_t nb = 1;
 
     std::vector<ContigInfo> contigs;                    // add order (rejected included)
@@ -495,6 +496,7 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
     // BOSSX_NO_OVERLAP=1 keeps them back to back.
     h->overlap_ok = getenv("BOSSX_NO_OVERLAP") == nullptr;
     h->chain_flow = getenv("BOSSX_CHAIN_BARRIER") == nullptr;
+    if (const char *e = getenv("BOSSX_FLOW_CE")) h->chain_flow_ce = atoi(e) == 1 ? 1 : 2;
     if ((rc = dev_alloc(h, &h->d_bucket_on, size_t(nb * h->NBK), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_bucket_sums, size_t(nb * h->NBK), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_drop_count, size_t(h->n_tiles), true))) return rc;
@@ -1279,15 +1281,20 @@ void launch_chain_variant(dim3 grid, dim3 block, size_t lds, hipStream_t stream,
     }
     hipLaunchKernelGGL((benefit_chain_kernel<MATRIX, LIVE, CH>), grid, block, lds, stream, P);
 }
-template <bool LIVE, int CH, int NBD>
-void launch_chain_flow(dim3 grid, dim3 block, size_t lds, hipStream_t stream, const ChainParams &P) {
+template <bool LIVE, int CH, int NBD, int CE>
+void launch_chain_flow_ce(dim3 grid, dim3 block, size_t lds, hipStream_t stream, const ChainParams &P) {
     static size_t allowed = 0;
     if (lds > allowed) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_flow_kernel<LIVE, CH, NBD>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_flow_kernel<LIVE, CH, NBD, CE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         allowed = lds;
     }
-    hipLaunchKernelGGL((benefit_chain_flow_kernel<LIVE, CH, NBD>), grid, block, lds, stream, P);
+    hipLaunchKernelGGL((benefit_chain_flow_kernel<LIVE, CH, NBD, CE>), grid, block, lds, stream, P);
+}
+template <bool LIVE, int CH, int NBD>
+void launch_chain_flow(int ce, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const ChainParams &P) {
+    if (ce == 1) launch_chain_flow_ce<LIVE, CH, NBD, 1>(grid, block, lds, stream, P);
+    else launch_chain_flow_ce<LIVE, CH, NBD, 2>(grid, block, lds, stream, P);
 }
 }  // extern "C++"
 
@@ -1309,8 +1316,9 @@ void launch_chain(bossx_engine *h, const ChainParams &P, size_t lds, hipStream_t
     h->last_chain_live = live;
     if (h->matrix_chain && h->chain_flow && ch == 256 && h->chain_flow_fits) {
         // as many buffers between the stages as the LDS holds next to the ring of the current windows
-        if (h->chain_flow_bufs == 5) { if (live) launch_chain_flow<true, 256, 5>(grid, block, lds, stream, P); else launch_chain_flow<false, 256, 5>(grid, block, lds, stream, P); }
-        else { if (live) launch_chain_flow<true, 256, 4>(grid, block, lds, stream, P); else launch_chain_flow<false, 256, 4>(grid, block, lds, stream, P); }
+        const int ce = h->chain_flow_ce;
+        if (h->chain_flow_bufs == 5) { if (live) launch_chain_flow<true, 256, 5>(ce, grid, block, lds, stream, P); else launch_chain_flow<false, 256, 5>(ce, grid, block, lds, stream, P); }
+        else { if (live) launch_chain_flow<true, 256, 4>(ce, grid, block, lds, stream, P); else launch_chain_flow<false, 256, 4>(ce, grid, block, lds, stream, P); }
     } else if (h->matrix_chain) {
         if (ch == 256) { if (live) launch_chain_variant<true, true, 256>(grid, block, lds, stream, P); else launch_chain_variant<true, false, 256>(grid, block, lds, stream, P); }
         else { if (live) launch_chain_variant<true, true, 128>(grid, block, lds, stream, P); else launch_chain_variant<true, false, 128>(grid, block, lds, stream, P); }
