@@ -3,7 +3,7 @@
 # the parity file (gpurun -- bash scripts/chain_flow_exp.sh)
 mkdir -p gpurun_out/flow
 python3 bench.py --prepare-only --workload chr20_21 >/dev/null 2>&1
-for env in BOSSX_FLOW_CE=1 BOSSX_FLOW_CE=2 BOSSX_CHAIN_BARRIER=1 BOSSX_FLOW_CE=2; do
+for env in BOSSX_FLOW_CE=1 BOSSX_FLOW_CE=2 BOSSX_FLOW_CE=2; do
   out=$(env $env timeout 600 python bench.py --workload chr20_21 --no-cpu-baseline --no-others --no-large 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read())
