@@ -815,6 +815,12 @@ def test_device_cigar_walk_equals_host_walk(in_tmp, monkeypatch):
                 lines[i] = "\t".join(f)
         summ = eng.stage_batch("\n".join(lines), batch["seqs"], barcodes=batch["barcodes"])
         assert summ["aligned"] > 0
+    # mappings of more pieces than the emit pass notes in LDS (kPieceCap = 1024 pieces, spans beyond
+    # ~260 kb): their pieces' first / last runs are searched for in global memory instead
+    batch = synth.make_batch(contigs, 60, seed=650, mean_len=250000.0, max_len=398_000, nbarcodes=nb, extras=False)
+    assert max(batch["read_lengths"].values()) > 300_000
+    summ = eng.stage_batch(batch["paf"], batch["seqs"], barcodes=batch["barcodes"])
+    assert summ["aligned"] > 0
     # ---- failure classes through the device walk -------------------------------------------
     monkeypatch.delenv("BOSSX_CHECK_DEVICE_WALK")
     batch = synth.make_batch(contigs, 300, seed=77, mean_len=3000.0, nbarcodes=nb, extras=False)
