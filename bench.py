@@ -148,11 +148,11 @@ def pmc_traffic(workload, kernel_substr, only=None):
     """HBM bytes per launch of `kernel_substr` from the newest committed rocprofv3 PMC summary
     of this workload (profiles/rNN_<workload>_rocprof_summary.json: FETCH_SIZE and WRITE_SIZE
     from separate --pmc passes, in KB; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).
-    Returns (bytes, file name, commit the profile was taken at)."""
+    Returns (bytes, file name, commit the profile was taken at, hash of the kernel sources then)."""
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_%s_rocprof_summary.json" % workload)))
     if not files:
-        return None, None, None
+        return None, None, None, None
     d = json.load(open(files[-1]))
     tot, found = 0.0, False
     for name, v in d.get("kernels", {}).items():
@@ -163,7 +163,19 @@ def pmc_traffic(workload, kernel_substr, only=None):
             per_update = v.get("launches_per_update", 1.0)
             tot += (2.0 * v["FETCH_SIZE_avg_per_launch"] + v["WRITE_SIZE_avg_per_launch"]) * 1024.0 * per_update
             found = True
-    return (tot if found else None), os.path.basename(files[-1]), d.get("commit")
+    return (tot if found else None), os.path.basename(files[-1]), d.get("commit"), d.get("kernel_sources")
+
+
+def kernel_sources_hash():
+    """sha1 over the library's sources (boss-runs_amd/csrc): ties a committed rocprofv3 summary to the
+    kernels it measured, whatever was committed next to them afterwards (docs, tests)."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(REPO, "boss-runs_amd", "csrc")
+    for f in ("bossx.hip", "kernels.hip.inc", "front_end.hip.inc", "engine.hpp", "paf_host.cpp", "rl_host.cpp", "Makefile"):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
 
 def current_commit():
@@ -599,7 +611,7 @@ def main():
         # (the profiled run also holds the every-tile sweeps of the full_sweep loop: when the timed region
         # swept only the tiles that receive bases, its traffic is that of the ingesting launches alone)
         incremental = kern[roof_k]["bytes"] < 0.99 * kern_full[roof_k]["bytes"]
-        traffic, traffic_src, traffic_commit = pmc_traffic(workload, "site_sweep_kernel",
+        traffic, traffic_src, traffic_commit, traffic_ksrc = pmc_traffic(workload, "site_sweep_kernel",
                                                            only="site_sweep_kernel<true" if incremental else None)
         commit = current_commit()
         longest_bins = max(c.length // 100 + 1 for c in runs.contigs_filt.values())
@@ -627,6 +639,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src, "traffic_commit": traffic_commit,
                          "traffic_same_commit": bool(commit and traffic_commit and commit[:12] == str(traffic_commit)[:12]),
+                         "traffic_same_kernel_sources": bool(traffic_ksrc and traffic_ksrc == kernel_sources_hash()),
                          "algorithmic_bytes": kern[roof_k]["bytes"], "avg_launch_ms": kern[roof_k]["avg_ms"],
                          "full_sweep": {"avg_launch_ms": kern_full[roof_k]["avg_ms"], "algorithmic_bytes": kern_full[roof_k]["bytes"],
                                         "achieved": kern_full[roof_k]["gbs"], "frac": (kern_full[roof_k]["gbs"] or 0.0) / HBM_PEAK_GBS,

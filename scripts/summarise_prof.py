@@ -8,7 +8,13 @@ per kernel.  `launches_per_update` = launches of the kernel / launches of strate
 (one per decision update)."""
 import csv, glob, json, os, sys
 out, tag = sys.argv[1], sys.argv[2]
-res = {"workload": tag, "commit": sys.argv[3] if len(sys.argv) > 3 else None, "kernels": {}}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    import bench
+    ksrc = bench.kernel_sources_hash()
+except Exception:
+    ksrc = None
+res = {"workload": tag, "commit": sys.argv[3] if len(sys.argv) > 3 else None, "kernel_sources": ksrc, "kernels": {}}
 def find(sub, pat):
     fs = glob.glob(os.path.join(out, sub, "**", pat), recursive=True)
     return fs[0] if fs else None
