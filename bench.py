@@ -167,12 +167,13 @@ def pmc_traffic(workload, kernel_substr, only=None):
 
 
 def kernel_sources_hash():
-    """sha1 over the library's sources (boss-runs_amd/csrc): ties a committed rocprofv3 summary to the
-    kernels it measured, whatever was committed next to them afterwards (docs, tests)."""
+    """sha1 over the device side of the library (boss-runs_amd/csrc: the .hip file, its kernel includes,
+    the shared header): ties a committed rocprofv3 summary to the kernels it measured, whatever was
+    committed next to them afterwards (docs, tests, host code)."""
     import hashlib
     h = hashlib.sha1()
     d = os.path.join(REPO, "boss-runs_amd", "csrc")
-    for f in ("bossx.hip", "kernels.hip.inc", "front_end.hip.inc", "engine.hpp", "paf_host.cpp", "rl_host.cpp", "Makefile"):
+    for f in ("bossx.hip", "kernels.hip.inc", "front_end.hip.inc", "engine.hpp"):
         with open(os.path.join(d, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]

@@ -878,10 +878,34 @@ extern "C" int bossx_host_parse(const char *const *contig_names, const int64_t *
         int64_t n_tiles = 0;
         for (const ContigInfo &c : contigs) if (!c.rejected && !c.remote) n_tiles += c.n_tiles;
         in2.n_tiles = n_tiles;
+        // ... with the caller's share of the two-phase job as bossx_stage_batch_ptrs brings it along: slices
+        // of reads looked at for bytes other than A/C/G/T while the calling thread groups and plans;
+        // collected (after_pass1) before the plans are flagged for the walk's base check
+        std::vector<uint8_t> dirty(size_t(n_reads), 0);
+        const int n_extra = n_reads > 0 ? std::min(n_reads, 7) : 0;
+        std::atomic<int> extras_done{0};
+        int done_at_collection = -1;
+        const std::function<void(int)> extra_fn = [&](int t) {
+            const int32_t i0 = int32_t(int64_t(n_reads) * t / n_extra), i1 = int32_t(int64_t(n_reads) * (t + 1) / n_extra);
+            for (int32_t i = i0; i < i1; ++i) {
+                const char *q = seq_ptrs ? seq_ptrs[i] : nullptr;
+                bool bad = false;
+                for (int64_t j = 0; q && j < seq_lens[i]; ++j) bad |= !(q[j] == 'A' || q[j] == 'C' || q[j] == 'G' || q[j] == 'T');
+                dirty[size_t(i)] = bad ? 1 : 0;
+            }
+            extras_done.fetch_add(1);
+        };
+        in2.extra_n = n_extra; in2.extra_fn = extra_fn;
+        in2.after_pass1 = [&]() { done_at_collection = extras_done.load(); };
+        in2.read_dirty = dirty.data();
         ParsedBatch pd;
         std::string err2;
         rc = parse_paf_batch(in2, contigs, index, nullptr, pd, err2);
         if (rc || pd.pre_code || pd.pre_range_gi >= 0) return fail(BOSSX_E_INVALID, "device-walk planning fails where the host walk passed: " + err2 + pd.pre_msg);
+        if (done_at_collection != n_extra) return fail(BOSSX_E_INVALID, "device-walk planning: the caller's tasks were not all done when the job was collected");
+        for (size_t i = 0; i < pd.plans.size(); ++i)
+            if (((pd.plans[i].flags & kPlanCheckBases) != 0) != (dirty[size_t(pd.plan_read[i])] != 0))
+                return fail(BOSSX_E_INVALID, "device-walk planning: base-check flags do not follow the reads");
         if (pd.total_emit != pb.total_emit || pd.n_rec != pb.n_rec || pd.emitted_per_contig != pb.emitted_per_contig)
             return fail(BOSSX_E_INVALID, "device-walk planning: totals differ");
         if (pd.ops_cap < pb.n_ops || pd.segs_cap < pb.segs.size()) return fail(BOSSX_E_INVALID, "device-walk planning: capacity too small");

@@ -236,6 +236,34 @@ def test_native_parser_vs_oracle_expansion(threads):
     assert np.array_equal(got["rev"], [int(r.rev) for r in recs])
 
 
+def test_dirty_reads_are_flagged_after_the_two_phase_job():
+    """The host half of staging runs as a two-phase job (paf_host.cpp, WorkPool::start / JobGuard): the
+    line parse + read index first, the caller's tasks — here, as in bossx_stage_batch_ptrs, slices of
+    reads looked at for bytes other than A/C/G/T — finish while the calling thread groups and plans,
+    and only after their collection are the plans of such reads flagged for the device walk's base
+    check.  bossx_host_parse drives exactly that and fails if the tasks were not all done at the
+    collection or if a flag does not follow its read.  A byte other than A/C/G/T in the soft-clipped
+    flank makes a read dirty without making the batch fail."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.engine import host_parse
+    ref = synth.make_reference([150_300, 260_100], seed=5, names=["a", "b"])
+    batch = synth.make_batch(ref, 900, seed=91, mean_len=4000.0, nbarcodes=1, extras=False)
+    contigs = [("a", 150_300, 0), ("b", 260_100, 0)]
+    clean = host_parse(contigs, batch["paf"], batch["seqs"], n_threads=4)
+    seqs = dict(batch["seqs"])
+    n_dirty = 0
+    for line in batch["paf"].split("\n"):
+        f = line.split("\t")
+        if len(f) > 3 and int(f[2]) >= 1 and n_dirty < 200:       # qstart >= 1: base 0 is outside the alignment
+            seqs[f[0]] = "N" + seqs[f[0]][1:]
+            n_dirty += 1
+    assert n_dirty >= 50
+    for threads in (1, 4, 8):
+        got = host_parse(contigs, batch["paf"], seqs, n_threads=threads)
+        for key in ("contig", "pos", "code", "barcode"):
+            assert np.array_equal(got[key], clean[key]), key
+
+
 def test_native_parser_errors_are_first_in_record_order():
     """With several faulty records the failure reported is the first one in record order,
     whatever the thread partition (the reference raises inside its per-record loop)."""
