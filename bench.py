@@ -168,14 +168,19 @@ def pmc_traffic(workload, kernel_substr, only=None):
 
 def kernel_sources_hash():
     """sha1 over the device side of the library (boss-runs_amd/csrc: the .hip file, its kernel includes,
-    the shared header): ties a committed rocprofv3 summary to the kernels it measured, whatever was
-    committed next to them afterwards (docs, tests, host code)."""
+    the shared header) with `//` comments and blank lines stripped: ties a committed rocprofv3 summary
+    to the kernel CODE it measured, whatever was committed next to it afterwards (docs, tests, host
+    code, comments)."""
     import hashlib
     h = hashlib.sha1()
     d = os.path.join(REPO, "boss-runs_amd", "csrc")
     for f in ("bossx.hip", "kernels.hip.inc", "front_end.hip.inc", "engine.hpp"):
-        with open(os.path.join(d, f), "rb") as fh:
-            h.update(f.encode() + b"\0" + fh.read())
+        h.update(f.encode() + b"\0")
+        with open(os.path.join(d, f), "r") as fh:
+            for line in fh:
+                code = line.split("//", 1)[0].rstrip()
+                if code:
+                    h.update(code.encode() + b"\n")
     return h.hexdigest()[:16]
 
 
