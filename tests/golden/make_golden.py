@@ -26,7 +26,7 @@ sys.path[:0] = [os.path.join(HERE, "_shims"), "/root/reference", REPO]
 
 sys.path.insert(0, os.path.join(REPO, "tests"))
 from scenarios import (SCENARIOS, E2E_REJECT, E2E_BATCHES, digest, e2e_reference, e2e_batch,  # noqa: E402
-                       batch_digest)
+                       batch_digest, saturated_coverage)
 from boss_runs_amd import synth  # noqa: E402
 
 
@@ -180,6 +180,85 @@ def run_scenario(out, tag, ploidy, nb):
     return d
 
 
+
+def run_saturated(out, ploidy=1, nb=1):
+    """The reference's update_wrapper on the state a long run converges to (scenarios.saturated_coverage:
+    every score `tiny` or 0.0, benefits ~1e-300), then one more ordinary batch on top of it.  The first
+    batch only provides read-start counts and the read-length distribution."""
+    import boss.config
+    import boss.runs.core
+    from boss.paf import Paf
+    contigs = e2e_reference()
+    tmp = tempfile.mkdtemp(prefix="golden_")
+    os.chdir(tmp)
+    fa = os.path.join(tmp, "ref.fa")
+    synth.write_fasta(fa, contigs)
+    open(os.path.join(tmp, "ref.mmi"), "w").close()
+    args = boss.config.BossConfig()
+    args.general.ref = fa
+    args.general.mmi = os.path.join(tmp, "ref.mmi")
+    args.general.name = "golden"
+    args.optional.ploidy = ploidy
+    args.optional.reject_refs = E2E_REJECT
+    runs = boss.runs.core.BossRuns(args=args)
+    runs.init()
+    d = dict(movesum_unpinned=np.array(1), ploidy=np.array(ploidy), nb=np.array(nb),
+             ref_digest=np.array(digest(*[c[1] for c in contigs])))
+
+    def ingest(b):
+        batch = e2e_batch(contigs, b, nb)
+        d["b%d_input_digest" % b] = np.array(batch_digest(batch))
+        runs.rl_dist.update(read_lengths=batch["read_lengths"])
+        paf = Paf.parse_PAF(StringIO(batch["paf"]), min_len=200)
+        inc = runs.cc.convert_records(paf_dict=paf, seqs=batch["seqs"],
+                                      quals={k: "I" * len(v) for k, v in batch["seqs"].items()})
+        runs._effect_increments(increments=inc)
+        runs.tracker.update(n=len(batch["seqs"]), paf_dict=paf)
+        runs.read_starts.count_read_starts(paf_dict=paf)
+
+    def update(tag):
+        captured = {}
+        orig = runs.scoring.find_strat_thread
+
+        def spy(benefit, smu, fhat, time_cost, _orig=orig, _cap=captured):
+            strat, thr = _orig(benefit=benefit, smu=smu, fhat=fhat, time_cost=time_cost)
+            _cap.update(threshold=thr, merged_strat=strat.copy(), benefit_adj=benefit.copy(), fhat_adj=fhat.copy())
+            return strat, thr
+        runs.scoring.find_strat_thread = spy
+        runs.update_wrapper()
+        runs.scoring.find_strat_thread = orig
+        assert captured, "strategies not switched on"
+        d[tag + "_threshold"] = np.array(captured["threshold"])
+        d[tag + "_merged_strat"] = np.packbits(captured["merged_strat"].reshape(-1))
+        d[tag + "_merged_shape"] = np.array(captured["merged_strat"].shape)
+        d[tag + "_benefit_adj"] = captured["benefit_adj"]
+        d[tag + "_benefit_max"] = np.array(captured["benefit_adj"].max())
+        for cname, c in runs.contigs.items():
+            key = "%s_%s_" % (tag, cname)
+            d[key + "strat"] = np.packbits(c.strat.reshape(-1))
+            d[key + "strat_shape"] = np.array(c.strat.shape)
+            if c.rej:
+                continue
+            d[key + "n_zero_scores"] = np.array(int((c.scores == 0).sum()))
+            d[key + "n_tiny_scores"] = np.array(int((c.scores == np.finfo(float).tiny).sum()))
+            d[key + "n_other_scores"] = np.array(int(c.scores.size - (c.scores == 0).sum() - (c.scores == np.finfo(float).tiny).sum()))
+            d[key + "scores_ds"] = c.scores_ds.copy()
+            d[key + "additional_benefit"] = c.additional_benefit.copy()
+
+    ingest(0)
+    runs.update_wrapper()
+    for c in runs.contigs.values():
+        if c.rej:
+            continue
+        c.coverage[:] = saturated_coverage(c.seq_int, nb=nb)
+        c.change_mask[:] = True
+    update("sat")
+    ingest(1)
+    update("sat1")
+    np.savez_compressed(os.path.join(out, "g_sat_p%d_nb%d.npz" % (ploidy, nb)), **d)
+    return d
+
+
 SIM_SCENARIOS = [("nb1", 1, False), ("nb2_unmapped", 2, True)]      # tag, nbarcodes, accept_unmapped
 SIM_BATCHES = 5
 
@@ -280,6 +359,10 @@ def run_sim_scenario(out, tag, nb, accept_unmapped):
 
 def main():
     out = HERE
+    if os.environ.get("GOLDEN_ONLY") == "sat":          # (the other fixtures are not touched)
+        d = run_saturated(out)
+        print("sat thresholds", float(d["sat_threshold"]), float(d["sat1_threshold"]), "max benefit", float(d["sat_benefit_max"]))
+        return
     gen_tables(out)
     gen_cigar(out)
     gen_dists(out)
@@ -287,6 +370,8 @@ def main():
         d = run_scenario(out, tag, pl, nb)
         print(tag, "updated:", [int(d["b%d_updated" % b]) for b in range(E2E_BATCHES)],
               "thr:", [float(d.get("b%d_threshold" % b, np.nan)) for b in range(E2E_BATCHES)])
+    d = run_saturated(out)
+    print("sat thresholds", float(d["sat_threshold"]), float(d["sat1_threshold"]), "max benefit", float(d["sat_benefit_max"]))
     for tag, nb, au in SIM_SCENARIOS:
         d = run_sim_scenario(out, tag, nb, au)
         print("sim", tag, [d["b%d_counts" % b].tolist() for b in range(SIM_BATCHES)])

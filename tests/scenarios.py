@@ -51,3 +51,26 @@ def batch_digest(batch):
 def unpack_strat(g, key, shape):
     n = int(np.prod(shape))
     return np.unpackbits(g[key])[:n].reshape(shape).astype(bool)
+
+
+# ---- the saturated regime (every site maxed or dropped out) -------------------------------------
+SAT_DEPTH = 240          # mean/8 >= 29: no site can sit between the dropout threshold and the depth cap of 30
+SAT_RAMP = 600
+
+
+def saturated_coverage(seq_int, nb=1, depth=SAT_DEPTH, ramp=SAT_RAMP):
+    """The coverage a long run converges to: every site `depth` reads deep, all on the reference
+    base, rising from zero over the first / falling over the last `ramp` sites (reads start
+    uniformly, so the ends of a contig fill last).  With depth 240 the dropout threshold
+    int(mean / 8) is 29: every score is `tiny` (depth >= 30) or 0.0 (dropped out) and every
+    benefit ~1e-300 — the regime in which an absolute fixed point loses ubar0."""
+    seq_int = np.asarray(seq_int)
+    L = seq_int.shape[0]
+    d = np.full(L, depth, dtype=np.int64)
+    r = np.arange(ramp, dtype=np.int64) * depth // ramp
+    d[:ramp] = r
+    d[L - ramp:] = r[::-1]
+    cov = np.zeros((L, 5, nb), dtype=np.uint16)
+    for b in range(nb):
+        cov[np.arange(L), seq_int, b] = d
+    return cov

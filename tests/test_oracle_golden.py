@@ -159,3 +159,48 @@ def test_golden_end_to_end(tag, ploidy, nb):
     assert np.allclose(g["final_ctgA_scores"], o.contigs["ctgA"].scores, rtol=1e-6, atol=1e-300)
     assert np.array_equal(g["final_ctgA_coverage"], o.contigs["ctgA"].coverage)
     assert np.array_equal(g["final_read_starts"], o.read_starts.merge())
+
+
+def test_golden_saturated_regime():
+    """The state a long run converges to — every score `tiny` (depth >= 30) or 0.0 (dropped out), every
+    benefit ~1e-300 (scenarios.saturated_coverage) — through the reference's own update_wrapper, and one
+    more ordinary batch on top of it: thresholds of 1e-304, masks, bin sums and benefits of the oracle
+    equal the reference's.  (An absolute fixed point for ubar0 lost the whole sum here and put the
+    threshold one exponent bin low: DESIGN 4.4.  The GPU is held to the oracle in this regime by
+    test_saturated_coverage_vs_oracle.)"""
+    from scenarios import saturated_coverage
+    g = np.load(os.path.join(GOLDEN, "g_sat_p1_nb1.npz"))
+    contigs = e2e_reference()
+    assert str(g["ref_digest"]) == digest(*[c[1] for c in contigs])
+    o = OracleRuns(e2e_contig_strings(contigs), ploidy=1, reject_refs={E2E_REJECT}, nbarcodes=1)
+
+    def ingest(b):
+        batch = e2e_batch(contigs, b, 1)
+        assert str(g["b%d_input_digest" % b]) == batch_digest(batch), "synthetic inputs drifted"
+        o.process_batch(batch["paf"], batch["seqs"], read_lengths=batch["read_lengths"])
+
+    def check(tag):
+        tiny = np.finfo(float).tiny
+        for cname, c in o.contigs.items():
+            key = "%s_%s_" % (tag, cname)
+            assert np.array_equal(unpack_strat(g, key + "strat", c.strat.shape), c.strat), (tag, cname)
+            if c.rej:
+                continue
+            assert int(g[key + "n_zero_scores"]) == int((c.scores == 0).sum())
+            assert int(g[key + "n_tiny_scores"]) == int((c.scores == tiny).sum())
+            assert np.array_equal(g[key + "scores_ds"], c.scores_ds)
+            assert np.array_equal(g[key + "additional_benefit"], c.additional_benefit)
+        assert float(g[tag + "_threshold"]) == o.threshold
+        assert 0.0 < o.threshold < 1e-300
+
+    ingest(0)                                    # (process_batch includes the update of batch 0)
+    for c in o.contigs_filt.values():
+        c.coverage[:] = saturated_coverage(c.seq_int, nb=1)
+        c.change_mask[:] = True
+    o.update_wrapper()
+    # the regime: nothing but `tiny` and 0.0 (no LUT value involved, hence bit-equality across CPUs)
+    assert all(int(g["sat_%s_n_other_scores" % n]) == 0 for n in o.contigs_filt)
+    check("sat")
+    ingest(1)
+    check("sat1")
+

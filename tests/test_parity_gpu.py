@@ -275,6 +275,46 @@ def test_saturated_coverage_vs_oracle(in_tmp):
     assert o.threshold < 1e-200
 
 
+def test_saturated_regime_vs_golden(in_tmp):
+    """The reference's own masks and thresholds (1e-304) on the state a long run converges to — every
+    score `tiny` or 0.0 (scenarios.saturated_coverage, tests/golden/g_sat_p1_nb1.npz) — and after one
+    more ordinary batch on top of it.  The coverage goes in through bossx_import, as a resumed run's
+    would."""
+    from scenarios import saturated_coverage
+    from oracle.contig import seq_to_int
+    g = np.load(os.path.join(GOLDEN, "g_sat_p1_nb1.npz"))
+    contigs = e2e_reference()
+    strs = dict(e2e_contig_strings(contigs))
+    runs = _product(1, 1, in_tmp)
+
+    def ingest(b):
+        batch = e2e_batch(contigs, b, 1)
+        assert str(g["b%d_input_digest" % b]) == batch_digest(batch)
+        runs.rl_dist.update(batch["read_lengths"])
+        runs.process_batch_paf(batch["paf"], batch["seqs"])
+
+    def check(tag):
+        assert runs.threshold == float(g[tag + "_threshold"]), tag
+        for cname, pc in runs.contigs.items():
+            key = "%s_%s_" % (tag, cname)
+            assert np.array_equal(pc.strat, unpack_strat(g, key + "strat", pc.strat.shape)), (tag, cname)
+            if pc.rej:
+                continue
+            assert np.array_equal(pc.scores_ds, g[key + "scores_ds"]), (tag, cname)
+            assert np.array_equal(pc.additional_benefit, g[key + "additional_benefit"]), (tag, cname)
+
+    ingest(0)
+    for cname, pc in runs.contigs.items():
+        if pc.rej:
+            continue
+        runs.engine.import_state(pc.index, "coverage", saturated_coverage(seq_to_int(strs[cname]), nb=1))
+        runs.engine.import_state(pc.index, "touched", np.ones(pc.length, dtype=np.uint8))
+    runs.update_wrapper()
+    check("sat")
+    ingest(1)
+    check("sat1")
+
+
 def test_full_size_ecoli_properties(in_tmp):
     """BASELINE configs[1] at full size (4.64 Mb, 4000-read batches) through size-independent
     properties: conservation of ingested bases, bucket sums = coverage sums, idempotence of an
