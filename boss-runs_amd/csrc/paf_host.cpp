@@ -685,25 +685,25 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             err = "internal: emit-run buffer too small";
             return BOSSX_E_INVALID;
         }
-        int nt = in.n_threads > 0 ? in.n_threads : parse_threads();
-        if (plans.size() < 256) nt = 1;
-        nt = int(std::min<size_t>(size_t(nt), plans.size()));
+        int nw = in.n_threads > 0 ? in.n_threads : parse_threads();
+        if (plans.size() < 256) nw = 1;
+        nw = int(std::min<size_t>(size_t(nw), plans.size()));
         // balance by CIGAR bytes (ops_at is their running upper bound)
-        std::vector<size_t> cut(size_t(nt) + 1, plans.size());
+        std::vector<size_t> cut(size_t(nw) + 1, plans.size());
         cut[0] = 0;
-        for (int t = 1; t < nt; ++t) {
-            const size_t want = ops_at * size_t(t) / size_t(nt);
+        for (int t = 1; t < nw; ++t) {
+            const size_t want = ops_at * size_t(t) / size_t(nw);
             size_t lo = cut[size_t(t) - 1], hi = plans.size();
             while (lo < hi) { const size_t mid = (lo + hi) / 2; if (plans[mid].ops_at < want) lo = mid + 1; else hi = mid; }
             cut[size_t(t)] = lo;
         }
-        wos.resize(size_t(nt));
+        wos.resize(size_t(nw));
         auto work = [&](int t) {
             const size_t p0 = cut[size_t(t)], p1 = cut[size_t(t) + 1];
             EmitOp *base = in.ops_buf + (p0 < plans.size() ? plans[p0].ops_at : ops_at);
             walk_plans(in, contigs, plans, p0, p1, base, wos[size_t(t)]);
         };
-        pool_run(nt, work);
+        pool_run(nw, work);
     }
     PT(T3);
     // first failure in record order; the IndexError class only if nothing else failed (the
