@@ -17,7 +17,6 @@ contigs — contiguous runs in FASTA order, which keeps the row-drift halo of
 All of it is latency-bound; with the "nccl" backend (= RCCL over xGMI) the tensors live on
 the GPU, with "gloo" (CPU tests) on the host.  There is no collective on the per-site path.
 """
-import logging
 
 import numpy as np
 

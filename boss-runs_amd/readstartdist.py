@@ -6,7 +6,6 @@ kept COMPACT (one value per 2-kb window and strand); the repeat(20) / pad / trim
 `_expand_fhat` and the later `adjust_length` are pure index arithmetic that the histogram
 kernel applies on the fly (csrc/kernels.hip.inc, threshold_hist_kernel).
 """
-import math
 
 import numpy as np
 from scipy.special import betaln

@@ -15,7 +15,6 @@ from pathlib import Path
 
 import numpy as np
 
-from . import _lib
 from .config import BossConfig
 from .engine import Engine
 from .masks import write_mask_bits
