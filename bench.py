@@ -16,7 +16,8 @@ batches already parsed and resident in HBM are reported beside it as `kernels_on
 
     python bench.py                               # N=1, chr20+chr21 110 Mb ploidy 2 (BASELINE configs[2])
     python bench.py --workload ecoli|barcoded|shard390|grch38
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
+    python bench.py --gpus N                      # starts its own N ranks (one per GPU, RCCL) and relays rank 0's line
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N     # the same under an outer launcher
 """
 import argparse
 import json
@@ -37,7 +38,7 @@ CHAIN_FLOOR_CYCLES = 5.1    # one dependent FP64 matrix op (20.4 cycles with acc
 WORKLOADS = {
     # name: (contig lengths, names, ploidy, nbarcodes, reject, preload depth)
     "ecoli": ([4_641_652], ["ecoli_K12"], 1, 1, None, 0.0),
-    "chr20_21": ([64_444_167, 46_709_983], ["chr20", "chr21"], 2, 1, None, 8.0),
+    "chr20_21": ([64_444_167, 46_709_983, 16_569], ["chr20", "chr21", "MT"], 2, 1, "MT", 8.0),
     "shard390": ([248_956_422, 138_394_717], ["chr1", "chr9"], 2, 1, None, 8.0),
     "barcoded": ([5_000_000] * 10, ["bac%02d" % i for i in range(10)], 1, 8, None, 0.0),
 }
@@ -86,7 +87,7 @@ def generate_batches(jobs):
     paths = [os.path.join(cache, "batch_%s_%d_%d_%d.pkl" % j) for j in jobs] if cache else []
     if cache and all(os.path.exists(p) for p in paths):
         return [pickle.load(open(p, "rb")) for p in paths]
-    n = min(len(jobs), max(1, min(32, (os.cpu_count() or 1))))
+    n = min(len(jobs), max(1, min(int(os.environ.get("BOSSX_GEN_PROCS", "32")), (os.cpu_count() or 1))))
     if n <= 1:
         out = [_gen_one(j) for j in jobs]
     else:
@@ -121,6 +122,8 @@ def make_runs(workload, mine, rank, world, device, track_entropy):
     args.optional.bucket_threshold = 0        # strategies on from the first update
     args.gpu.device = device
     args.gpu.track_entropy = bool(track_entropy)
+    if reject:       # BASELINE configs[2]: reject_refs=MT (the 16.5-kb MT is dropped by the 100-kb filter first, reference.py:330-337)
+        args.optional.reject_refs = ",".join("%s_r%d" % (reject, r) for r in range(world))
     if nb > 1:
         args.general.barcodes = ["barcode%02d" % (i + 1) for i in range(nb)]
     if world == 1 and not os.environ.get("BOSSX_FORCE_COLLECTIVES"):
@@ -136,7 +139,7 @@ def make_runs(workload, mine, rank, world, device, track_entropy):
         # masks stay on their owner rank in the timed loop (the all-gather to rank 0 is only
         # needed when boss.npz is written; halo rows are still exchanged every update)
         runs.init(contigs=[(n, mine_d.get(n, L)) for n, L in allc], sharded_reads=True, gather_masks=False)
-        assert all(not runs.contigs[n].remote for n in mine_d), "partition must give each rank its own contigs"
+        assert all(not runs.contigs[n].remote for n in mine_d if n in runs.contigs), "partition must give each rank its own contigs"
     runs.write_masks = False                  # npz write is reported separately
     runs.log_fractions = False
     if preload > 0:
@@ -300,7 +303,8 @@ def cpu_baseline_like_for_like(runs, contigs, workload, batch):
     from boss_runs_amd import synth
     from oracle.pipeline import OracleRuns
     lens, names, ploidy, nb, reject, preload = WORKLOADS[workload]
-    o = OracleRuns([(n, synth.codes_to_str(c)) for n, c in contigs], ploidy=ploidy, nbarcodes=nb, bucket_threshold=0)
+    o = OracleRuns([(n, synth.codes_to_str(c)) for n, c in contigs], ploidy=ploidy, nbarcodes=nb, bucket_threshold=0,
+                   reject_refs={"%s_r0" % reject} if reject else ())
     for name, oc in o.contigs_filt.items():
         pc = runs.contigs[name]
         oc.coverage[:] = pc.coverage
@@ -487,8 +491,47 @@ def emit_json(obj):
     out.flush()
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher around it: this process never touches a GPU —
+    it starts N fresh ranks (one per GPU, `torch.distributed.run` on 127.0.0.1, RCCL over xGMI) of
+    this same script and relays rank 0's single JSON line.  (Under the driver's own
+    `python -m torch.distributed.run ... bench.py --gpus N` the ranks already exist: RANK / WORLD_SIZE
+    are set and this function is not reached.)"""
+    import socket
+    import subprocess
+    import torch
+    n_dev = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if n_dev < a.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (a.gpus, n_dev))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # N ranks share the host: bound each rank's parser pool and generator pool
+    ncpu = os.cpu_count() or 1
+    env.setdefault("BOSSX_PARSE_THREADS", str(max(2, min(16, ncpu // a.gpus))))
+    env.setdefault("BOSSX_GEN_PROCS", str(max(1, min(32, ncpu // a.gpus))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = []
+    for line in p.stdout:
+        if line.lstrip().startswith("{"):
+            lines.append(line.strip())
+        else:
+            sys.stderr.write(line)
+    rc = p.wait()
+    if rc != 0 or not lines:
+        raise SystemExit("bench.py --gpus %d: the ranks exited with code %d and %d result line(s)" % (a.gpus, rc, len(lines)))
+    sys.stdout.write(lines[-1] + "\n")
+    sys.stdout.flush()
+
+
 def main():
     a = parse_args()
+    if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and not a.prepare_only:
+        return spawn_ranks(a)
     if not a.prepare_only:
         own_stdout()
     rank = int(os.environ.get("RANK", "0"))
@@ -626,9 +669,10 @@ def main():
             "value": value, "unit": "Mbp/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u16+f64", "data": "synthetic",
-            "config": {"workload": "%s: %s bp, ploidy %d, nbarcodes %d, %d-read PAF batches (mean 6 kb), per GPU; "
+            "config": {"workload": "%s: %s bp%s, ploidy %d, nbarcodes %d, %d-read PAF batches (mean 6 kb), per GPU; "
                                    "step = PAF text + reads in host memory -> masks in host memory"
                        % (workload, "+".join("%d" % c[1].shape[0] for c in contigs),
+                          (" (reject_refs=%s)" % WORKLOADS[workload][4]) if WORKLOADS[workload][4] else "",
                           WORKLOADS[workload][2], nb, a.reads),
                        "sites_per_gpu": G, "aligned_bases_per_batch": aligned,
                        "track_entropy": bool(a.track_entropy),

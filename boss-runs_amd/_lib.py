@@ -52,6 +52,11 @@ class UpdateResult(C.Structure):
                 ("ubar0", C.c_double)]
 
 
+# private binding helper (csrc/bossx_py.h): not part of the C-ABI
+PRIVATE_PROTOTYPES = {
+    "bossx_py_str_pointers": (C.c_int, [C.py_object, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
 # name -> (restype, argtypes); every symbol include/bossx.h declares
 PROTOTYPES = {
     "bossx_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
@@ -76,7 +81,6 @@ PROTOTYPES = {
     "bossx_rl_update": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
                                   C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                   C.c_void_p, C.POINTER(C.c_int32)]),
-    "bossx_py_str_pointers": (C.c_int, [C.py_object, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bossx_host_parse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                    C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
@@ -170,7 +174,7 @@ def load_gil():
     if _pylib is None:
         load()
         _pylib = C.PyDLL(LIB_PATH)
-        res, args = PROTOTYPES["bossx_py_str_pointers"]
+        res, args = PRIVATE_PROTOTYPES["bossx_py_str_pointers"]
         _pylib.bossx_py_str_pointers.restype = res
         _pylib.bossx_py_str_pointers.argtypes = args
     return _pylib

@@ -108,6 +108,8 @@ struct bossx_engine {
     double pending_emit = 0, pending_ops = 0;
     bool touched_dirty = false;     // the `touched` byte array holds flags the next sweep must read
     bool full_sweep_needed = true;  // bin sums / bucket sums are not current everywhere (start, import, preload): sweep every tile
+    bool dz_fresh = false;          // the last sweep may have zeroed sites by dropout for the first time (see launch_sweep)
+    std::unordered_map<const void *, size_t> lds_granted;   // dynamic LDS each chain kernel has been cleared for ON THIS DEVICE
     std::vector<int32_t> last_thr;  // dropout threshold each contig was last swept with
     uint32_t *d_tile_cov = nullptr; // [nb][n_tiles] depth total of each tile at its last sweep
     uint32_t *d_tile_ref = nullptr;
@@ -767,6 +769,16 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
     bossx_engine::Staged &st = h->slots[size_t(h->slot)];
     st.valid = false;
     st.emit_tiles_built = false;
+    // Inputs are borrowed for the call only: the worker threads start asynchronous copies out of the
+    // caller's text (and, on the bossx_stage_batch path, out of its pageable read blob), so no way out
+    // of this function may leave one in flight.
+    struct UploadGuard {
+        bossx_engine *h; bool ok = false;
+        ~UploadGuard() {
+            if (ok) return;
+            hipStreamSynchronize(h->stream_txt); hipStreamSynchronize(h->stream_up); hipStreamSynchronize(h->stream);
+        }
+    } upload_guard{h};
     // slack: the ingest prologue reads a 384-byte window that may start at the last base
     if ((rc = grow_dev(h, &st.d_blob, &st.blob_cap, blob_bytes + 1024, 0))) return rc;
     ParseInput in{paf ? paf : "", paf ? paf_len : 0, names, name_off, seq_off, barcodes, n_reads, min_len, h->nb};
@@ -844,10 +856,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
         in.n_tiles = h->n_tiles;
         std::string err;
         rc = parse_paf_batch(in, h->contigs, h->index, summary, pb, err);
-        if (rc) {                                          // inputs are borrowed for the call only
-            hipStreamSynchronize(h->stream_txt); hipStreamSynchronize(h->stream_up); hipStreamSynchronize(h->stream);
-            return fail(h, rc, err);
-        }
+        if (rc) return fail(h, rc, err);                  // (upload_guard drains the copies)
         HIPCHK(up_err);
         const auto t1 = std::chrono::steady_clock::now();
         auto t_launched = t1;
@@ -930,6 +939,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
     if (aligned_bases) *aligned_bases = int64_t(pb.total_emit);
     st.pb = std::move(pb);
     st.valid = true;
+    upload_guard.ok = true;
     return BOSSX_OK;
 }
 
@@ -1067,7 +1077,17 @@ int launch_sweep(bossx_engine *h) {
     for (size_t k = 0; k < thr.size(); ++k) thr_changed = thr_changed || thr[k] != h->last_thr[k];
     const char *inc_env = getenv("BOSSX_INCREMENTAL");
     const bool want_inc = inc_env ? atoi(inc_env) != 0 : n_touched * 2 < size_t(h->n_tiles);
-    const bool full = h->full_sweep_needed || h->touched_dirty || thr_changed || split || !want_inc;
+    // The reference looks every site that dropout zeroed up again at the NEXT update (`scores == 0.0`,
+    // sequences.py:433-441) and writes its entropy then.  New zeros only appear in a sweep whose
+    // threshold moved (or after an import / preload): coverage only grows, so under an unchanged
+    // threshold no site falls to or below it.  The update after such a sweep therefore sweeps every
+    // tile once more when the entropy array is kept — an untouched tile would otherwise hold the
+    // entropy (and the SCORED bit) of its freshly zeroed sites back until it next receives a base.
+    const bool dz_resweep = h->dz_fresh && h->d_entropy && !getenv("BOSSX_NO_DZ_RESWEEP");
+    const bool full = h->full_sweep_needed || h->touched_dirty || thr_changed || split || !want_inc || dz_resweep;
+    bool any_thr = false;
+    for (int32_t t : thr) any_thr = any_thr || t >= 0;
+    h->dz_fresh = any_thr && (h->full_sweep_needed || h->touched_dirty || thr_changed);
     // The chain of this update may run NEXT TO the sweep (second stream, tiles handed over as they
     // are published).  Measured on MI355X it no longer pays by default: the concurrent chain variant
     // is ~8 % slower than the serial one (agent-scope loads, flag polling), a publishing sweep is
@@ -1198,10 +1218,8 @@ int bossx_get_bucket_sums(bossx_engine *h, int32_t contig, uint64_t *dst) {
     HIPCHK(hipMemcpyAsync(&flag, h->d_err, sizeof(flag), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (flag) {
-        const int32_t flag_bits = flag;
         HIPCHK(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
-        return fail(h, BOSSX_E_RANGE, (flag_bits & 8) ? "a coverage counter reached 8192: beyond the depth this engine scores exactly (the reference's uint16 counters wrap at 65536)"
-                                                      : "a read contains a base other than A/C/G/T inside an aligned segment");
+        return fail(h, BOSSX_E_RANGE, "a read contains a base other than A/C/G/T inside an aligned segment");
     }
     return BOSSX_OK;
 }
@@ -1271,30 +1289,29 @@ int fill_chain_params(bossx_engine *h, const int32_t *windows, const double *mul
 }
 
 extern "C++" {
-template <bool MATRIX, bool LIVE, int CH>
-void launch_chain_variant(dim3 grid, dim3 block, size_t lds, hipStream_t stream, const ChainParams &P) {
-    static size_t allowed = 0;                   // dynamic LDS this instantiation has been cleared for
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: the size each
+// instantiation has been cleared for is remembered per ENGINE (= per device), not per process.
+void grant_lds(bossx_engine *h, const void *fn, size_t lds) {
+    size_t &allowed = h->lds_granted[fn];
     if (lds > allowed) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_kernel<MATRIX, LIVE, CH>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         allowed = lds;
     }
+}
+template <bool MATRIX, bool LIVE, int CH>
+void launch_chain_variant(bossx_engine *h, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const ChainParams &P) {
+    grant_lds(h, reinterpret_cast<const void *>(benefit_chain_kernel<MATRIX, LIVE, CH>), lds);
     hipLaunchKernelGGL((benefit_chain_kernel<MATRIX, LIVE, CH>), grid, block, lds, stream, P);
 }
 template <bool LIVE, int CH, int NBD, int CE>
-void launch_chain_flow_ce(dim3 grid, dim3 block, size_t lds, hipStream_t stream, const ChainParams &P) {
-    static size_t allowed = 0;
-    if (lds > allowed) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(benefit_chain_flow_kernel<LIVE, CH, NBD, CE>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-        allowed = lds;
-    }
+void launch_chain_flow_ce(bossx_engine *h, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const ChainParams &P) {
+    grant_lds(h, reinterpret_cast<const void *>(benefit_chain_flow_kernel<LIVE, CH, NBD, CE>), lds);
     hipLaunchKernelGGL((benefit_chain_flow_kernel<LIVE, CH, NBD, CE>), grid, block, lds, stream, P);
 }
 template <bool LIVE, int CH, int NBD>
-void launch_chain_flow(int ce, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const ChainParams &P) {
-    if (ce == 1) launch_chain_flow_ce<LIVE, CH, NBD, 1>(grid, block, lds, stream, P);
-    else launch_chain_flow_ce<LIVE, CH, NBD, 2>(grid, block, lds, stream, P);
+void launch_chain_flow(bossx_engine *h, int ce, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const ChainParams &P) {
+    if (ce == 1) launch_chain_flow_ce<LIVE, CH, NBD, 1>(h, grid, block, lds, stream, P);
+    else launch_chain_flow_ce<LIVE, CH, NBD, 2>(h, grid, block, lds, stream, P);
 }
 }  // extern "C++"
 
@@ -1317,14 +1334,14 @@ void launch_chain(bossx_engine *h, const ChainParams &P, size_t lds, hipStream_t
     if (h->matrix_chain && h->chain_flow && ch == 256 && h->chain_flow_fits) {
         // as many buffers between the stages as the LDS holds next to the ring of the current windows
         const int ce = h->chain_flow_ce;
-        if (h->chain_flow_bufs == 5) { if (live) launch_chain_flow<true, 256, 5>(ce, grid, block, lds, stream, P); else launch_chain_flow<false, 256, 5>(ce, grid, block, lds, stream, P); }
-        else { if (live) launch_chain_flow<true, 256, 4>(ce, grid, block, lds, stream, P); else launch_chain_flow<false, 256, 4>(ce, grid, block, lds, stream, P); }
+        if (h->chain_flow_bufs == 5) { if (live) launch_chain_flow<true, 256, 5>(h, ce, grid, block, lds, stream, P); else launch_chain_flow<false, 256, 5>(h, ce, grid, block, lds, stream, P); }
+        else { if (live) launch_chain_flow<true, 256, 4>(h, ce, grid, block, lds, stream, P); else launch_chain_flow<false, 256, 4>(h, ce, grid, block, lds, stream, P); }
     } else if (h->matrix_chain) {
-        if (ch == 256) { if (live) launch_chain_variant<true, true, 256>(grid, block, lds, stream, P); else launch_chain_variant<true, false, 256>(grid, block, lds, stream, P); }
-        else { if (live) launch_chain_variant<true, true, 128>(grid, block, lds, stream, P); else launch_chain_variant<true, false, 128>(grid, block, lds, stream, P); }
+        if (ch == 256) { if (live) launch_chain_variant<true, true, 256>(h, grid, block, lds, stream, P); else launch_chain_variant<true, false, 256>(h, grid, block, lds, stream, P); }
+        else { if (live) launch_chain_variant<true, true, 128>(h, grid, block, lds, stream, P); else launch_chain_variant<true, false, 128>(h, grid, block, lds, stream, P); }
     } else {
-        if (ch == 256) { if (live) launch_chain_variant<false, true, 256>(grid, block, lds, stream, P); else launch_chain_variant<false, false, 256>(grid, block, lds, stream, P); }
-        else { if (live) launch_chain_variant<false, true, 128>(grid, block, lds, stream, P); else launch_chain_variant<false, false, 128>(grid, block, lds, stream, P); }
+        if (ch == 256) { if (live) launch_chain_variant<false, true, 256>(h, grid, block, lds, stream, P); else launch_chain_variant<false, false, 256>(h, grid, block, lds, stream, P); }
+        else { if (live) launch_chain_variant<false, true, 128>(h, grid, block, lds, stream, P); else launch_chain_variant<false, false, 128>(h, grid, block, lds, stream, P); }
     }
     // algorithmic bytes: read the downsampled scores once per direction, write both strands
     time_end(h, BOSSX_K_BENEFIT, double(h->B) * h->nb * (2 * 8.0 + 2 * 8.0), stream);
@@ -1707,10 +1724,8 @@ int bossx_dist_finish(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, b
     if (strat_all && (rc = copy_masks(h, strat_all, false))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     if (*herr) {
-        const int32_t flag_bits = *herr;
         HIPCHK(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
-        return fail(h, BOSSX_E_RANGE, (flag_bits & 8) ? "a coverage counter reached 8192: beyond the depth this engine scores exactly (the reference's uint16 counters wrap at 65536)"
-                                                      : "a read contains a base other than A/C/G/T inside an aligned segment");
+        return fail(h, BOSSX_E_RANGE, "a read contains a base other than A/C/G/T inside an aligned segment");
     }
     if (contig_on) {
         for (size_t i = 0; i < h->contigs.size(); ++i) contig_on[i] = 0;
@@ -1910,10 +1925,8 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
     }
     if (hc->any_on) h->host_armed = true;
     if (*herr) {
-        const int32_t flag_bits = *herr;
         HIPCHK(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
-        return fail(h, BOSSX_E_RANGE, (flag_bits & 8) ? "a coverage counter reached 8192: beyond the depth this engine scores exactly (the reference's uint16 counters wrap at 65536)"
-                                                      : "a read contains a base other than A/C/G/T inside an aligned segment");
+        return fail(h, BOSSX_E_RANGE, "a read contains a base other than A/C/G/T inside an aligned segment");
     }
     if (contig_on) {
         for (size_t i = 0; i < h->contigs.size(); ++i) contig_on[i] = 0;

@@ -10,6 +10,7 @@
 // (ValueError/AssertionError -> BOSSX_E_PARSE, KeyError -> BOSSX_E_KEY, IndexError ->
 // BOSSX_E_RANGE); on error nothing is ingested.
 #include "engine.hpp"
+#include "bossx_py.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -349,8 +350,17 @@ class WorkPool {
         if (first_only) return;
         while ((i = j.next_rest.fetch_add(1)) < j.n) { (*j.fn)(i); j.pending.fetch_sub(1, std::memory_order_release); }
     }
+    // Workers never outnumber the host's other hardware threads, and an explicit BOSSX_PARSE_THREADS
+    // bounds the pool as well as the line parse (tasks are pulled dynamically: fewer workers still
+    // finish the job, the caller takes part).
+    static int worker_cap() {
+        const unsigned hc = std::thread::hardware_concurrency();
+        int cap = std::min<int>(hc > 1 ? int(hc) - 1 : 0, 63);
+        if (getenv("BOSSX_PARSE_THREADS")) cap = std::min(cap, parse_threads() - 1);
+        return std::max(cap, 0);
+    }
     void ensure(int want) {
-        want = std::min(want, 63);
+        want = std::min(want, worker_cap());
         std::lock_guard<std::mutex> lk(m_);
         while (int(threads_.size()) < want) threads_.emplace_back([this] { loop(); });
     }
@@ -990,7 +1000,7 @@ extern "C" int bossx_paf_select_lines(const char *paf, size_t paf_len, const cha
     return BOSSX_OK;
 }
 
-// Binding helper for CPython callers (include/bossx.h): buffer pointer + length of every str in
+// Binding helper for CPython callers (bossx_py.h, private): buffer pointer + length of every str in
 // the Python list `list` through the interpreter's own PyList_GetItem / PyUnicode_AsUTF8AndSize
 // (passed in by address, so this library does not link against libpython).  Must be called
 // with the GIL held (ctypes.PyDLL).

@@ -115,8 +115,8 @@ class BossRuns(Boss):
     def init(self, contigs=None, engine=None, is_local=None, mapper=None) -> None:
         """boss/runs/core.py:23-55.  `contigs` optionally replaces the FASTA with an iterable
         of (name, sequence).  `mapper`: a reference-shaped mapper (boss/mapper.py:27: `mu`,
-        `_mappy_batch` / `map_sequences`); without one, the reference's own construction
-        `Mapper(ref=self.ref.mmi)` (core.py:41-42) is attempted when an index is configured."""
+        `_mappy_batch` / `map_sequences`) — what the reference builds at core.py:41-42; without one
+        only `process_batch_paf` (PAF text supplied by the caller) is available."""
         a = self.args
         if not a.general.barcodes:
             self.barcodes_index = {"": 0}
@@ -131,13 +131,7 @@ class BossRuns(Boss):
         self.contigs = self.ref.contigs
         self.contigs_filt = {n: c for n, c in self.contigs.items() if not c.rej}
         self.contig_names = list(self.contigs.keys())
-        self.mapper = mapper
-        if mapper is None and a.general.mmi:
-            try:
-                from .mapper import Mapper
-                self.mapper = Mapper(ref=self.ref.mmi)
-            except ImportError as e:           # mappy not installed: PAF text has to be supplied
-                logging.info("no mapper: %s", e)
+        self.mapper = mapper           # minimap2 itself is upstream of this path: the caller attaches its Mapper
         self.read_counts = {n: 0 for n in self.contigs}          # AbundanceTracker
         self.total_reads = 0
         self.read_starts = ReadStartDist(contigs=self.contigs_filt)

@@ -140,13 +140,6 @@ int bossx_rl_update(uint16_t *hist, int64_t hist_len, const int64_t *lens, int64
                     int64_t min_len_exclusive, int32_t eta, int64_t *hi_inout,
                     double *lam, int64_t *longest_read, int32_t *approx_ccl, int32_t *observed);
 
-/* CPython binding helper: pointer + length of the UTF-8 buffer of each str in the Python list
- * `list` (a PyObject*), obtained through the addresses of the interpreter's PyList_GetItem and
- * PyUnicode_AsUTF8AndSize; lets the ctypes layer hand a dict of reads to
- * bossx_stage_batch_ptrs without one ctypes call per read.  Call with the GIL held.            */
-int bossx_py_str_pointers(void *list, int64_t n, void *list_get_item, void *as_utf8_and_size,
-                          const char **ptrs, int64_t *lens);
-
 /* Host-only check of the PAF front end: no engine, no device.  Parses exactly like
  * bossx_stage_batch_ptrs (same filters, mapping choice, CIGAR walk, error codes; `n_threads`
  * 0 = default) for contigs given as names / lengths / BOSSX_CONTIG_* flags, verifies the tile

@@ -335,3 +335,145 @@ def test_index_error_batches_ingest_nothing(in_tmp):
         assert np.array_equal(runs.contigs[n].strat, strat_before[n]), n
     good(2)
     good(3)
+
+
+def test_grch38_geometry_one_gpu(in_tmp):
+    """BASELINE configs[3] geometry on ONE GPU (the whole 3.1 Gb reference fits one MI355X): the 24
+    chromosome lengths of GRCh38 + MT (dropped by the 100-kb filter, reference.py:330-331) + three
+    scaffolds >= 100 kb = 27 contigs, 1.5 M sweep tiles, 31 M bins, chr1's 2.49 M-bin move_sum chain,
+    26 rows of drift in _distribute_strategy (core.py:125-155), packed masks (`mask_format="bits"`).
+    ~8x preloaded depth, then two 4000-read updates.
+      * oracle, every per-site / per-bin array, on the three scaffolds (contig-local stages);
+      * the oracle's strategy stage (find_strat_thread + _distribute_strategy) over ALL 31 M bins:
+        threshold, chosen exponent, normaliser, and every contig's mask;
+      * properties at full size: every 20-kb bucket of every contig gains exactly the aligned bases
+        the batch's chosen mappings put there (conservation), bucket sums = coverage sums (chr21),
+        masks stay 1 outside switched-on buckets, an update without reads changes nothing."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.runs import BossRuns
+    from oracle.contig import OContig, adjust_length
+    from oracle.dists import OReadlengthDist, OReadStartDist
+    from oracle.model import SiteModel, PatternCache
+    from oracle.pafcigar import parse_paf, convert_records, best_mapper
+    from oracle.strategy import find_strategy, distribute
+    names = ["chr%d" % (i + 1) for i in range(22)] + ["chrX", "chrY"]
+    allc = list(zip(names, synth.GRCH38_LENS)) + [("MT", synth.MT_LEN), ("scaf_150k", 150_000),
+                                                   ("scaf_250k", 250_000), ("scaf_400k", 400_000)]
+    kept = [(n, L) for n, L in allc if L >= 100_000]
+    assert len(kept) == 27
+    codes = {n: np.random.default_rng(9000 + i).integers(0, 4, size=L, dtype=np.uint8) for i, (n, L) in enumerate(allc)}
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    args = BossConfig()
+    args.general.name = "grch38"
+    args.optional.ploidy = 2
+    args.optional.reject_refs = "MT"
+    args.optional.bucket_threshold = 8          # Poisson(8) buckets: about half of them switch on
+    args.gpu.mask_format = "bits"
+    args.gpu.track_entropy = True
+    runs = BossRuns(args)
+    runs.init(contigs=((n, acgt[codes[n]].tobytes()) for n, _ in allc))
+    runs.write_masks = False
+    runs.log_fractions = False
+    eng = runs.engine
+    assert list(runs.contigs) == [n for n, _ in kept]
+    assert runs.ref.n_sites == sum(L for _, L in kept) == 3_089_069_832
+    assert eng.merged_bins == sum(L // 100 + 1 for _, L in kept)
+    eng.preload_coverage(8.0, seed=17)
+    scaffolds = ["scaf_150k", "scaf_250k", "scaf_400k"]
+    cache = PatternCache(SiteModel(2))
+    ocs = {}
+    for n in scaffolds:
+        oc = OContig(n, acgt[codes[n]].tobytes().decode(), nbarcodes=1)
+        pc = runs.contigs[n]
+        oc.coverage[:] = pc.coverage
+        oc.change_mask[:] = eng.export(pc.index, "touched")[:, None].astype(bool)
+        ocs[n] = oc
+    o_rl = OReadlengthDist()
+    o_rs = OReadStartDist({n: runs.contigs[n] for n, _ in kept})
+    expect = {n: np.ones((L // 100, 2, 1), dtype=bool) for n, L in kept}
+    thr_b = args.optional.bucket_threshold
+
+    def oracle_update(step, inc):
+        for n, oc in ocs.items():
+            if inc is not None:
+                oc.increment_coverage(inc.get(n, []))
+            oc.update_scores(cache)
+            oc.modify_scores()
+            oc.check_buckets(threshold=thr_b)
+            oc.calc_smu()
+            oc.calc_u(o_rl.approx_ccl)
+            pc = runs.contigs[n]
+            assert np.array_equal(pc.coverage, oc.coverage), (step, n)
+            assert np.array_equal(pc.scores, oc.scores), (step, n)
+            assert np.array_equal(pc.entropy, oc.entropy), (step, n)
+            assert np.array_equal(pc.bucket_switches, oc.bucket_switches), (step, n)
+            assert np.array_equal(pc.scores_ds, oc.scores_ds), (step, n)
+            assert np.array_equal(pc.additional_benefit, oc.additional_benefit), (step, n)
+        # strategy stage over all 27 contigs: the other blocks come from the device, whose
+        # per-contig stages are the ones verified above (and at 111 Mb in test_chr20_21_full_size_vs_oracle)
+        benefit = np.concatenate([runs.contigs[n].additional_benefit for n, _ in kept])
+        fhat = o_rs.update_f_pointmass()[:, :, np.newaxis]
+        target = runs.ref.n_sites // 100
+        detail = {}
+        strat, thr = find_strategy(adjust_length(target, benefit), adjust_length(target, benefit),
+                                   adjust_length(target, fhat), o_rl.time_cost, detail=detail)
+        del benefit, fhat
+        assert runs.threshold == thr, step
+        assert runs.last_stats["strat_size"] == detail["strat_size"], step
+        assert runs.last_stats["normaliser"] == detail["normaliser"], step
+        sw = {n: runs.contigs[n].bucket_switches for n, _ in kept}
+        stand = {n: _StandIn(L, 1, expect[n], sw[n]) for n, L in kept}
+        distribute(stand, strat)
+        some_on = some_off = False
+        for n, L in kept:
+            got = runs.contigs[n].strat
+            assert np.array_equal(got, expect[n]), (step, n)
+            on_rows = np.repeat(sw[n][:, 0], 200)[: L // 100]
+            assert got[~on_rows].all(), (step, n)            # rows of buckets still off keep the initial 1
+            some_on, some_off = some_on or on_rows.any(), some_off or (~on_rows).any()
+        assert some_on and some_off
+
+    prime_rl = {"p%d" % i: 3000 + 41 * i for i in range(300)}
+    runs.rl_dist.update(prime_rl)
+    o_rl.update(prime_rl)
+    runs.update_wrapper()
+    oracle_update("prime", None)
+    contig_list = [(n, codes[n]) for n, _ in kept]
+    # the scaffolds are 0.03 % of the genome: weight them up so that the oracle sees their increments
+    w = np.ones(len(kept))
+    w[-3:] = 400.0
+    for b in range(2):
+        bs0 = {n: eng.bucket_sums(runs.contigs[n].index)[0].copy() for n, _ in kept}
+        batch = synth.make_batch(contig_list, 4000, seed=38000 + b, extras=True, start_weights=w)
+        paf = parse_paf(batch["paf"], min_len=200)
+        o_rl.update(batch["read_lengths"])
+        o_rs.count_read_starts(paf)
+        inc = convert_records({k: v for k, v in paf.items() if any(r.tname in scaffolds for r in v)}, batch["seqs"])
+        runs.rl_dist.update(batch["read_lengths"])
+        runs.process_batch_paf(batch["paf"], batch["seqs"])
+        assert np.array_equal(runs.rl_dist.approx_ccl, o_rl.approx_ccl)
+        assert np.array_equal(runs.read_starts.merge(), o_rs.merge())
+        oracle_update(b, inc)
+        # conservation, bucket by bucket, genome-wide: every emitted reference base of every chosen mapping
+        gain = {n: np.zeros(L // 20000, dtype=np.uint64) for n, L in kept}
+        for recs in paf.values():
+            r = best_mapper(recs) if len(recs) > 1 else recs[0]
+            if r.tname not in gain:
+                continue
+            g = gain[r.tname]
+            for q in range(r.tstart // 20000, min((r.tend - 1) // 20000, g.shape[0] - 1) + 1):
+                g[q] += np.uint64(max(0, min(r.tend, (q + 1) * 20000) - max(r.tstart, q * 20000)))
+        for n, _ in kept:
+            assert np.array_equal(eng.bucket_sums(runs.contigs[n].index)[0] - bs0[n], gain[n]), (b, n)
+    c21 = runs.contigs["chr21"]
+    depth = c21.coverage.sum(axis=1, dtype=np.uint64)[:, 0]
+    nfull = c21.length // 20000
+    assert np.array_equal(eng.bucket_sums(c21.index)[0], depth[: nfull * 20000].reshape(-1, 20000).sum(axis=1))
+    del depth
+    # idempotence: an update without new reads changes neither the threshold nor a single mask bit
+    thr1, bits1 = runs.threshold, eng.strat_bits.copy()
+    runs.update_wrapper()
+    assert runs.threshold == thr1 and np.array_equal(eng.strat_bits, bits1)
+    frac = float(np.mean([runs.contigs[n].strat.mean() for n in ("chr1", "chr21", "scaf_400k")]))
+    assert 0.0 < frac < 1.0

@@ -757,6 +757,7 @@ def test_random_scenarios_vs_oracle(in_tmp, seed):
             pc = runs.contigs[n]
             assert np.array_equal(pc.coverage, oc.coverage), (seed, b, n)
             assert np.array_equal(pc.scores, oc.scores), (seed, b, n)
+            assert np.array_equal(pc.entropy, oc.entropy), (seed, b, n)
             assert np.array_equal(pc.bucket_switches, oc.bucket_switches), (seed, b, n)
             assert np.array_equal(pc.strat, oc.strat), (seed, b, n)
             if o.threshold is not None:
@@ -955,13 +956,29 @@ def test_stagewise_consumers_recover_from_a_timed_out_chain(in_tmp, monkeypatch)
             assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize("seed", [21, 22, 23, 24])
+def _drop_mappings_into(batch, contig, lo, hi):
+    """Remove the PAF lines whose target interval overlaps [lo, hi) of `contig`: a stretch that never
+    receives a base (a deletion in the sampled genome: what dropout is for)."""
+    keep = []
+    for line in batch["paf"].split("\n"):
+        f = line.split("\t")
+        if len(f) > 8 and f[5] == contig and int(f[7]) < hi and int(f[8]) > lo:
+            continue
+        keep.append(line)
+    batch["paf"] = "\n".join(keep)
+    return batch
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23, 24, 25])
 def test_incremental_sweep_vs_oracle(in_tmp, monkeypatch, seed):
     """Only the tiles a batch touches are swept when no contig's dropout threshold moved
-    (BOSSX_INCREMENTAL=1 forces it whenever legal): bin sums, bucket sums and masks of the untouched
-    tiles must stay exactly what a full sweep (and the oracle, which recomputes everything every
-    update) gives — through threshold changes, dropout activation, empty batches, sparse batches on
-    a few Mb, with the chain next to the sweep."""
+    (BOSSX_INCREMENTAL=1 forces it whenever legal): bin sums, bucket sums, masks AND the per-site
+    entropy of the untouched tiles must stay exactly what a full sweep (and the oracle, which
+    recomputes everything every update) gives — through threshold changes, dropout activation, empty
+    batches, sparse batches on a few Mb, with the chain next to the sweep.  Seed 25: ploidy 2 and a
+    40-kb stretch that no read ever reaches — its never-scored sites are zeroed by dropout at the
+    dense batch and the reference writes their (diploid) entropy at the NEXT update
+    (sequences.py:433-441), whether or not their tiles receive a base then."""
     from boss_runs_amd import synth
     from boss_runs_amd.config import BossConfig
     from boss_runs_amd.runs import BossRuns
@@ -972,6 +989,9 @@ def test_incremental_sweep_vs_oracle(in_tmp, monkeypatch, seed):
     lens = [int(rng.integers(600_000, 1_500_000)), int(rng.integers(100_000, 400_000))]
     nb = int(rng.choice([1, 2]))
     ploidy = int(rng.choice([1, 2]))
+    hole = None
+    if seed == 25:
+        nb, ploidy, hole = 1, 2, (300_000, 340_000)
     contigs = synth.make_reference(lens, seed=seed, names=["big", "small"])
     strs = [(n, synth.codes_to_str(c)) for n, c in contigs]
     args = BossConfig()
@@ -991,6 +1011,8 @@ def test_incremental_sweep_vs_oracle(in_tmp, monkeypatch, seed):
             n_reads = 2500 if b == 2 else int(rng.integers(30, 200))
             w = [1.0, 0.3] if b % 2 else [0.2, 2.0]
             batch = synth.make_batch(contigs, n_reads, seed=seed * 100 + b, mean_len=5000.0, nbarcodes=nb, start_weights=w)
+            if hole:
+                _drop_mappings_into(batch, "big", *hole)
         bcs = batch["barcodes"] if nb > 1 else None
         o.process_batch(batch["paf"], batch["seqs"], read_lengths=batch["read_lengths"], barcodes=bcs)
         runs.rl_dist.update(batch["read_lengths"])
@@ -1000,6 +1022,7 @@ def test_incremental_sweep_vs_oracle(in_tmp, monkeypatch, seed):
             pc = runs.contigs[n]
             assert np.array_equal(pc.coverage, oc.coverage), (seed, b, n)
             assert np.array_equal(pc.scores, oc.scores), (seed, b, n)
+            assert np.array_equal(pc.entropy, oc.entropy), (seed, b, n)
             assert np.array_equal(pc.bucket_switches, oc.bucket_switches), (seed, b, n)
             assert np.array_equal(pc.strat, oc.strat), (seed, b, n)
             if o.threshold is not None:
@@ -1011,3 +1034,108 @@ def test_incremental_sweep_vs_oracle(in_tmp, monkeypatch, seed):
             for k in range(nb):
                 assert np.array_equal(bs[k], depth[: nfull * 20000, k].reshape(-1, 20000).sum(axis=1)), (seed, b, n, k)
     assert o.threshold is not None
+    if hole:
+        big = o.contigs["big"]
+        never = big.coverage[hole[0]:hole[1]].sum(axis=(1, 2)) == 0
+        assert never.all() and (big.scores[hole[0]:hole[1]] == 0.0).all()          # zeroed by dropout, never touched
+        # ... and their entropy is the diploid table's, not the haploid initial fill
+        from oracle.model import SiteModel
+        assert (big.entropy[hole[0]:hole[1], 0] != SiteModel(1).ent0[0]).all()
+
+
+def _exact_reads(contigs, name, spans, prefix):
+    """PAF lines + sequences of error-free '+' reads covering the given (start, end) target spans."""
+    codes = dict(contigs)[name]
+    L = codes.shape[0]
+    lines, seqs = [], {}
+    from boss_runs_amd import synth
+    for i, (a, b) in enumerate(spans):
+        rid = "%s_%d" % (prefix, i)
+        n = b - a
+        seqs[rid] = synth.codes_to_str(codes[a:b])
+        lines.append("%s\t%d\t0\t%d\t+\t%s\t%d\t%d\t%d\t%d\t%d\t60\ttp:A:P\tcg:Z:%dM\tAS:i:%d" %
+                     (rid, n, n, name, L, a, b, n, n, n, n))
+    return "\n".join(lines), seqs
+
+
+@pytest.mark.parametrize("nb", [1, 2])
+def test_counters_beyond_8192_vs_oracle(in_tmp, nb):
+    """reference.py:145: the counters are uint16 and nothing stops at any depth below 65,536.  Sites
+    whose counters pass 8,192 (the limit of the sweep's packed half-word arithmetic), whose FIVE
+    counters together pass 65,535, and a counter close to the uint16 limit — imported as a resumed
+    run's state (bossx_import) and then driven further by ingested reads — must not raise, must leave
+    their neighbours' scores alone, and coverage / scores / entropy / masks must equal the oracle's."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.runs import BossRuns
+    from oracle.pipeline import OracleRuns
+    contigs = synth.make_reference([150_000, 120_000], seed=31, names=["pileA", "pileB"])
+    strs = [(n, synth.codes_to_str(c)) for n, c in contigs]
+    args = BossConfig()
+    args.general.name = "pile%d" % nb
+    args.optional.ploidy = 2
+    args.optional.bucket_threshold = 1
+    if nb > 1:
+        args.general.barcodes = ["barcode%02d" % (i + 1) for i in range(nb)]
+    runs = BossRuns(args)
+    runs.init(contigs=strs)
+    runs.log_fractions = False
+    o = OracleRuns(strs, ploidy=2, nbarcodes=nb, bucket_threshold=1)
+    rng = np.random.default_rng(5)
+    A, B, C = 50_000, 50_003, 50_010            # inside one tile, A and B in one 8-site group of a thread
+    for name, codes in contigs:
+        L = codes.shape[0]
+        cov = np.zeros((L, 5, nb), dtype=np.uint16)
+        for b in range(nb):
+            cov[np.arange(L), codes, b] = rng.poisson(6.0, L).astype(np.uint16)
+            cov[:, 4, b] = rng.poisson(0.2, L).astype(np.uint16)
+        if name == "pileA":
+            cov[A, codes[A], 0] = 8_185                      # passes 8,192 with the reads below
+            cov[B, :, nb - 1] = 13_105                       # five counters: 65,525, passes 65,535
+            cov[C, codes[C], 0] = 65_500                     # close to the uint16 limit (no wrap: 65,500 + 40)
+            cov[C + 7, 4, 0] = 30_000                        # a deep DELETION counter, another thread's group
+        o.contigs[name].coverage[:] = cov
+        o.contigs[name].change_mask[:] = True
+        pc = runs.contigs[name]
+        runs.engine.import_state(pc.index, "coverage", cov)
+        runs.engine.import_state(pc.index, "touched", np.ones(L, dtype=np.uint8))
+    prime_rl = {"p%d" % i: 2000 + 37 * i for i in range(300)}
+    runs.rl_dist.update(prime_rl)
+    o.rl_dist.update(prime_rl)
+
+    def compare(step):
+        assert runs.threshold == o.threshold and o.threshold is not None, step
+        for n, oc in o.contigs.items():
+            pc = runs.contigs[n]
+            assert np.array_equal(pc.coverage, oc.coverage), (step, n)
+            assert np.array_equal(pc.scores, oc.scores), (step, n)
+            assert np.array_equal(pc.entropy, oc.entropy), (step, n)
+            assert np.array_equal(pc.bucket_switches, oc.bucket_switches), (step, n)
+            assert np.array_equal(pc.scores_ds, oc.scores_ds), (step, n)
+            assert np.array_equal(pc.strat, oc.strat), (step, n)
+            depth = oc.coverage.sum(axis=1, dtype=np.uint64)
+            bs = runs.engine.bucket_sums(pc.index)
+            nfull = oc.length // 20000
+            for k in range(nb):
+                assert np.array_equal(bs[k], depth[: nfull * 20000, k].reshape(-1, 20000).sum(axis=1)), (step, n, k)
+
+    runs.update_wrapper()
+    o.update_wrapper()
+    compare("prime")
+    for b in range(2):
+        batch = synth.make_batch(contigs, 300, seed=3100 + b, mean_len=4000.0, nbarcodes=nb)
+        paf, seqs = _exact_reads(contigs, "pileA", [(49_400 + 7 * i, 50_600 + 3 * i) for i in range(20)], "deep%d" % b)
+        batch["paf"] += "\n" + paf
+        batch["seqs"].update(seqs)
+        batch["read_lengths"].update({k: len(v) for k, v in seqs.items()})
+        batch["barcodes"].update({k: (i % nb) for i, k in enumerate(seqs)})
+        bcs = batch["barcodes"] if nb > 1 else None
+        o.process_batch(batch["paf"], batch["seqs"], read_lengths=batch["read_lengths"], barcodes=bcs)
+        runs.rl_dist.update(batch["read_lengths"])
+        runs.process_batch_paf(batch["paf"], batch["seqs"], barcodes=bcs)      # no IndexError
+        compare(b)
+    oa = o.contigs["pileA"]
+    codesA = contigs[0][1]
+    assert int(oa.coverage[A, codesA[A], 0]) > 8_192
+    assert int(oa.coverage[B, :, nb - 1].sum(dtype=np.uint64)) > 65_535
+    assert int(oa.coverage[C, codesA[C], 0]) > 65_500
