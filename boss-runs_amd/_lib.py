@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbossx.so")
+# BOSSX_LIB: another build of the same library (experiments with compile-time switches: `make variant`)
+LIB_PATH = os.environ.get("BOSSX_LIB") or os.path.join(_HERE, "csrc", "libbossx.so")
 
 HIST_BINS = 1088
 NCOMP = 278256

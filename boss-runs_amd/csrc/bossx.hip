@@ -41,6 +41,7 @@ struct bossx_engine {
     unsigned long long *d_rs_sums = nullptr;
     uint32_t *d_tile_done = nullptr;   // [n_tiles] sweep -> chain hand-off flags (epoch stamped)
     uint32_t *d_tile_order = nullptr;  // [n_tiles] block -> tile for publishing launches: every contig's two ends first
+    uint16_t *d_tile_contig = nullptr; // [n_tiles] tile -> local contig
     uint32_t epoch = 0;
     bool overlap_ok = false;           // decided at finalize (BOSSX_OVERLAP / BOSSX_NO_OVERLAP / size); cleared after a chain time-out
     bool host_armed = false;           // the host has seen ctrl.any_on set
@@ -98,6 +99,9 @@ struct bossx_engine {
         uint8_t *d_blob = nullptr; size_t blob_cap = 0;
         TileSeg *d_segs = nullptr; size_t segs_cap = 0;
         TileRef *d_tilerefs = nullptr; size_t tilerefs_cap = 0;
+        uint8_t *d_codes = nullptr; size_t codes_cap = 0;          // per emitted base (expand_codes_kernel)
+        TilePiece *d_pieces = nullptr; size_t pieces_cap = 0;      // per segment
+        uint32_t n_segs = 0;
         ParsedBatch pb;
         bool valid = false;
         bool emit_tiles_built = false;
@@ -235,12 +239,13 @@ void time_collect(bossx_engine *h) {
 SweepParams sweep_params(bossx_engine *h) {
     SweepParams P;
     P.cov = h->d_cov; P.meta = h->d_meta; P.touched = h->d_touched; P.entropy = h->d_entropy;
-    P.tile_ref = h->d_tile_ref; P.tiles = nullptr; P.n_groups = 0; P.segs = nullptr; P.ops = nullptr; P.blob = nullptr;
+    P.tile_ref = h->d_tile_ref; P.tiles = nullptr; P.n_groups = 0; P.pieces = nullptr; P.codes = nullptr;
+    P.tile_contig = h->d_tile_contig;
     P.err_flag = h->d_err; P.use_touched = h->touched_dirty ? 1 : 0;
     P.probe = getenv("BOSSX_SWEEP_PROBE") ? h->d_stats + kStatWords + 80 : nullptr;
     if (h->pending_slot >= 0) {
         const bossx_engine::Staged &st = h->slots[size_t(h->pending_slot)];
-        P.tiles = st.d_tilerefs; P.n_groups = uint32_t(st.pb.tiles.size()); P.segs = st.d_segs; P.ops = st.d_ops; P.blob = st.d_blob;
+        P.tiles = st.d_tilerefs; P.n_groups = uint32_t(st.pb.tiles.size()); P.pieces = st.d_pieces; P.codes = st.d_codes;
     }
     P.ds = h->d_ds; P.bucket_sums = h->d_bucket_sums; P.tile_cov = h->d_tile_cov; P.n_tiles = h->n_tiles;
     P.lut_score = h->d_lut_score; P.lut_ent = h->d_lut_ent; P.ct = table_of(h);
@@ -359,13 +364,14 @@ void bossx_destroy(bossx_engine *h) {
     if (h->d_rs_sums) hipFree(h->d_rs_sums);
     if (h->d_tile_done) hipFree(h->d_tile_done);
     if (h->d_tile_order) hipFree(h->d_tile_order);
+    if (h->d_tile_contig) hipFree(h->d_tile_contig);
     void *ptrs[] = {h->d_cov, h->d_meta, h->d_touched, h->d_strat, h->d_bucket_on, h->d_entropy, h->d_ds,
                     h->d_benefit, h->d_lut_score, h->d_lut_ent, h->d_fhat, h->d_bucket_sums, h->d_drop_count,
                     h->d_stats, h->d_tile_cov, h->d_tails /* base of the tails + result block */, h->d_tile_off, h->d_site_off, h->d_length, h->d_bin_off, h->d_row_off,
                     h->d_strat_off, h->d_bucket_off, h->d_drop_thr, h->d_local, h->d_limbs,
                     h->d_strat_bits};
     for (void *p : ptrs) if (p) hipFree(p);
-    for (auto &st : h->slots) { if (st.d_ops) hipFree(st.d_ops); if (st.d_tiles) hipFree(st.d_tiles); if (st.d_blob) hipFree(st.d_blob); if (st.d_segs) hipFree(st.d_segs); if (st.d_tilerefs) hipFree(st.d_tilerefs); }
+    for (auto &st : h->slots) { if (st.d_ops) hipFree(st.d_ops); if (st.d_tiles) hipFree(st.d_tiles); if (st.d_blob) hipFree(st.d_blob); if (st.d_segs) hipFree(st.d_segs); if (st.d_tilerefs) hipFree(st.d_tilerefs); if (st.d_codes) hipFree(st.d_codes); if (st.d_pieces) hipFree(st.d_pieces); }
     if (h->d_tile_ref) hipFree(h->d_tile_ref);
     if (h->h_pin) hipHostFree(h->h_pin);
     if (h->h_paf_pin) hipHostFree(h->h_paf_pin);
@@ -485,6 +491,17 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
             for (int64_t t = 0; t < c.n_tiles; ++t)
                 key.emplace_back(std::min(t, c.n_tiles - 1 - t), uint32_t(c.tile_off + t));
         }
+        // tile -> contig (one load instead of a binary search over the contig table), and the identity the
+        // sweep's early loads rely on: a tile's first site is tile * kTileSites
+        std::vector<uint16_t> tc(size_t(h->n_tiles > 0 ? h->n_tiles : 1), 0);
+        if (h->filt.size() > 65535) return fail(h, BOSSX_E_INVALID, "more than 65535 contigs");
+        for (size_t k = 0; k < h->filt.size(); ++k) {
+            const ContigInfo &c = h->contigs[size_t(h->filt[k])];
+            if (c.n_tiles && c.site_off != c.tile_off * kTileSites) return fail(h, BOSSX_E_INVALID, "internal: site / tile geometry");
+            for (int64_t t = 0; t < c.n_tiles; ++t) tc[size_t(c.tile_off + t)] = uint16_t(k);
+        }
+        if ((rc = dev_alloc(h, &h->d_tile_contig, tc.size()))) return rc;
+        HIPCHK(hipMemcpy(h->d_tile_contig, tc.data(), tc.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         std::sort(key.begin(), key.end());
         std::vector<uint32_t> order(key.size());
         for (size_t i = 0; i < key.size(); ++i) order[i] = key[i].second;
@@ -845,6 +862,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
         if (!defer_reads || any_dirty.load()) await_reads();
     };
     ParsedBatch pb;
+    uint32_t dev_n_segs = 0;
     const auto t_pre = std::chrono::steady_clock::now();
     if (host_walk) {
         if ((rc = stage_host_walk(h, st, in, summary, pb))) return rc;
@@ -924,6 +942,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
             if (best_gi >= 0) return fail(h, BOSSX_E_RANGE, msg);
         }
         pb.n_ops = totals[0];
+        dev_n_segs = totals[1];
         if (getenv("BOSSX_CHECK_DEVICE_WALK") && (rc = check_device_walk(h, st, in, pb, totals[1]))) return rc;
         if (timing) {
             const auto t2 = std::chrono::steady_clock::now();
@@ -934,6 +953,20 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
         }
         pb.plans.clear(); pb.plans.shrink_to_fit();
         pb.plan_read.clear(); pb.plan_gi.clear();
+    }
+    // ---- per-base codes and per-segment pieces: what the sweep's gather reads (asynchronous; the batch
+    // has passed every check, and the read blob's upload is ordered before this point) --------------
+    st.n_segs = host_walk ? uint32_t(pb.segs.size()) : dev_n_segs;
+    if (pb.n_ops) {
+        if ((rc = grow_dev(h, &st.d_codes, &st.codes_cap, size_t(pb.total_emit) + kCodePad + 32, 4096))) return rc;
+        if ((rc = grow_dev(h, &st.d_pieces, &st.pieces_cap, size_t(st.n_segs), 64))) return rc;
+        ExpandParams X;
+        X.ops = st.d_ops; X.n_ops = uint32_t(pb.n_ops); X.total_emit = uint32_t(pb.total_emit);
+        X.blob = st.d_blob; X.codes = st.d_codes; X.segs = st.d_segs; X.n_segs = st.n_segs; X.pieces = st.d_pieces;
+        X.err_flag = h->d_err;
+        X.op_blocks = (X.n_ops + 255u) / 256u;
+        hipLaunchKernelGGL(expand_codes_kernel, dim3(X.op_blocks + (X.n_segs + 255u) / 256u), dim3(256), 0, h->stream, X);
+        HIPCHK(hipGetLastError());
     }
     if (n_rec) *n_rec = pb.n_rec;
     if (aligned_bases) *aligned_bases = int64_t(pb.total_emit);
@@ -1167,8 +1200,8 @@ int launch_sweep(bossx_engine *h) {
     h->last_thr = thr;
     h->full_sweep_needed = false;
     // algorithmic bytes: per site*barcode 10 B counters + 1 B state read; per 100-site bin 8 B
-    // downsampled score write; per ingested base 1 B read base + 2 B counter write-back, per
-    // emit run 16 B (entropy / state write-backs of changed sites are data dependent and not
+    // downsampled score write; per ingested base 1 B code read + 2 B counter write-back
+    // (entropy / state write-backs of changed sites are data dependent and not
     // counted; the counter READ of an ingested base is already in the 10 B/site)
     double sites = 0;
     for (int32_t fi : h->filt) if (!h->contigs[size_t(fi)].remote) sites += double(h->contigs[size_t(fi)].length);
@@ -1176,7 +1209,7 @@ int launch_sweep(bossx_engine *h) {
     if (!full) { sites = double(n_touched) * kTileSites; bins = double(n_touched) * kTileBins; }   // incremental: the swept tiles only
     double bytes = sites * h->nb * 11.0 + bins * h->nb * 8.0;
     if (h->touched_dirty || split) bytes += sites;
-    if (h->pending_slot >= 0) bytes += 3.0 * h->pending_emit + 16.0 * h->pending_ops;
+    if (h->pending_slot >= 0) bytes += 3.0 * h->pending_emit;      // (the emit runs are read by expand_codes_kernel, not by the sweep)
     time_end(h, BOSSX_K_SWEEP, bytes);
     HIPCHK(hipGetLastError());
     if (P.probe) {

@@ -17,7 +17,7 @@ constexpr int kBucket = BOSSX_BUCKET;      // 20-kb activation bucket
 constexpr int kTileSites = 2000;           // sites per sweep tile: 20 bins, 1/10 bucket
 constexpr int kTileBins = kTileSites / kWindow;
 constexpr int kEmitTile = 2048;            // emitted reference bases per ingest tile (fallback scatter)
-constexpr int kSegMax = 256;               // emitted bases per tile segment (one wave's staging round)
+constexpr int kSegMax = kTileSites;        // emitted bases per tile segment: one piece per (mapping, tile)
 
 // One emitting CIGAR run (M-like or D) of a chosen mapping, 16 bytes, loaded as one uint4.
 //   emit_start : index of its first emitted base in the batch-wide emit order
@@ -58,6 +58,17 @@ struct TileSeg {
     uint32_t e_lo, e_hi;      // emit-index range [e_lo, e_hi)
     uint32_t op_lo, op_hi;    // first and last (inclusive) emit run overlapping the range
 };
+// What the sweep reads of a segment (front_end.hip.inc: expand_codes_kernel): where the piece starts in
+// the per-base code array and which sites of its tile it covers.
+struct TilePiece {
+    uint32_t e_lo;            // emit index of its first base = index into the code array
+    uint32_t loc_len;         // bits 0-15 first site within the tile, bits 16-31 number of sites (<= kTileSites)
+};
+// Base codes of the emitted bases of a batch, one byte each, in emit order: 0..3 = A C G T on the
+// reference strand, 4 = deletion, kCodeSkip = nothing to count.  kCodePad bytes precede entry 0 so
+// that a thread may read the 8 bytes that START up to 7 bytes before a piece.
+constexpr uint32_t kCodeSkip = 7;
+constexpr uint32_t kCodePad = 16;
 // The segments one barcode contributes to one sweep tile.  The groups of a tile are consecutive
 // (ascending barcode); a tile's first group is what tile_ref points at.
 struct TileRef {
