@@ -901,6 +901,8 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
             W.group_count = W.ops_off + n_plans + 1; W.group_cursor = W.group_count + n_groups;
             W.totals = W.group_cursor + n_groups;
             W.ops = st.d_ops; W.groups = st.d_tilerefs; W.n_groups = n_groups; W.segs = st.d_segs;
+            if ((rc = grow_dev(h, &st.d_tiles, &st.tiles_cap, size_t(pb.total_emit / kEmitTile) + 2, 64))) return rc;
+            W.emit_tile_op = st.d_tiles;
             const dim3 grid((n_plans + 3) / 4), block(256);
             hipLaunchKernelGGL(cigar_walk_kernel<false>, grid, block, 0, h->stream, W);
             hipLaunchKernelGGL(walk_scan_kernel, dim3(1), dim3(1024), 0, h->stream, W);
@@ -958,14 +960,19 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
     // has passed every check, and the read blob's upload is ordered before this point) --------------
     st.n_segs = host_walk ? uint32_t(pb.segs.size()) : dev_n_segs;
     if (pb.n_ops) {
-        if ((rc = grow_dev(h, &st.d_codes, &st.codes_cap, size_t(pb.total_emit) + kCodePad + 32, 4096))) return rc;
+        if ((rc = grow_dev(h, &st.d_codes, &st.codes_cap, size_t(pb.total_emit) + kCodePad + size_t(kExpandTile) + 32, 4096))) return rc;
         if ((rc = grow_dev(h, &st.d_pieces, &st.pieces_cap, size_t(st.n_segs), 64))) return rc;
         ExpandParams X;
         X.ops = st.d_ops; X.n_ops = uint32_t(pb.n_ops); X.total_emit = uint32_t(pb.total_emit);
         X.blob = st.d_blob; X.codes = st.d_codes; X.segs = st.d_segs; X.n_segs = st.n_segs; X.pieces = st.d_pieces;
         X.err_flag = h->d_err;
-        X.op_blocks = (X.n_ops + 255u) / 256u;
-        hipLaunchKernelGGL(expand_codes_kernel, dim3(X.op_blocks + (X.n_segs + 255u) / 256u), dim3(256), 0, h->stream, X);
+        X.code_blocks = (X.total_emit + uint32_t(kExpandTile) - 1u) / uint32_t(kExpandTile);
+        if (host_walk) {        // (the device walk's second pass wrote the tile -> run table itself)
+            if ((rc = grow_dev(h, &st.d_tiles, &st.tiles_cap, size_t(X.code_blocks) + 2, 64))) return rc;
+            hipLaunchKernelGGL(emit_tiles_kernel, dim3(X.code_blocks / 256 + 1), dim3(256), 0, h->stream, st.d_ops, X.n_ops, X.code_blocks, st.d_tiles);
+        }
+        X.tile_op = st.d_tiles;
+        hipLaunchKernelGGL(expand_codes_kernel, dim3(X.code_blocks + (X.n_segs + 255u) / 256u), dim3(256), 0, h->stream, X);
         HIPCHK(hipGetLastError());
     }
     if (n_rec) *n_rec = pb.n_rec;

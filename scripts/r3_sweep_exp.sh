@@ -6,6 +6,7 @@ if [ -z "$SKIP_TESTS" ]; then
 ( timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k "end_to_end or incremental or deep or counters or awkward or random or two_batches or saturated or simulation or emulated" 2>&1 | tail -8 ) > gpurun_out/r3exp/parity.log 2>&1
 tail -4 gpurun_out/r3exp/parity.log
 fi
+export BOSSX_BATCH_CACHE=/tmp/bossx_batches_exp
 for v in "$@"; do
   lib=boss-runs_amd/csrc/libbossx${v:+_$v}.so
   [ -f "$lib" ] || { echo "no $lib"; continue; }
