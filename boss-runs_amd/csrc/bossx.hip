@@ -123,6 +123,7 @@ struct bossx_engine {
     uint8_t *h_plan_pin = nullptr; size_t plan_pin_cap = 0;   // MapPlan[] + TileRef[] + read-back block
     MapPlan *d_plans = nullptr; size_t d_plans_cap = 0;
     uint32_t *d_walk = nullptr; size_t d_walk_cap = 0;        // n_runs | walk_err | ops_off | group_count | group_cursor | totals
+    uint32_t *d_lane_scan = nullptr; size_t d_lane_scan_cap = 0;   // per mapping and lane: exclusive prefixes of the walk (pass 1 -> pass 2)
     std::vector<uint8_t> read_dirty;                          // per read: holds a byte other than A/C/G/T
     bool blob_is_pinned = false;                              // the blob handed to stage_core lies in h_blob_pin
     // pinned scratch
@@ -379,6 +380,7 @@ void bossx_destroy(bossx_engine *h) {
     if (h->d_paf) hipFree(h->d_paf);
     if (h->d_plans) hipFree(h->d_plans);
     if (h->d_walk) hipFree(h->d_walk);
+    if (h->d_lane_scan) hipFree(h->d_lane_scan);
     if (h->h_blob_pin) hipHostFree(h->h_blob_pin);
     if (h->h_ops_pin) hipHostFree(h->h_ops_pin);
     for (int k = 0; k < BOSSX_K_COUNT; ++k) { if (h->ev0[k]) hipEventDestroy(h->ev0[k]); if (h->ev1[k]) hipEventDestroy(h->ev1[k]); }
@@ -815,7 +817,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
     // of following it.  The text slices come first and travel on a third stream: the device walk
     // waits for THEM only (it reads the bases of a mapping only where the host saw a byte other
     // than A/C/G/T in the read), the sweep that applies the batch for the reads.
-    std::atomic<int> up_fail{0}, any_dirty{0};
+    std::atomic<int> up_fail{0}, any_dirty{0}, txt_done{0};
     const int dev = h->cfg.device;
     in.extra_fn = [&, n_g, n_c, dev](int t) {
         static thread_local int dev_set = -1;
@@ -824,6 +826,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
             const size_t lo = in.paf_len * size_t(t) / size_t(n_c), hi = in.paf_len * size_t(t + 1) / size_t(n_c);
             memcpy(h->h_paf_pin + lo, in.paf + lo, hi - lo);
             if (hi > lo && hipMemcpyAsync(h->d_paf + lo, h->h_paf_pin + lo, hi - lo, hipMemcpyHostToDevice, h->stream_txt) != hipSuccess) up_fail.store(1);
+            txt_done.fetch_add(1, std::memory_order_release);
         } else {                  // reads [b, e) of a byte-balanced slice: gather (if still scattered) and look at the bases
             const int g = t - n_c;
             const size_t lo_b = blob_bytes * size_t(g) / size_t(n_g), hi_b = blob_bytes * size_t(g + 1) / size_t(n_g);
@@ -872,48 +875,81 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
         in.device_walk = true;
         in.read_dirty = h->read_dirty.data();
         in.n_tiles = h->n_tiles;
+        // ---- device walk, launched from INSIDE the parse as soon as the plans exist (early_walk): it needs
+        // the text and the plans, not the reads — the workers are still gathering and uploading those
+        // (the gather into page-locked memory is the long pole of the host side) ----------------------
+        int early_rc = BOSSX_OK;
+        uint32_t n_plans = 0, n_groups = 0;
+        WalkParams W{};
+        uint32_t *back = nullptr;
+        size_t plan_bytes = 0, group_bytes = 0;
+        auto t_launched = std::chrono::steady_clock::now(), t_plans = t_launched;
+        in.early_walk = [&](ParsedBatch &pbe) {
+            t_plans = std::chrono::steady_clock::now();
+            n_plans = uint32_t(pbe.plans.size()); n_groups = uint32_t(pbe.tiles.size());
+            if (!n_plans) return;
+            auto go = [&]() -> int {
+                int rc2;
+                while (txt_done.load(std::memory_order_acquire) < n_c) _mm_pause();     // the text slices have been handed to the DMA engine
+                if (up_fail.load()) return fail(h, BOSSX_E_HIP, "upload of the PAF text failed");
+                HIPCHK(hipEventRecord(h->ev_txt, h->stream_txt));
+                HIPCHK(hipStreamWaitEvent(h->stream, h->ev_txt, 0));
+                if ((rc2 = grow_dev(h, &st.d_ops, &st.ops_cap, pbe.ops_cap, 1024))) return rc2;
+                if ((rc2 = grow_dev(h, &st.d_segs, &st.segs_cap, pbe.segs_cap, 64))) return rc2;
+                if ((rc2 = grow_dev(h, &st.d_tilerefs, &st.tilerefs_cap, size_t(n_groups), 64))) return rc2;
+                if ((rc2 = grow_dev(h, &h->d_plans, &h->d_plans_cap, size_t(n_plans), 64))) return rc2;
+                if ((rc2 = grow_dev(h, &h->d_lane_scan, &h->d_lane_scan_cap, size_t(n_plans) * 64 * 3, 4096))) return rc2;
+                if ((rc2 = grow_dev(h, &st.d_tiles, &st.tiles_cap, size_t(pbe.total_emit / kEmitTile) + 2, 64))) return rc2;
+                const size_t n_walk = size_t(n_plans) * 3 + 1 + size_t(n_groups) * 2 + 4;
+                if ((rc2 = grow_dev(h, &h->d_walk, &h->d_walk_cap, n_walk, 64))) return rc2;
+                plan_bytes = size_t(n_plans) * sizeof(MapPlan); group_bytes = size_t(n_groups) * sizeof(TileRef);
+                if ((rc2 = grow_pin(h, &h->h_plan_pin, &h->plan_pin_cap, plan_bytes + group_bytes + size_t(n_plans) * 4 + 64))) return rc2;
+                memcpy(h->h_plan_pin, pbe.plans.data(), plan_bytes);
+                memcpy(h->h_plan_pin + plan_bytes, pbe.tiles.data(), group_bytes);
+                HIPCHK(hipMemcpyAsync(h->d_plans, h->h_plan_pin, plan_bytes, hipMemcpyHostToDevice, h->stream));
+                HIPCHK(hipMemcpyAsync(st.d_tilerefs, h->h_plan_pin + plan_bytes, group_bytes, hipMemcpyHostToDevice, h->stream));
+                HIPCHK(hipMemsetAsync(h->d_walk, 0, n_walk * sizeof(uint32_t), h->stream));
+                W.plans = h->d_plans; W.n_plans = n_plans; W.paf = h->d_paf; W.blob = st.d_blob;
+                W.n_runs = h->d_walk; W.walk_err = W.n_runs + n_plans; W.ops_off = W.walk_err + n_plans;
+                W.group_count = W.ops_off + n_plans + 1; W.group_cursor = W.group_count + n_groups;
+                W.totals = W.group_cursor + n_groups;
+                W.ops = st.d_ops; W.groups = st.d_tilerefs; W.n_groups = n_groups; W.segs = st.d_segs;
+                W.emit_tile_op = st.d_tiles; W.lane_scan = h->d_lane_scan; W.nb = h->nb;
+                const dim3 grid((n_plans + 3) / 4), block(256);
+                hipLaunchKernelGGL(cigar_walk_kernel<false>, grid, block, 0, h->stream, W);
+                hipLaunchKernelGGL(walk_scan_kernel, dim3(1), dim3(1024), 0, h->stream, W);
+                hipLaunchKernelGGL(cigar_walk_kernel<true>, grid, block, 0, h->stream, W);
+                HIPCHK(hipGetLastError());
+                back = reinterpret_cast<uint32_t *>(h->h_plan_pin + plan_bytes + group_bytes);
+                HIPCHK(hipMemcpyAsync(back, W.totals, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+                return BOSSX_OK;
+            };
+            early_rc = go();
+            t_launched = std::chrono::steady_clock::now();
+        };
         std::string err;
         rc = parse_paf_batch(in, h->contigs, h->index, summary, pb, err);
         if (rc) return fail(h, rc, err);                  // (upload_guard drains the copies)
+        if (early_rc) return early_rc;
         HIPCHK(up_err);
         const auto t1 = std::chrono::steady_clock::now();
-        auto t_launched = t1;
-        const uint32_t n_plans = uint32_t(pb.plans.size()), n_groups = uint32_t(pb.tiles.size());
         uint32_t totals[4] = {0, 0, 0, 0};
         std::vector<uint32_t> walk_err;
         if (n_plans) {
-            if ((rc = grow_dev(h, &st.d_ops, &st.ops_cap, pb.ops_cap, 1024))) return rc;
-            if ((rc = grow_dev(h, &st.d_segs, &st.segs_cap, pb.segs_cap, 64))) return rc;
-            if ((rc = grow_dev(h, &st.d_tilerefs, &st.tilerefs_cap, size_t(n_groups), 64))) return rc;
-            if ((rc = grow_dev(h, &h->d_plans, &h->d_plans_cap, size_t(n_plans), 64))) return rc;
-            const size_t n_walk = size_t(n_plans) * 3 + 1 + size_t(n_groups) * 2 + 4;
-            if ((rc = grow_dev(h, &h->d_walk, &h->d_walk_cap, n_walk, 64))) return rc;
-            const size_t plan_bytes = size_t(n_plans) * sizeof(MapPlan), group_bytes = size_t(n_groups) * sizeof(TileRef);
-            if ((rc = grow_pin(h, &h->h_plan_pin, &h->plan_pin_cap, plan_bytes + group_bytes + size_t(n_plans) * 4 + 64))) return rc;
-            memcpy(h->h_plan_pin, pb.plans.data(), plan_bytes);
-            memcpy(h->h_plan_pin + plan_bytes, pb.tiles.data(), group_bytes);
-            HIPCHK(hipMemcpyAsync(h->d_plans, h->h_plan_pin, plan_bytes, hipMemcpyHostToDevice, h->stream));
-            HIPCHK(hipMemcpyAsync(st.d_tilerefs, h->h_plan_pin + plan_bytes, group_bytes, hipMemcpyHostToDevice, h->stream));
-            HIPCHK(hipMemsetAsync(h->d_walk, 0, n_walk * sizeof(uint32_t), h->stream));
-            WalkParams W;
-            W.plans = h->d_plans; W.n_plans = n_plans; W.paf = h->d_paf; W.blob = st.d_blob;
-            W.n_runs = h->d_walk; W.walk_err = W.n_runs + n_plans; W.ops_off = W.walk_err + n_plans;
-            W.group_count = W.ops_off + n_plans + 1; W.group_cursor = W.group_count + n_groups;
-            W.totals = W.group_cursor + n_groups;
-            W.ops = st.d_ops; W.groups = st.d_tilerefs; W.n_groups = n_groups; W.segs = st.d_segs;
-            if ((rc = grow_dev(h, &st.d_tiles, &st.tiles_cap, size_t(pb.total_emit / kEmitTile) + 2, 64))) return rc;
-            W.emit_tile_op = st.d_tiles;
-            const dim3 grid((n_plans + 3) / 4), block(256);
-            hipLaunchKernelGGL(cigar_walk_kernel<false>, grid, block, 0, h->stream, W);
-            hipLaunchKernelGGL(walk_scan_kernel, dim3(1), dim3(1024), 0, h->stream, W);
-            hipLaunchKernelGGL(cigar_walk_kernel<true>, grid, block, 0, h->stream, W);
-            HIPCHK(hipGetLastError());
-            t_launched = std::chrono::steady_clock::now();
-            uint32_t *back = reinterpret_cast<uint32_t *>(h->h_plan_pin + plan_bytes + group_bytes);
-            HIPCHK(hipMemcpyAsync(back, W.totals, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+            if (pb.any_check_bases) {
+                // some read holds a byte other than A/C/G/T: look at the bases of its aligned runs, now that the
+                // reads are on their way (the plans go up again, with their flags)
+                await_reads(); HIPCHK(up_err);
+                HIPCHK(hipStreamSynchronize(h->stream));              // the first copy of the plans has left the staging buffer
+                memcpy(h->h_plan_pin, pb.plans.data(), plan_bytes);
+                HIPCHK(hipMemcpyAsync(h->d_plans, h->h_plan_pin, plan_bytes, hipMemcpyHostToDevice, h->stream));
+                hipLaunchKernelGGL(check_bases_kernel, dim3((n_plans + 3) / 4), dim3(256), 0, h->stream, W);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipMemcpyAsync(back, W.totals, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+            }
             HIPCHK(hipStreamSynchronize(h->stream));
             memcpy(totals, back, sizeof(totals));
-            await_reads(); HIPCHK(up_err);                 // (ordered before the sweep that applies the batch)
+            await_reads(); HIPCHK(up_err);                 // (ordered before the kernels that read the bases)
             if (totals[2]) {
                 walk_err.resize(n_plans);
                 HIPCHK(hipMemcpy(walk_err.data(), W.walk_err, size_t(n_plans) * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -948,10 +984,10 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
         if (getenv("BOSSX_CHECK_DEVICE_WALK") && (rc = check_device_walk(h, st, in, pb, totals[1]))) return rc;
         if (timing) {
             const auto t2 = std::chrono::steady_clock::now();
-            fprintf(stderr, "[bossx] stage_batch: before the parse %.2f, host parse %.2f ms, plan upload + launches %.2f, waiting for uploads + device walk %.2f ms (%u mappings, %u runs, %u segments, %u groups)\n",
-                    std::chrono::duration<double, std::milli>(t_pre - t0).count(), std::chrono::duration<double, std::milli>(t1 - t_pre).count(),
-                    std::chrono::duration<double, std::milli>(t_launched - t1).count(), std::chrono::duration<double, std::milli>(t2 - t_launched).count(),
-                    n_plans, totals[0], totals[1], n_groups);
+            fprintf(stderr, "[bossx] stage_batch: before the parse %.2f, lines -> plans %.2f ms, text wait + plan upload + walk launches %.2f, rest of the host parse (collecting the gather) %.2f, waiting for the device walk %.2f ms (%u mappings, %u runs, %u segments, %u groups)\n",
+                    std::chrono::duration<double, std::milli>(t_pre - t0).count(), std::chrono::duration<double, std::milli>(t_plans - t_pre).count(),
+                    std::chrono::duration<double, std::milli>(t_launched - t_plans).count(), std::chrono::duration<double, std::milli>(t1 - t_launched).count(),
+                    std::chrono::duration<double, std::milli>(t2 - t1).count(), n_plans, totals[0], totals[1], n_groups);
         }
         pb.plans.clear(); pb.plans.shrink_to_fit();
         pb.plan_read.clear(); pb.plan_gi.clear();

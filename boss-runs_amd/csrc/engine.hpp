@@ -93,7 +93,7 @@ struct alignas(16) MapPlan {
     uint32_t flags;            // bits 0-7 barcode, bit 8 reverse strand, bit 9 read holds a byte other than ACGT
     uint32_t seg_cap;          // upper bound of its tile segments
     int32_t q_rel;             // index of q0 inside the read (for the bounds checks; may be out of range)
-    uint32_t pad;
+    uint32_t g_first;          // index of the (tile, barcode) group of the mapping's first tile
 };
 static_assert(sizeof(MapPlan) == 64, "MapPlan is uploaded as is");
 constexpr uint32_t kPlanRev = 1u << 8;
@@ -137,6 +137,7 @@ struct ParsedBatch {
     int pre_code = 0; std::string pre_msg; int64_t pre_gi = -1;      // first KeyError / ValueError class failure of the pre-pass
     int64_t pre_range_gi = -1; std::string pre_range_msg;            // first IndexError class failure of the pre-pass
     size_t ops_cap = 0, segs_cap = 0;      // capacities the device buffers need
+    bool any_check_bases = false;          // some plan was flagged kPlanCheckBases after early_walk had been called
 };
 
 struct ParseInput {
@@ -161,6 +162,10 @@ struct ParseInput {
     std::function<void(int)> extra_fn;
     int extra_n = 0;
     std::function<void()> after_pass1;
+    // device walk: called with the finished plans / groups BEFORE the caller's extra tasks are collected
+    // (the plans carry no kPlanCheckBases flags yet: ParsedBatch::any_check_bases tells whether a
+    // second look at the bases is needed once the reads have been examined)
+    std::function<void(ParsedBatch &)> early_walk;
 };
 
 // Persistent worker threads for the host front end (creating 40 threads per batch cost more than

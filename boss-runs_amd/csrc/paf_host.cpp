@@ -452,7 +452,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         cuts[size_t(t)] = nl ? nl + 1 : in.paf + in.paf_len;
     }
     std::vector<LineOut> los(static_cast<size_t>(nt));
-    static const bool trace = getenv("BOSSX_STAGE_TIMING") != nullptr;
+    const bool trace = getenv("BOSSX_STAGE_TIMING") != nullptr;
     std::vector<double> tb, te;
     const auto r0 = std::chrono::steady_clock::now();
     const int n_tasks = nt + 1 + in.extra_n;
@@ -671,14 +671,29 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
                 out.tiles.push_back(TileRef{t, 0u, 0u, bc});
             }
         }
-        // the caller's tasks (gather + base check + uploads) have had the grouping and the plans to finish
-        collect_pass1();
-        for (size_t i = 0; i < out.plans.size(); ++i)
-            if (!in.read_dirty || in.read_dirty[out.plan_read[i]]) out.plans[i].flags |= kPlanCheckBases;
+        // index of every mapping's first (tile, barcode) group in that sorted list: rank of its key among the marked ones
+        {
+            static thread_local std::vector<uint32_t> rank;
+            rank.resize(marks.size() + 1);
+            uint32_t acc = 0;
+            for (size_t w = 0; w < marks.size(); ++w) { rank[w] = acc; acc += uint32_t(__builtin_popcountll(marks[w])); }
+            for (MapPlan &mp : out.plans) {
+                const size_t key = size_t(mp.site0 / kTileSites) * size_t(in.nbarcodes) + size_t(mp.flags & 0xffu);
+                mp.g_first = key < n_keys ? rank[key >> 6] + uint32_t(__builtin_popcountll(marks[key >> 6] & ((1ull << (key & 63)) - 1ull))) : 0u;
+            }
+        }
         out.ops_cap = ops_at + 1;
         out.segs_cap = seg_cap + 1;
         out.total_emit = cur_emit;
         out.n_rec = n_rec;
+        // The device walk needs the plans and the text, not the reads: the caller may launch it now, while
+        // the workers still gather and upload the reads (early_walk also waits for the text slices).
+        if (in.early_walk) in.early_walk(out);
+        // the caller's tasks (gather + base check + uploads) have had the grouping and the plans to finish
+        collect_pass1();
+        out.any_check_bases = false;
+        for (size_t i = 0; i < out.plans.size(); ++i)
+            if (!in.read_dirty || in.read_dirty[out.plan_read[i]]) { out.plans[i].flags |= kPlanCheckBases; out.any_check_bases = true; }
         // failures of the pre-pass travel with the batch: the caller merges them with the device
         // walk's per-mapping outcome (first ValueError / KeyError class failure in record order; the
         // IndexError class only if nothing else failed)
@@ -924,6 +939,11 @@ extern "C" int bossx_host_parse(const char *const *contig_names, const int64_t *
         for (size_t i = 0; i < pd.tiles.size(); ++i)
             if (pd.tiles[i].tile != pb.tiles[i].tile || pd.tiles[i].bc != pb.tiles[i].bc)
                 return fail(BOSSX_E_INVALID, "device-walk planning: groups differ");
+        for (const MapPlan &mp : pd.plans) {       // the group index the device walk starts from
+            const uint32_t t0 = uint32_t(mp.site0 / kTileSites), bc = mp.flags & 0xffu;
+            if (mp.span && (mp.g_first >= pd.tiles.size() || pd.tiles[mp.g_first].tile != t0 || pd.tiles[mp.g_first].bc != bc))
+                return fail(BOSSX_E_INVALID, "device-walk planning: first group of a mapping is wrong");
+        }
         uint64_t span_sum = 0;
         for (const MapPlan &mp : pd.plans) {
             if (mp.emit0 != uint32_t(span_sum)) return fail(BOSSX_E_INVALID, "device-walk planning: emit order broken");
