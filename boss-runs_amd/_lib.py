@@ -55,6 +55,8 @@ class UpdateResult(C.Structure):
 
 # private binding helper (csrc/bossx_py.h): not part of the C-ABI
 PRIVATE_PROTOTYPES = {
+    "bossx_py_dict_pointers": (C.c_int64, [C.py_object, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]),
     "bossx_py_str_pointers": (C.c_int, [C.py_object, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
@@ -175,9 +177,10 @@ def load_gil():
     if _pylib is None:
         load()
         _pylib = C.PyDLL(LIB_PATH)
-        res, args = PRIVATE_PROTOTYPES["bossx_py_str_pointers"]
-        _pylib.bossx_py_str_pointers.restype = res
-        _pylib.bossx_py_str_pointers.argtypes = args
+        for name, (res, args) in PRIVATE_PROTOTYPES.items():
+            fn = getattr(_pylib, name)
+            fn.restype = res
+            fn.argtypes = args
     return _pylib
 
 

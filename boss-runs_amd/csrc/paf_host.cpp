@@ -425,6 +425,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
     // read id -> index in the batch (built by one task of pass 1's parallel region)
     std::unordered_map<std::string_view, int32_t> read_index;
     bool dup_names = false;
+    std::atomic<bool> index_ready{false};
     auto read_name = [&](int32_t i) { return std::string_view(in.names + in.name_off[i], size_t(in.name_off[i + 1] - in.name_off[i])); };
     auto build_read_index = [&]() {
         read_index.reserve(size_t(in.n_reads) * 2 + 1);
@@ -432,7 +433,11 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             auto ins = read_index.insert_or_assign(read_name(i), i);   // later duplicates win, like a dict
             if (!ins.second) dup_names = true;
         }
+        index_ready.store(true, std::memory_order_release);
     };
+    // (the index is built by a worker NEXT TO the grouping below, which needs it only for a record
+    // whose read is neither the previous record's nor the next one of the batch)
+    auto wait_index = [&]() { while (!index_ready.load(std::memory_order_acquire)) __builtin_ia32_pause(); };
 
     // ---- pass 1 (threads over line ranges): lines -> filtered records, in line order; then the
     // best record per query name, groups in first-appearance order --------------------------
@@ -441,7 +446,9 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
     // caller brought along (gathering the reads, copying the text, their uploads), which the workers
     // finish meanwhile and which is collected before the device walk is launched.
     std::vector<Group> groups;
-    int nt = in.n_threads > 0 ? in.n_threads : parse_threads();
+    // Many small line ranges, pulled dynamically: a worker that wakes up late finds nothing left instead of
+    // holding a sixteenth of the text back (one straggler used to set the pace: 0.28 ms against a mean of 0.06).
+    int nt = in.n_threads > 0 ? in.n_threads : int(std::min<size_t>(128, std::max<size_t>(1, in.paf_len / (size_t(48) << 10))));
     if (in.paf_len < (size_t(1) << 16)) nt = 1;
     std::vector<const char *> cuts(size_t(nt) + 1, in.paf + in.paf_len);
     cuts[0] = in.paf;
@@ -479,7 +486,8 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         }
         if (in.after_pass1) in.after_pass1();
     };
-    pass1.job = WorkPool::get().start(n_tasks, nt + 1, pass1_fn);
+    pass1.job = WorkPool::get().start(n_tasks, nt, pass1_fn);       // (the caller goes on once the LINES are done)
+    if (!pass1.job) index_ready.store(true);                         // everything ran inline
     if (trace) fprintf(stderr, "  [pass1] lines + name index done after %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count());
     if (!in.device_walk || in.summary_only) collect_pass1();     // nothing to overlap with on these paths
     {
@@ -489,52 +497,65 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             line_base += lo.n_lines;
         }
         // best record per query name, groups in first-appearance order.  Names are resolved to batch
-        // indices here (one hash lookup per record); only names that are NOT in the batch — a KeyError
-        // for the reference — need a map of their own
-        std::vector<int32_t> group_of_read(size_t(in.n_reads), -1);
-        std::unordered_map<std::string_view, int32_t> group_of_unknown;
-        size_t n_recs = 0;
-        for (const LineOut &lo : los) n_recs += lo.recs.size();
-        groups.reserve(n_recs);
+        // indices here; only names that are NOT in the batch — a KeyError for the reference — need a
+        // map of their own.
         // A mapper reports its hits read by read, in the order the reads were handed over: the read
         // of a record is the previous record's or the next one in the batch far more often than not,
-        // and comparing two names is much cheaper than hashing one.  (Not with duplicate names in
-        // the batch: a dict keeps the last one.)
-        int32_t cursor = -1;
-        for (LineOut &lo : los) {
-            for (Rec &r : lo.recs) {
-                int32_t read = -1;
-                const std::string_view qn(r.qname);
-                if (!dup_names && cursor >= 0 && read_name(cursor) == qn) read = cursor;
-                else if (!dup_names && cursor + 1 < in.n_reads && read_name(cursor + 1) == qn) read = cursor + 1;
-                else {
-                    const auto ri = read_index.find(qn);
-                    if (ri != read_index.end()) read = ri->second;
-                }
-                if (read >= 0) cursor = read;
-                int32_t *slot = nullptr;
-                int32_t unknown_slot = -1;
-                if (read >= 0) slot = &group_of_read[size_t(read)];
-                else {
-                    auto it = group_of_unknown.find(qn);
-                    if (it != group_of_unknown.end()) unknown_slot = it->second;
-                    slot = &unknown_slot;
-                }
-                if (*slot < 0) {
-                    groups.push_back(Group{std::move(r), r.mapq, r.as, read});
-                    if (read >= 0) *slot = int32_t(groups.size() - 1);
-                    else group_of_unknown.emplace(std::string_view(groups.back().best.qname), int32_t(groups.size() - 1));
-                } else {
-                    Group &g = groups[size_t(*slot)];
-                    // argsort by (mapq, AS), last element wins; stable for ties (paf.py:716-721)
-                    if (r.mapq > g.key_q || (r.mapq == g.key_q && r.as >= g.key_dp)) {
-                        g.key_q = r.mapq; g.key_dp = r.as;
-                        std::string keep = std::move(g.best.qname);     // the map's key views this buffer
-                        g.best = std::move(r);
-                        g.best.qname = std::move(keep);
+        // and comparing two names is much cheaper than hashing one — so the grouping starts right
+        // away, OPTIMISTICALLY, while a worker still builds the name index: it waits for the index only
+        // at the first record that is out of order.  Duplicate names in the batch (a dict keeps the last
+        // one; impossible from a Python dict, possible through the C-ABI) show when the index is done:
+        // the grouping is then repeated on freshly parsed lines with index lookups only.
+        auto do_grouping = [&](bool use_cursor) {
+            std::vector<int32_t> group_of_read(size_t(in.n_reads), -1);
+            std::unordered_map<std::string_view, int32_t> group_of_unknown;
+            size_t n_recs = 0;
+            for (const LineOut &lo : los) n_recs += lo.recs.size();
+            groups.clear();
+            groups.reserve(n_recs);
+            int32_t cursor = -1;
+            for (LineOut &lo : los) {
+                for (Rec &r : lo.recs) {
+                    int32_t read = -1;
+                    const std::string_view qn(r.qname);
+                    if (use_cursor && cursor >= 0 && read_name(cursor) == qn) read = cursor;
+                    else if (use_cursor && cursor + 1 < in.n_reads && read_name(cursor + 1) == qn) read = cursor + 1;
+                    else {
+                        wait_index();
+                        const auto ri = read_index.find(qn);
+                        if (ri != read_index.end()) read = ri->second;
+                    }
+                    if (read >= 0) cursor = read;
+                    int32_t *slot = nullptr;
+                    int32_t unknown_slot = -1;
+                    if (read >= 0) slot = &group_of_read[size_t(read)];
+                    else {
+                        auto it = group_of_unknown.find(qn);
+                        if (it != group_of_unknown.end()) unknown_slot = it->second;
+                        slot = &unknown_slot;
+                    }
+                    if (*slot < 0) {
+                        groups.push_back(Group{std::move(r), r.mapq, r.as, read});
+                        if (read >= 0) *slot = int32_t(groups.size() - 1);
+                        else group_of_unknown.emplace(std::string_view(groups.back().best.qname), int32_t(groups.size() - 1));
+                    } else {
+                        Group &g = groups[size_t(*slot)];
+                        // argsort by (mapq, AS), last element wins; stable for ties (paf.py:716-721)
+                        if (r.mapq > g.key_q || (r.mapq == g.key_q && r.as >= g.key_dp)) {
+                            g.key_q = r.mapq; g.key_dp = r.as;
+                            std::string keep = std::move(g.best.qname);     // the map's key views this buffer
+                            g.best = std::move(r);
+                            g.best.qname = std::move(keep);
+                        }
                     }
                 }
             }
+        };
+        do_grouping(true);
+        wait_index();
+        if (dup_names) {
+            for (int t = 0; t < nt; ++t) { los[size_t(t)] = LineOut(); parse_lines(cuts[size_t(t)], cuts[size_t(t) + 1], in.min_len, los[size_t(t)]); }
+            do_grouping(false);
         }
     }
 
@@ -1041,3 +1062,25 @@ extern "C" int bossx_py_str_pointers(void *list, int64_t n, void *list_get_item,
     }
     return BOSSX_OK;
 }
+
+extern "C" int64_t bossx_py_dict_pointers(void *dict, int64_t cap, void *dict_next, void *as_utf8_and_size,
+                                          const char **key_ptrs, int64_t *key_lens, const char **val_ptrs, int64_t *val_lens) {
+    using next_t = int (*)(void *, long *, void **, void **);      // PyDict_Next(dict, &pos, &key, &value): borrowed references
+    using utf_t = const char *(*)(void *, long *);
+    next_t next = reinterpret_cast<next_t>(dict_next);
+    utf_t utf = reinterpret_cast<utf_t>(as_utf8_and_size);
+    if (!next || !utf || !dict || cap < 0 || (cap > 0 && (!key_ptrs || !key_lens || !val_ptrs || !val_lens))) return BOSSX_E_INVALID;
+    long pos = 0;
+    void *k = nullptr, *v = nullptr;
+    int64_t n = 0;
+    while (next(dict, &pos, &k, &v)) {
+        if (n >= cap) return BOSSX_E_INVALID;
+        long kl = 0, vl = 0;
+        const char *kp = utf(k, &kl), *vp = utf(v, &vl);
+        if (!kp || !vp) return BOSSX_E_INVALID;                      // not a str (the interpreter has set its error indicator)
+        key_ptrs[n] = kp; key_lens[n] = kl; val_ptrs[n] = vp; val_lens[n] = vl;
+        ++n;
+    }
+    return n;
+}
+

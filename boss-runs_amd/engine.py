@@ -24,6 +24,28 @@ class _PinnedBlock:
             pass
 
 
+class _LazyIds:
+    """The read names of a staged batch in batch order, listed only if somebody asks (the simulation
+    path does; the per-update path does not)."""
+
+    def __init__(self, seqs):
+        self._seqs, self._ids = seqs, None
+
+    def _list(self):
+        if self._ids is None:
+            self._ids = list(self._seqs.keys())
+        return self._ids
+
+    def __getitem__(self, i):
+        return self._list()[i]
+
+    def __len__(self):
+        return len(self._seqs)
+
+    def __iter__(self):
+        return iter(self._list())
+
+
 class Engine:
     def __init__(self, nbarcodes=1, device=0, track_entropy=True, stream=None):
         self.lib = _lib.load()
@@ -163,12 +185,48 @@ class Engine:
         out["ids"] = ids
         return out
 
+    _dict_next = None
+
+    def _dict_pointers(self, seqs):
+        """Pointers / lengths of the names and sequences of a {read id: sequence} dict, one pass in C
+        (PyDict_Next; the dict keeps every buffer alive for the call).  The arrays are the engine's
+        own and are reused by the next call."""
+        if Engine._dict_next is None:
+            Engine._dict_next = (C.cast(C.pythonapi.PyDict_Next, C.c_void_p).value,
+                                 C.cast(C.pythonapi.PyUnicode_AsUTF8AndSize, C.c_void_p).value)
+        n = len(seqs)
+        buf = self.__dict__.get("_ptr_buf")
+        if buf is None or buf[0].size < n:
+            cap = max(n, 1) * 5 // 4 + 16
+            buf = self._ptr_buf = (np.empty(cap, np.uint64), np.empty(cap, np.int64), np.empty(cap, np.uint64), np.empty(cap, np.int64))
+        got = _lib.load_gil().bossx_py_dict_pointers(seqs, n, Engine._dict_next[0], Engine._dict_next[1],
+                                                     buf[0].ctypes.data, buf[1].ctypes.data, buf[2].ctypes.data, buf[3].ctypes.data)
+        if got != n:
+            raise TypeError("read names and sequences must be str")
+        return buf
+
+    def _summary_buffers(self, n):
+        """Per-mapping summary arrays of a staging call (reused between calls: the caller gets views)."""
+        s = self.__dict__.get("_summ_buf")
+        if s is None or s["read_idx"].size < max(n, 1):
+            cap = max(n, 1) * 5 // 4 + 16
+            s = self._summ_buf = dict(read_idx=np.zeros(cap, np.int32), contig_idx=np.zeros(cap, np.int32),
+                                      rev=np.zeros(cap, np.uint8), tstart=np.zeros(cap, np.int64),
+                                      tend=np.zeros(cap, np.int64), qlen=np.zeros(cap, np.int64))
+            self._summ_struct = _lib.BatchSummary(*[s[k].ctypes.data for k in ("read_idx", "contig_idx", "rev", "tstart", "tend", "qlen")])
+        return s, self._summ_struct
+
     def _stage_batch_ptrs(self, paf_text, seqs, barcodes, min_len):
-        ids = list(seqs.keys())
-        vals = list(seqs.values())
-        n = len(ids)
-        nptr, nlen = self._str_pointers(ids)
-        sptr, slen = self._str_pointers(vals)
+        if type(seqs) is dict:
+            n = len(seqs)
+            nptr, nlen, sptr, slen = self._dict_pointers(seqs)
+            ids = None
+        else:
+            ids = list(seqs.keys())
+            vals = list(seqs.values())
+            n = len(ids)
+            nptr, nlen = self._str_pointers(ids)
+            sptr, slen = self._str_pointers(vals)
         if isinstance(paf_text, str):
             # the interpreter's own UTF-8 buffer of the str (for ASCII text: the string itself): no copy
             pp, pl = self._str_pointers([paf_text])
@@ -178,12 +236,11 @@ class Engine:
             paf_len = len(paf)
         bc = None
         if barcodes is not None:
-            bc = np.ascontiguousarray([barcodes[i] for i in ids] if isinstance(barcodes, dict) else barcodes,
-                                      dtype=np.int32)
-        s = dict(read_idx=np.zeros(max(n, 1), np.int32), contig_idx=np.zeros(max(n, 1), np.int32),
-                 rev=np.zeros(max(n, 1), np.uint8), tstart=np.zeros(max(n, 1), np.int64),
-                 tend=np.zeros(max(n, 1), np.int64), qlen=np.zeros(max(n, 1), np.int64))
-        summ = _lib.BatchSummary(*[s[k].ctypes.data for k in ("read_idx", "contig_idx", "rev", "tstart", "tend", "qlen")])
+            if isinstance(barcodes, dict):
+                bc = np.fromiter((barcodes[i] for i in (seqs.keys() if ids is None else ids)), dtype=np.int32, count=n)
+            else:
+                bc = np.ascontiguousarray(barcodes, dtype=np.int32)
+        s, summ = self._summary_buffers(n)
         n_rec = C.c_int32(0)
         aligned = C.c_int64(0)
         self._ck(self.lib.bossx_stage_batch_ptrs(self.h, paf, paf_len, nptr.ctypes.data, nlen.ctypes.data,
@@ -191,9 +248,9 @@ class Engine:
                                                  None if bc is None else bc.ctypes.data, n, int(min_len),
                                                  C.byref(summ), C.byref(n_rec), C.byref(aligned)))
         k = n_rec.value
-        out = {key: v[:k] for key, v in s.items()}
+        out = {key: v[:k].copy() for key, v in s.items()}      # (the engine's buffers are reused by the next staging call)
         out["aligned"] = aligned.value
-        out["ids"] = ids
+        out["ids"] = _LazyIds(seqs) if ids is None else ids
         return out
 
     def paf_summary(self, paf_text, read_ids, min_len=1):
