@@ -31,6 +31,10 @@ struct bossx_engine {
     hipStream_t stream2 = nullptr;
     hipStream_t stream_up = nullptr;   // slice-wise uploads of a batch being staged (issued by the worker threads)
     hipEvent_t ev_up = nullptr;
+    // ... three more queues for them: sixteen workers handing their slices to ONE stream queued up behind its lock
+    static constexpr int kUpStreams = 4;
+    hipStream_t stream_ups[kUpStreams] = {nullptr, nullptr, nullptr, nullptr};   // [0] = stream_up
+    hipEvent_t ev_ups[kUpStreams] = {nullptr, nullptr, nullptr, nullptr};         // [0] = ev_up
     hipStream_t stream_txt = nullptr;  // the PAF text goes up on its own: the device walk needs nothing else
     hipEvent_t ev_txt = nullptr;
     hipEvent_t ev_begin = nullptr, ev_chain = nullptr, ev_sweep = nullptr, ev_fhat = nullptr;
@@ -340,6 +344,10 @@ int bossx_create(const bossx_config *cfg, bossx_engine **out) {
         hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&h->stream_txt, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_txt, hipEventDisableTiming) != hipSuccess) return BOSSX_E_HIP;
+    h->stream_ups[0] = h->stream_up; h->ev_ups[0] = h->ev_up;
+    for (int i = 1; i < bossx_engine::kUpStreams; ++i)
+        if (hipStreamCreateWithFlags(&h->stream_ups[i], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_ups[i], hipEventDisableTiming) != hipSuccess) return BOSSX_E_HIP;
     *out = e.release();
     return BOSSX_OK;
 }
@@ -351,6 +359,10 @@ void bossx_destroy(bossx_engine *h) {
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
     if (h->stream_up) { hipStreamSynchronize(h->stream_up); hipStreamDestroy(h->stream_up); }
     if (h->ev_up) hipEventDestroy(h->ev_up);
+    for (int i = 1; i < bossx_engine::kUpStreams; ++i) {
+        if (h->stream_ups[i]) { hipStreamSynchronize(h->stream_ups[i]); hipStreamDestroy(h->stream_ups[i]); }
+        if (h->ev_ups[i]) hipEventDestroy(h->ev_ups[i]);
+    }
     if (h->stream_txt) { hipStreamSynchronize(h->stream_txt); hipStreamDestroy(h->stream_txt); }
     if (h->ev_txt) hipEventDestroy(h->ev_txt);
     if (h->ev_begin) hipEventDestroy(h->ev_begin);
@@ -795,7 +807,9 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
         bossx_engine *h; bool ok = false;
         ~UploadGuard() {
             if (ok) return;
-            hipStreamSynchronize(h->stream_txt); hipStreamSynchronize(h->stream_up); hipStreamSynchronize(h->stream);
+            hipStreamSynchronize(h->stream_txt);
+            for (int i = 0; i < bossx_engine::kUpStreams; ++i) hipStreamSynchronize(h->stream_ups[i]);
+            hipStreamSynchronize(h->stream);
         }
     } upload_guard{h};
     // slack: the ingest prologue reads a 384-byte window that may start at the last base
@@ -843,7 +857,8 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
             }
             if (dirty) any_dirty.store(1, std::memory_order_relaxed);
             if (i1 > i0 && seq_off[i1] > seq_off[i0] &&
-                hipMemcpyAsync(st.d_blob + seq_off[i0], seqs + seq_off[i0], size_t(seq_off[i1] - seq_off[i0]), hipMemcpyHostToDevice, h->stream_up) != hipSuccess)
+                hipMemcpyAsync(st.d_blob + seq_off[i0], seqs + seq_off[i0], size_t(seq_off[i1] - seq_off[i0]), hipMemcpyHostToDevice,
+                               h->stream_ups[g % bossx_engine::kUpStreams]) != hipSuccess)
                 up_fail.store(1);
         }
     };
@@ -853,7 +868,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
     bool reads_awaited = false;
     auto await_reads = [&]() {
         if (reads_awaited || up_err != hipSuccess) return;
-        up_err = hipStreamWaitEvent(h->stream, h->ev_up, 0);
+        for (int i = 0; i < bossx_engine::kUpStreams && up_err == hipSuccess; ++i) up_err = hipStreamWaitEvent(h->stream, h->ev_ups[i], 0);
         reads_awaited = true;
     };
     const bool defer_reads = seq_ptrs != nullptr && !host_walk && !getenv("BOSSX_NO_DEFER_READS");
@@ -861,7 +876,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
         if (up_fail.load()) { up_err = hipErrorUnknown; return; }
         up_err = hipEventRecord(h->ev_txt, h->stream_txt);
         if (up_err == hipSuccess) up_err = hipStreamWaitEvent(h->stream, h->ev_txt, 0);
-        if (up_err == hipSuccess) up_err = hipEventRecord(h->ev_up, h->stream_up);
+        for (int i = 0; i < bossx_engine::kUpStreams && up_err == hipSuccess; ++i) up_err = hipEventRecord(h->ev_ups[i], h->stream_ups[i]);
         if (!defer_reads || any_dirty.load()) await_reads();
     };
     ParsedBatch pb;
