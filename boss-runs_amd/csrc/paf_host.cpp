@@ -434,8 +434,12 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             const size_t n = s.size(), k = n < 8 ? n : 8;
             memcpy(&a, s.data(), k);
             memcpy(&b, s.data() + n - k, k);
-            uint64_t h = (a * 0x9E3779B97F4A7C15ull) ^ (b * 0xC2B2AE3D27D4EB4Full) ^ (uint64_t(n) * 0x165667B19E3779F9ull);
-            return h ^ (h >> 29);
+            // (names of one batch share their first and last bytes' low bits — "r1003_17", "r1003_18": every input
+            // bit has to reach the slot bits, so mix, multiply and take the HIGH half)
+            uint64_t h = a ^ (b << 32 | b >> 32) ^ (uint64_t(n) << 56);
+            h *= 0xD6E8FEB86659FD93ull; h ^= h >> 32;
+            h *= 0xD6E8FEB86659FD93ull; h ^= h >> 32;
+            return h;
         }
         std::string_view name(int32_t i) const { return std::string_view(in->names + in->name_off[i], size_t(in->name_off[i + 1] - in->name_off[i])); }
         void reserve(const ParseInput &input) {
