@@ -694,8 +694,7 @@ int grow_pin(bossx_engine *h, T **p, size_t *cap, size_t need) {
 namespace {
 
 const char *walk_message(uint32_t e) {
-    if (e & kWalkBadCigar) return "malformed CIGAR";
-    if (e & kWalkBadOp) return "unknown CIGAR op";
+    if (e & kWalkBadCigar) return "no CIGAR operation, or a run of 10^9 bases or more";
     if (e & kWalkOutsideRead) return "CIGAR walks outside the read";
     if (e & kWalkQueryMismatch) return "CIGAR does not consume qend - qstart query bases";
     if (e & kWalkSpanMismatch) return "CIGAR does not span tend - tstart reference bases";
@@ -832,8 +831,10 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
     // waits for THEM only (it reads the bases of a mapping only where the host saw a byte other
     // than A/C/G/T in the read), the sweep that applies the batch for the reads.
     std::atomic<int> up_fail{0}, any_dirty{0}, txt_done{0};
+    int n_up = bossx_engine::kUpStreams;
+    if (const char *e = getenv("BOSSX_UP_STREAMS")) n_up = std::min(std::max(atoi(e), 1), int(bossx_engine::kUpStreams));
     const int dev = h->cfg.device;
-    in.extra_fn = [&, n_g, n_c, dev](int t) {
+    in.extra_fn = [&, n_g, n_c, dev, n_up](int t) {
         static thread_local int dev_set = -1;
         if (dev_set != dev) { if (hipSetDevice(dev) != hipSuccess) up_fail.store(1); dev_set = dev; }
         if (t < n_c) {
@@ -858,7 +859,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
             if (dirty) any_dirty.store(1, std::memory_order_relaxed);
             if (i1 > i0 && seq_off[i1] > seq_off[i0] &&
                 hipMemcpyAsync(st.d_blob + seq_off[i0], seqs + seq_off[i0], size_t(seq_off[i1] - seq_off[i0]), hipMemcpyHostToDevice,
-                               h->stream_ups[g % bossx_engine::kUpStreams]) != hipSuccess)
+                               h->stream_ups[g % n_up]) != hipSuccess)
                 up_fail.store(1);
         }
     };
@@ -979,9 +980,12 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
             const int32_t r = pb.plan_read[i];
             return std::string(names + name_off[r], size_t(name_off[r + 1] - name_off[r]));
         };
+        // (CIGAR text is tokenised like the reference's re.findall: what it skips is skipped; what remains are a
+        // shape mismatch — ValueError, sequences.py:790 — and the span assertion, sequences.py:732)
         for (uint32_t i = 0; i < uint32_t(walk_err.size()); ++i)
             if (walk_err[i] & kWalkParseMask)
-                return fail(h, BOSSX_E_PARSE, "read '" + plan_name(i) + "': " + walk_message(walk_err[i] & kWalkParseMask));
+                return fail(h, (walk_err[i] & kWalkParseMask) == kWalkSpanMismatch ? BOSSX_E_ASSERT : BOSSX_E_PARSE,
+                            "read '" + plan_name(i) + "': " + walk_message(walk_err[i] & kWalkParseMask));
         if (pb.pre_code) return fail(h, pb.pre_code, pb.pre_msg);
         {
             int64_t best_gi = pb.pre_range_gi;

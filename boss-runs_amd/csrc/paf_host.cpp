@@ -40,21 +40,33 @@ struct Rec {
     bool rev;
     const char *cg; size_t cg_len;   // points into the PAF text
     bool has_cg;
+    // columns that are not integers stay strings in the reference (conv_type, paf.py:103-108) and only
+    // matter where it computes with them: bit = column index
+    uint32_t bad_cols = 0;
 };
 
-// Python `int(s)` for the plain forms PAF uses: optional sign + decimal digits.
+std::string_view strip(std::string_view s);
+
+// Python `int(s)` for a str: surrounding whitespace, optional sign, decimal digits with single
+// underscores between them.  Values beyond +-2^62 saturate (Python's integers do not overflow; nothing
+// on the path can hold such a value either: the checks downstream reject it like the reference does).
 bool parse_int(std::string_view s, int64_t &v) {
+    s = strip(s);
     size_t i = 0, n = s.size();
-    while (i < n && (s[i] == ' ')) ++i;
     bool neg = false;
     if (i < n && (s[i] == '+' || s[i] == '-')) { neg = s[i] == '-'; ++i; }
-    if (i >= n) return false;
+    if (i >= n || s[i] < '0' || s[i] > '9') return false;
+    constexpr int64_t kBig = int64_t(1) << 62;
     int64_t x = 0;
+    bool prev_us = false;
     for (; i < n; ++i) {
-        char c = s[i];
+        const char c = s[i];
+        if (c == '_') { if (prev_us) return false; prev_us = true; continue; }
         if (c < '0' || c > '9') return false;
-        x = x * 10 + (c - '0');
+        prev_us = false;
+        x = x >= kBig / 10 ? kBig : x * 10 + (c - '0');
     }
+    if (prev_us) return false;
     v = neg ? -x : x;
     return true;
 }
@@ -68,7 +80,7 @@ std::string normalise_name(std::string_view s) {
 
 std::string_view strip(std::string_view s) {
     size_t b = 0, e = s.size();
-    auto ws = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\f' || c == '\v'; };
+    auto ws = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\f' || c == '\v' || (c >= 0x1c && c <= 0x1f); };   // str.strip()
     while (b < e && ws(s[b])) ++b;
     while (e > b && ws(s[e - 1])) --e;
     return s.substr(b, e - b);
@@ -78,6 +90,8 @@ struct Group {
     Rec best;
     int64_t key_q, key_dp;
     int32_t read = -1;       // index of the read in the batch (-1: the name is not in the batch)
+    int32_t n_recs = 1;      // kept records of this read
+    bool bad_mapq = false;   // one of them has a mapq that is not an integer (np.array(..., dtype=int) in choose_best_mapper)
 };
 
 struct CigarTable {
@@ -107,20 +121,28 @@ struct LineOut {
     std::vector<Rec> recs;       // records that pass the min_len / primary filters, line order
     int64_t n_lines = 0;
     int64_t err_line = 0;        // 1-based within the range, 0 = none
+    int err_code = BOSSX_OK;     // class of the reference's exception for that line
     std::string err_msg;
 };
 
-// Paf.parse_PAF / PafLine.__init__ over the lines of [p, end) (paf.py:18-75, 631-672).
+// Paf.parse_PAF / PafLine.__init__ over the lines of [p, end) (paf.py:18-75, 631-672), with the
+// reference's exception classes (tests/golden/g_errors.json holds what it does, case by case):
+//   fewer than 12 columns, blank lines included     IndexError  (f[i], paf.py:50-51)
+//   tag that is not key:type:value                  ValueError  (x.split(":") unpacking, paf.py:95-98)
+//   tag type other than i / A / f / Z               KeyError    (c[tag])
+//   AS that int() does not take                     ValueError  (paf.py:62)
+//   alignment block length that is not an integer   TypeError   (str < int, paf.py:666)
+// Other non-integer columns stay strings there and only matter if the path computes with them
+// (Rec::bad_cols; the unused ones — tlen, number of matches — never do).
 void parse_lines(const char *p, const char *end, int64_t min_len, LineOut &lo) {
     std::vector<std::string_view> f;
-    auto fail = [&](const char *msg) { lo.err_line = lo.n_lines; lo.err_msg = msg; };
+    auto fail = [&](int code, const char *msg) { lo.err_line = lo.n_lines; lo.err_code = code; lo.err_msg = msg; };
     while (p < end) {
         const char *nl = static_cast<const char *>(memchr(p, '\n', size_t(end - p)));
         const char *le = nl ? nl : end;
         std::string_view line = strip(std::string_view(p, size_t(le - p)));
         p = nl ? nl + 1 : end;
         ++lo.n_lines;
-        if (line.empty()) continue;
         f.clear();
         size_t s = 0;
         while (true) {
@@ -129,13 +151,11 @@ void parse_lines(const char *p, const char *end, int64_t min_len, LineOut &lo) {
             f.push_back(line.substr(s, t - s));
             s = t + 1;
         }
-        if (f.size() < 12) return fail(": fewer than 12 columns");
+        if (f.size() < 12) return fail(BOSSX_E_RANGE, ": fewer than 12 columns");
         Rec r;
-        int64_t tlen, nmatch;
-        bool ok = parse_int(f[1], r.qlen) && parse_int(f[2], r.qstart) && parse_int(f[3], r.qend) &&
-                  parse_int(f[6], tlen) && parse_int(f[7], r.tstart) && parse_int(f[8], r.tend) &&
-                  parse_int(f[9], nmatch) && parse_int(f[10], r.alnlen) && parse_int(f[11], r.mapq);
-        if (!ok) return fail(": non-integer core column");
+        r.qlen = r.qstart = r.qend = r.tstart = r.tend = r.alnlen = r.mapq = 0;
+        auto col = [&](size_t k, int64_t &dst) { if (!parse_int(f[k], dst)) { dst = 0; r.bad_cols |= 1u << k; } };
+        col(1, r.qlen); col(2, r.qstart); col(3, r.qend); col(7, r.tstart); col(8, r.tend); col(10, r.alnlen); col(11, r.mapq);
         r.rev = !(f[4].size() == 1 && f[4][0] == '+');   // paf.py:58
         r.as = 0; r.has_cg = false; r.cg = nullptr; r.cg_len = 0;
         bool primary = false;
@@ -145,16 +165,27 @@ void parse_lines(const char *p, const char *end, int64_t min_len, LineOut &lo) {
             size_t c2 = c1 == std::string_view::npos ? c1 : tag.find(':', c1 + 1);
             if (c1 == std::string_view::npos || c2 == std::string_view::npos ||
                 tag.find(':', c2 + 1) != std::string_view::npos)
-                return fail(": malformed tag");   // x.split(':') unpack
-            std::string_view key = tag.substr(0, c1), val = tag.substr(c2 + 1);
+                return fail(BOSSX_E_PARSE, ": malformed tag");   // x.split(':') unpack
+            std::string_view key = tag.substr(0, c1), typ = tag.substr(c1 + 1, c2 - c1 - 1), val = tag.substr(c2 + 1);
+            if (!(typ.size() == 1 && (typ[0] == 'i' || typ[0] == 'A' || typ[0] == 'f' || typ[0] == 'Z')))
+                return fail(BOSSX_E_KEY, ": unknown tag type");
             if (key == "AS") {
-                if (!parse_int(val, r.as)) return fail(": AS is not an integer");
+                // int(tags_parsed.get("AS", 0)): an int, a float (truncated) or a str that int() has to take
+                bool ok = false;
+                if (typ[0] == 'f') {
+                    const std::string tmp(strip(val));
+                    char *ep = nullptr;
+                    const double d = tmp.empty() ? 0.0 : strtod(tmp.c_str(), &ep);
+                    if (!tmp.empty() && ep && *ep == '\0' && d == d && d > -9e18 && d < 9e18) { r.as = int64_t(d); ok = true; }
+                }
+                if (!ok && !parse_int(val, r.as)) return fail(BOSSX_E_PARSE, ": AS is not an integer");
             } else if (key == "cg") {
                 r.has_cg = true; r.cg = val.data(); r.cg_len = val.size();
             } else if (key == "tp") {
                 primary = (val == "P");
             }
         }
+        if (r.bad_cols & (1u << 10)) return fail(BOSSX_E_TYPE, ": alignment block length is not an integer");   // paf.py:666
         if (r.alnlen < min_len) continue;     // paf.py:666-667
         if (!primary) continue;               // paf.py:668-669
         r.qname = normalise_name(f[0]);
@@ -162,6 +193,10 @@ void parse_lines(const char *p, const char *end, int64_t min_len, LineOut &lo) {
         lo.recs.push_back(std::move(r));
     }
 }
+
+}  // namespace
+
+namespace {
 
 // One chosen mapping, resolved against the batch and the contig table (sequential pre-pass).
 struct Plan {
@@ -229,14 +264,19 @@ void walk_plans(const ParseInput &in, const std::vector<ContigInfo> &contigs, co
         EmitOp *const first = w;
         const uint32_t meta_base = (uint32_t(pl.bc) << 8) | (r.rev ? kOpRev : 0u);
         const char *cp = r.cg, *ce = r.cg + r.cg_len;
+        // the reference tokenises with re.findall(r"(\d+)([MIDNSHP=XB])") (sequences.py:672,767): whatever
+        // is not digits directly followed by one of these letters is skipped, silently
+        size_t n_tok = 0;
         while (cp < ce) {
             int64_t len = 0;
             const char *d0 = cp;
             unsigned d;
-            while (cp < ce && (d = unsigned(*cp) - unsigned('0')) < 10u) { len = len * 10 + int64_t(d); ++cp; }
-            if (cp == d0 || cp >= ce) return fail(BOSSX_E_PARSE, "read '" + r.qname + "': malformed CIGAR");
+            while (cp < ce && (d = unsigned(*cp) - unsigned('0')) < 10u) { len = len >= (int64_t(1) << 40) ? len : len * 10 + int64_t(d); ++cp; }
+            if (cp >= ce) break;                         // digits without a letter at the end
             const char op = *cp++;
-            if (!kCigarOp[static_cast<unsigned char>(op)]) return fail(BOSSX_E_PARSE, "read '" + r.qname + "': unknown CIGAR op");
+            if (cp - 1 == d0 || !kCigarOp[static_cast<unsigned char>(op)]) continue;
+            ++n_tok;
+            if (len >= int64_t(1000000000)) return fail(BOSSX_E_PARSE, "read '" + r.qname + "': CIGAR run of 10^9 bases or more");
             if (len == 0) continue;
             if (op == 'I') {                       // consumes query, emits nothing (sequences.py:781)
                 consumed += len; q += qstep * len;
@@ -262,11 +302,12 @@ void walk_plans(const ParseInput &in, const std::vector<ContigInfo> &contigs, co
             ref_pos += len;
             if (!del) { consumed += len; q += qstep * len; }
         }
+        if (n_tok == 0) return fail(BOSSX_E_PARSE, "read '" + r.qname + "': no CIGAR operation");      // zip(*[]), sequences.py:769
         if (consumed != q_need)
             return fail(BOSSX_E_PARSE, "read '" + r.qname + "': CIGAR consumes " + std::to_string(consumed) +
                                        " query bases, PAF says " + std::to_string(q_need));
         if (ref_pos - tlo != thi - tlo)
-            return fail(BOSSX_E_PARSE, "read '" + r.qname + "': CIGAR spans " + std::to_string(ref_pos - tlo) +
+            return fail(BOSSX_E_ASSERT, "read '" + r.qname + "': CIGAR spans " + std::to_string(ref_pos - tlo) +
                                        " reference bases, PAF says " + std::to_string(thi - tlo));   // sequences.py:732
         wo.emitted_per_contig[size_t(pl.cidx)] += uint64_t(thi - tlo);
         // split the read's emitted stretch at sweep-tile boundaries (padded site space)
@@ -355,8 +396,9 @@ class WorkPool {
     // finish the job, the caller takes part).
     static int worker_cap() {
         const unsigned hc = std::thread::hardware_concurrency();
-        int cap = std::min<int>(hc > 1 ? int(hc) - 1 : 0, 63);
+        int cap = std::min<int>(hc > 1 ? int(hc) - 1 : 0, 2 * parse_threads() - 1);
         if (getenv("BOSSX_PARSE_THREADS")) cap = std::min(cap, parse_threads() - 1);
+        if (const char *e = getenv("BOSSX_POOL_THREADS")) cap = std::min(cap, std::max(atoi(e), 1) - 1);
         return std::max(cap, 0);
     }
     void ensure(int want) {
@@ -487,7 +529,9 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
     std::vector<Group> groups;
     // Many small line ranges, pulled dynamically: a worker that wakes up late finds nothing left instead of
     // holding a sixteenth of the text back (one straggler used to set the pace: 0.28 ms against a mean of 0.06).
-    int nt = in.n_threads > 0 ? in.n_threads : int(std::min<size_t>(128, std::max<size_t>(1, in.paf_len / (size_t(48) << 10))));
+    size_t task_kb = 48;
+    if (const char *e = getenv("BOSSX_LINE_TASK_KB")) task_kb = size_t(std::max(atoi(e), 4));
+    int nt = in.n_threads > 0 ? in.n_threads : int(std::min<size_t>(256, std::max<size_t>(1, in.paf_len / (task_kb << 10))));
     if (in.paf_len < (size_t(1) << 16)) nt = 1;
     std::vector<const char *> cuts(size_t(nt) + 1, in.paf + in.paf_len);
     cuts[0] = in.paf;
@@ -532,7 +576,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
     {
         int64_t line_base = 0;
         for (const LineOut &lo : los) {          // first failing line in file order
-            if (lo.err_line) { err = "PAF line " + std::to_string(line_base + lo.err_line) + lo.err_msg; return BOSSX_E_PARSE; }
+            if (lo.err_line) { err = "PAF line " + std::to_string(line_base + lo.err_line) + lo.err_msg; return lo.err_code; }
             line_base += lo.n_lines;
         }
         // best record per query name, groups in first-appearance order.  Names are resolved to batch
@@ -578,12 +622,15 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
                         if (it != group_of_unknown.end()) unknown_slot = it->second;
                         slot = &unknown_slot;
                     }
+                    const bool bad_q = (r.bad_cols & (1u << 11)) != 0;
                     if (*slot < 0) {
-                        groups.push_back(Group{std::move(r), r.mapq, r.as, read});
+                        groups.push_back(Group{std::move(r), r.mapq, r.as, read, 1, bad_q});
                         if (read >= 0) *slot = int32_t(groups.size() - 1);
                         else group_of_unknown.emplace(std::string_view(groups.back().best.qname), int32_t(groups.size() - 1));
                     } else {
                         Group &g = groups[size_t(*slot)];
+                        ++g.n_recs;
+                        g.bad_mapq = g.bad_mapq || bad_q;
                         // argsort by (mapq, AS), last element wins; stable for ties (paf.py:716-721)
                         if (r.mapq > g.key_q || (r.mapq == g.key_q && r.as >= g.key_dp)) {
                             g.key_q = r.mapq; g.key_dp = r.as;
@@ -617,6 +664,10 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
     for (size_t gi = 0; gi < groups.size(); ++gi) {
         const Rec &r = groups[gi].best;
         auto pre_fail = [&](int code, std::string msg) { pre_err.group = int64_t(gi); pre_err.code = code; pre_err.msg = std::move(msg); };
+        if (groups[gi].n_recs > 1 && groups[gi].bad_mapq) {
+            pre_fail(BOSSX_E_PARSE, "read '" + r.qname + "': mapping quality is not an integer");   // choose_best_mapper, paf.py:716-718
+            break;
+        }
         if (groups[gi].read < 0) {
             pre_fail(BOSSX_E_KEY, "read '" + r.qname + "' is mapped in the PAF but absent from the batch");
             break;                      // seqs[rec.qname], sequences.py:708/713
@@ -635,8 +686,17 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         }
         ++n_rec;
         if (in.summary_only) continue;
+        // columns that stayed strings: the reference computes qlen - qend / qlen - qstart on '-' mappings
+        // (sequences.py:709-710), slices with qstart / qend on '+' ones (:790) and takes min / max of the
+        // target coordinates (:730-731) — a TypeError each; a '+' mapping never looks at qlen
+        const uint32_t bad_q = r.bad_cols & ((1u << 2) | (1u << 3) | (r.rev ? (1u << 1) : 0u));
+        if (r.rev && bad_q) { pre_fail(BOSSX_E_TYPE, "read '" + r.qname + "': query coordinate is not an integer"); break; }
         if (!r.has_cg) {
-            pre_fail(BOSSX_E_PARSE, "read '" + r.qname + "': mapping without cg tag");   // assert rec.cigar is not None
+            pre_fail(BOSSX_E_ASSERT, "read '" + r.qname + "': mapping without cg tag");   // assert rec.cigar is not None
+            break;
+        }
+        if (bad_q || (r.bad_cols & ((1u << 7) | (1u << 8)))) {
+            pre_fail(BOSSX_E_TYPE, "read '" + r.qname + "': coordinate is not an integer");
             break;
         }
         Plan pl{&r, int64_t(gi), read, cidx, 0, cur_emit, ops_at};
@@ -708,7 +768,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             const int64_t c_end = c.site_off + c.n_tiles * kTileSites;
             if (s_end > c_end) s_end = c_end;
             uint32_t ntile = 0;
-            for (int64_t t = int64_t(mp.site0) / kTileSites; t * kTileSites < s_end; ++t) {
+            for (int64_t t = int64_t(mp.site0) / kTileSites; thi > tlo && t * kTileSites < s_end; ++t) {      // (a mapping of insertions only emits nothing)
                 const size_t key = size_t(t) * size_t(in.nbarcodes) + size_t(pl.bc);
                 if (key < n_keys) marks[key >> 6] |= 1ull << (key & 63);
                 ++ntile;

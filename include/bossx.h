@@ -26,11 +26,13 @@ extern "C" {
 #define BOSSX_OK 0
 #define BOSSX_E_INVALID   (-1)  /* bad argument / call order                                  */
 #define BOSSX_E_HIP       (-2)  /* HIP runtime failure (message carries hipGetErrorString)     */
-#define BOSSX_E_PARSE     (-3)  /* malformed PAF / CIGAR (reference raises ValueError/Assert)  */
-#define BOSSX_E_KEY       (-4)  /* read id in PAF not present in the batch (KeyError)          */
-#define BOSSX_E_RANGE     (-5)  /* mapping outside its contig / non-ACGT read base (IndexError)*/
+#define BOSSX_E_PARSE     (-3)  /* malformed tag / AS value, CIGAR that does not consume qend - qstart read bases (ValueError) */
+#define BOSSX_E_KEY       (-4)  /* read id in PAF not present in the batch, unknown tag type letter (KeyError) */
+#define BOSSX_E_RANGE     (-5)  /* PAF line with fewer than 12 columns, mapping outside its contig, non-ACGT read base (IndexError) */
 #define BOSSX_E_WINDOW    (-6)  /* move_sum window outside [1, n] (Bottleneck ValueError)      */
 #define BOSSX_E_EMPTY     (-7)  /* no non-zero benefit (np.max of empty array: ValueError)     */
+#define BOSSX_E_TYPE      (-8)  /* a PAF column the path computes with is not an integer (TypeError: paf.py:103-108 keeps it a str) */
+#define BOSSX_E_ASSERT    (-9)  /* mapping without cg tag / CIGAR does not span tend - tstart (AssertionError, sequences.py:718,732) */
 
 #define BOSSX_WINDOW        100     /* strategy / downsampling window, reference.py:109,215   */
 #define BOSSX_BUCKET        20000   /* activation bucket, reference.py:83                      */

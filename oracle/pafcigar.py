@@ -6,6 +6,7 @@ _parse_content), :709-722 (choose_best_mapper) and
 """
 import re
 from collections import defaultdict
+from io import StringIO
 
 import numpy as np
 
@@ -57,10 +58,8 @@ def parse_paf(text, min_len=1):
     """PAF text -> {qname: [PafRec]} keeping primary records with block length >= min_len
     (paf.py:654-672)."""
     out = defaultdict(list)
-    for line in text.splitlines():
-        if not line.strip():
-            continue
-        rec = PafRec(line)
+    for line in StringIO(text):          # as the reference reads it (mapper.py:64): lines end at '\n' only
+        rec = PafRec(line)               # (a blank line is an IndexError there, paf.py:50-51)
         if rec.alignment_block_length < min_len:
             continue
         if not rec.primary:

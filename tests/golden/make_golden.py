@@ -57,6 +57,35 @@ def gen_tables(out):
     np.savez_compressed(os.path.join(out, "g_tables.npz"), **d)
 
 
+def gen_errors(out):
+    """What the reference does with malformed / unusual batches (scenarios.error_cases): the exception class
+    of Paf.parse_PAF -> CoverageConverter.convert_records -> Contig.increment_coverage, or a digest of
+    the coverage it ends with."""
+    import json
+    from boss.paf import Paf
+    from boss.runs.reference import Contig
+    from boss.runs.sequences import CoverageConverter
+    from scenarios import error_cases
+    contigs, cases = error_cases()
+    res = {}
+    for name, paf_text, seqs in cases:
+        conts = {n: Contig(n, synth.codes_to_str(c)) for n, c in contigs}
+        stage = "parse_PAF"
+        try:
+            paf = Paf.parse_PAF(StringIO(paf_text), min_len=200)
+            stage = "convert_records"
+            inc = CoverageConverter().convert_records(paf_dict=paf, seqs=seqs,
+                                                      quals={k: "I" * len(v) for k, v in seqs.items()})
+            stage = "increment_coverage"
+            for n, c in conts.items():          # core.py:77-86: every contig of contigs_filt
+                c.increment_coverage(inc[n])
+            res[name] = {"ok": digest(*[conts[n].coverage for n in sorted(conts)]), "n_reads": len(paf)}
+        except Exception as e:                  # noqa: BLE001 - the class is the datum
+            res[name] = {"error": type(e).__name__, "stage": stage}
+    with open(os.path.join(out, "g_errors.json"), "w") as fh:
+        json.dump(res, fh, indent=1, sort_keys=True)
+
+
 def gen_cigar(out):
     from boss.paf import Paf
     from boss.runs.sequences import CoverageConverter
@@ -359,12 +388,16 @@ def run_sim_scenario(out, tag, nb, accept_unmapped):
 
 def main():
     out = HERE
+    if os.environ.get("GOLDEN_ONLY") == "errors":       # (the other fixtures are not touched)
+        gen_errors(out)
+        return
     if os.environ.get("GOLDEN_ONLY") == "sat":          # (the other fixtures are not touched)
         d = run_saturated(out)
         print("sat thresholds", float(d["sat_threshold"]), float(d["sat1_threshold"]), "max benefit", float(d["sat_benefit_max"]))
         return
     gen_tables(out)
     gen_cigar(out)
+    gen_errors(out)
     gen_dists(out)
     for tag, pl, nb in SCENARIOS:
         d = run_scenario(out, tag, pl, nb)

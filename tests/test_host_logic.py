@@ -297,7 +297,7 @@ def test_native_parser_errors_are_first_in_record_order():
             host_parse(contigs, "\n".join(bad), batch["seqs"], n_threads=threads, expand=False)
         bad = list(lines)
         bad[300] = "\t".join(bad[300].split("\t")[:7])
-        with pytest.raises(ValueError, match="PAF line 301"):
+        with pytest.raises(IndexError, match="PAF line 301"):          # f[i] on a short line (paf.py:50-51)
             host_parse(contigs, "\n".join(bad), batch["seqs"], n_threads=threads, expand=False)
 
 
@@ -429,3 +429,34 @@ def test_readlength_fast_path_equals_float_scan():
     p.update(lens)
     o.update({"r%d" % i: int(v) for i, v in enumerate(lens)})
     assert np.array_equal(p.approx_ccl, o.approx_ccl) and p.lam == o.lam and p.longest_read == o.longest_read == 3000
+
+
+def test_native_front_end_error_classes_equal_the_reference():
+    """The native PAF / CIGAR front end against tests/golden/g_errors.json (what the reference itself does
+    with 60-odd malformed / unusual batches, scenarios.error_cases): the same exception class where the
+    reference raises, the same coverage where it does not — truncated lines (IndexError), non-integer
+    columns (TypeError only where the reference ever looks at them), tag syntax (ValueError / KeyError),
+    CIGAR text the reference's regex skips over, shape mismatches (ValueError) vs span assertions
+    (AssertionError), reads with other letters (IndexError) ..."""
+    import json
+    from scenarios import GOLDEN, digest, error_cases
+    from boss_runs_amd.engine import host_parse
+    contigs, cases = error_cases()
+    gold = json.load(open(os.path.join(GOLDEN, "g_errors.json")))
+    clist = [(n, c.shape[0], 0) for n, c in contigs]
+    bad = []
+    for name, paf_text, seqs in cases:
+        for threads in (1, 3):
+            try:
+                out = host_parse(clist, paf_text, seqs, n_threads=threads, min_len=200)
+                cov = {n: np.zeros((c.shape[0], 5, 1), dtype=np.uint16) for n, c in contigs}
+                for k, (n, _) in enumerate(contigs):
+                    sel = out["contig"] == k
+                    np.add.at(cov[n], (out["pos"][sel], out["code"][sel].astype(np.int64), 0), 1)
+                got = {"ok": digest(*[cov[n] for n in sorted(cov)])}
+            except Exception as e:          # noqa: BLE001
+                got = {"error": type(e).__name__}
+            want = gold[name]
+            if got.get("error") != want.get("error") or got.get("ok") != want.get("ok"):
+                bad.append((name, threads, got, {k: want[k] for k in want if k in ("ok", "error")}))
+    assert not bad, bad

@@ -204,3 +204,34 @@ def test_golden_saturated_regime():
     ingest(1)
     check("sat1")
 
+
+
+def _error_fixture():
+    import json
+    return json.load(open(os.path.join(GOLDEN, "g_errors.json")))
+
+
+def test_oracle_error_classes_equal_the_reference():
+    """tests/golden/g_errors.json: what the REFERENCE does with 60-odd malformed / unusual batches
+    (scenarios.error_cases) — the exception class of Paf.parse_PAF / convert_records /
+    increment_coverage (paf.py:18-75, 631-672; sequences.py:678-794; reference.py:122-145) or the
+    coverage it ends with.  The oracle must do the same, case by case."""
+    from scenarios import digest, error_cases
+    from oracle.contig import OContig
+    from oracle.pafcigar import parse_paf, convert_records
+    from boss_runs_amd import synth
+    contigs, cases = error_cases()
+    gold = _error_fixture()
+    assert set(gold) == {n for n, _, _ in cases}
+    for name, paf_text, seqs in cases:
+        conts = {n: OContig(n, synth.codes_to_str(c)) for n, c in contigs}
+        try:
+            paf = parse_paf(paf_text, min_len=200)
+            inc = convert_records(paf, seqs)
+            for n, c in conts.items():
+                c.increment_coverage(inc[n])
+            got = {"ok": digest(*[conts[n].coverage for n in sorted(conts)])}
+        except Exception as e:          # noqa: BLE001
+            got = {"error": type(e).__name__}
+        want = gold[name]
+        assert got.get("error") == want.get("error") and got.get("ok") == want.get("ok"), (name, got, want)

@@ -98,9 +98,9 @@ def test_error_behaviour(in_tmp):
     seqs = dict(batch["seqs"])
     with pytest.raises(KeyError):
         runs.engine.stage_batch(batch["paf"], {k: v for k, v in seqs.items() if k != rid})
-    # CIGAR inconsistent with the PAF coordinates -> ValueError / AssertionError class
+    # CIGAR inconsistent with the PAF coordinates -> AssertionError (sequences.py:732)
     bad = "\t".join(first[:8] + [str(int(first[8]) + 5)] + first[9:])
-    with pytest.raises(ValueError):
+    with pytest.raises(AssertionError):
         runs.engine.stage_batch(bad, seqs)
     # nothing was ingested by the failed calls
     runs.engine.sweep()
@@ -877,13 +877,18 @@ def test_device_cigar_walk_equals_host_walk(in_tmp, monkeypatch):
         return "\n".join(out)
     stage = lambda paf, s=seqs: eng.stage_batch(paf, s, barcodes=batch["barcodes"])
     with pytest.raises(ValueError, match="CIGAR"):
-        stage(with_cigar(40, lambda c: "7M" + c))                 # spans / consumes too much
-    with pytest.raises(ValueError, match="malformed CIGAR"):
-        stage(with_cigar(40, lambda c: c + "12"))                 # trailing digits
-    with pytest.raises(ValueError, match="malformed CIGAR"):
-        stage(with_cigar(40, lambda c: "M" + c))                  # operation without a length
-    with pytest.raises(ValueError, match="unknown CIGAR op"):
-        stage(with_cigar(40, lambda c: c.replace("M", "Z", 1)))
+        stage(with_cigar(40, lambda c: "7M" + c))                 # consumes too much of the read: shape mismatch (sequences.py:790)
+    with pytest.raises(AssertionError, match="span"):
+        stage(with_cigar(40, lambda c: "3D" + c))                 # emits too much: the span assertion (sequences.py:732)
+    good = stage(batch["paf"])["aligned"]
+    # what the reference's re.findall skips is skipped: digits at the end, a letter without a length, garbage
+    assert stage(with_cigar(40, lambda c: c + "12"))["aligned"] == good
+    assert stage(with_cigar(40, lambda c: "M" + c))["aligned"] == good
+    assert stage(with_cigar(40, lambda c: "?!" + c))["aligned"] == good
+    with pytest.raises(ValueError, match="CIGAR"):
+        stage(with_cigar(40, lambda c: c.replace("M", "Z", 1)))   # ... and a skipped run is missing from the count
+    with pytest.raises(ValueError, match="CIGAR"):
+        stage(with_cigar(40, lambda c: "hello"))                  # no operation at all
     with pytest.raises(ValueError, match="outside the read"):
         f = lines[41].split("\t")
         rid = f[0]
@@ -1139,3 +1144,38 @@ def test_counters_beyond_8192_vs_oracle(in_tmp, nb):
     assert int(oa.coverage[A, codesA[A], 0]) > 8_192
     assert int(oa.coverage[B, :, nb - 1].sum(dtype=np.uint64)) > 65_535
     assert 65_400 < int(oa.coverage[C, codesA[C], 0]) < 65_536
+
+
+def test_device_front_end_error_classes_equal_the_reference():
+    """tests/golden/g_errors.json (what the reference does with 60-odd malformed / unusual batches,
+    scenarios.error_cases) through the C-ABI and the DEVICE CIGAR walk: the same exception class where the
+    reference raises — and nothing ingested — the same coverage where it does not."""
+    import json
+    from scenarios import digest, error_cases
+    from boss_runs_amd.engine import Engine
+    from boss_runs_amd.scoring import SiteScoring
+    from boss_runs_amd import synth
+    contigs, cases = error_cases()
+    gold = json.load(open(os.path.join(GOLDEN, "g_errors.json")))
+    hap = SiteScoring(1)
+    bad = []
+    for name, paf_text, seqs in cases:
+        eng = Engine(nbarcodes=1, track_entropy=False)
+        for n, c in contigs:
+            eng.add_contig(n, synth.codes_to_str(c))
+        eng.finalize(hap.score0[0], hap.ent0[0])
+        eng.set_lut(*hap.tables())
+        try:
+            eng.stage_batch(paf_text, seqs, ingest=True)
+            eng.sweep()
+            got = {"ok": digest(*[eng.export(k, "coverage") for k, _ in sorted(enumerate(contigs), key=lambda kc: kc[1][0])])}
+        except Exception as e:          # noqa: BLE001
+            got = {"error": type(e).__name__}
+            eng.sweep()
+            assert all(int(eng.export(k, "coverage").sum()) == 0 for k in range(len(contigs))), name
+        want = gold[name]
+        if got.get("error") != want.get("error") or got.get("ok") != want.get("ok"):
+            bad.append((name, got, {k: want[k] for k in want if k in ("ok", "error")}))
+        eng.close()
+    assert not bad, bad
+
