@@ -466,7 +466,7 @@ def run_grch38(a, rank, world, local_rank, steps=None, warmup=None):
                "chain_floor_ms": longest * CHAIN_FLOOR_CYCLES / GPU_CLOCK_GHZ * 1e-6,
                "note": "the update cannot be shorter than the exact move_sum chain of chr1 (chain_floor_ms) on any GPU "
                        "count: strong scaling of this path is chr1-bound by design",
-               "collectives_per_update": (runs.comm.n_collectives / max(n_b, 1)) if distributed else 0,
+               "collectives_per_update": (runs.n_collectives / max(n_b, 1)) if distributed else 0,
                "generation_s": t_gen}
     eng.close()
     return out
@@ -678,7 +678,7 @@ def main():
                        "track_entropy": bool(a.track_entropy),
                        "parallelism": "contig-sharded x%d, one global threshold" % world,
                        "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
-                       "collectives_per_update": (runs.comm.n_collectives / max(n_b + 2 * a.steps, 1)) if distributed else 0},
+                       "collectives_per_update": (runs.n_collectives / max(n_b + 2 * a.steps, 1)) if distributed else 0},
             "commit": commit,
             "timed_region_s": elapsed,
             "kernels_only_ms": 1e3 * elapsed_res / a.steps,

@@ -16,6 +16,9 @@
 #include <string>
 #include <thread>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types only: the library is loaded on first use (dlopen), see RcclApi
+
 #include "engine.hpp"
 #include "kernels.hip.inc"
 #include "front_end.hip.inc"
@@ -65,6 +68,12 @@ struct bossx_engine {
     int chain_flow_bufs = 4;        // difference buffers it is launched with (5 when the LDS allows)
     int chain_flow_ce = 2;          // the chain wave stores the carry into every CE-th step, the tail waves rebuild the others (BOSSX_FLOW_CE=1: all of them)
     int32_t nb = 1;
+
+    // native multi-GPU driver (bossx_dist_init): RCCL communicator of this engine's device
+    ncclComm_t comm = nullptr;
+    int32_t dist_rank = 0, dist_world = 1;
+    bool dist_armed = false;           // "some strategy is on" has been seen globally (sticky)
+    int64_t n_collectives = 0;
 
     std::vector<ContigInfo> contigs;                    // add order (rejected included)
     std::unordered_map<std::string, int32_t> index;     // name -> add order
@@ -352,10 +361,13 @@ int bossx_create(const bossx_config *cfg, bossx_engine **out) {
     return BOSSX_OK;
 }
 
+extern "C++" { namespace { void rccl_destroy(ncclComm_t comm); } }
+
 void bossx_destroy(bossx_engine *h) {
     if (!h) return;
     hipSetDevice(h->cfg.device);
     hipStreamSynchronize(h->stream);
+    if (h->comm) { rccl_destroy(h->comm); h->comm = nullptr; }
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
     if (h->stream_up) { hipStreamSynchronize(h->stream_up); hipStreamDestroy(h->stream_up); }
     if (h->ev_up) hipEventDestroy(h->ev_up);
@@ -1793,7 +1805,14 @@ static int copy_masks(bossx_engine *h, uint8_t *dst, bool bits) {
     return BOSSX_OK;
 }
 
+namespace { int dist_finish_impl(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, bossx_update_result *res, bool bits); }
+
 int bossx_dist_finish(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, bossx_update_result *res) {
+    return dist_finish_impl(h, strat_all, contig_on, res, false);
+}
+
+namespace {
+int dist_finish_impl(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, bossx_update_result *res, bool bits) {
     if (!h || !h->finalized || !res) return fail(h, BOSSX_E_INVALID, "bad dist_finish call");
     HIPCHK(hipSetDevice(h->cfg.device));
     { int jrc = settle_chain(h); if (jrc) return jrc; }
@@ -1816,7 +1835,7 @@ int bossx_dist_finish(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, b
     int32_t *herr = reinterpret_cast<int32_t *>(pin + sizeof(Ctrl));
     uint8_t *hon = reinterpret_cast<uint8_t *>(pin + sizeof(Ctrl) + 16);
     HIPCHK(hipMemcpyAsync(pin, h->d_result, h->result_bytes, hipMemcpyDeviceToHost, h->stream));
-    if (strat_all && (rc = copy_masks(h, strat_all, false))) return rc;
+    if (strat_all && (rc = copy_masks(h, strat_all, bits))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     if (*herr) {
         HIPCHK(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
@@ -1834,6 +1853,118 @@ int bossx_dist_finish(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, b
         HIPCHK(hipMemsetAsync(&h->d_ctrl->err, 0, sizeof(int32_t), h->stream));
         return fail(h, BOSSX_E_EMPTY, "no non-zero benefit (np.max of an empty array)");
     }
+    return BOSSX_OK;
+}
+}  // namespace
+
+// ---- native collectives driver ------------------------------------------------------------------------
+extern "C++" {
+namespace {
+// librccl through dlopen: libbossx.so stays loadable (and single-GPU runs stay possible) where no RCCL is
+// installed, and inside a torch process the already loaded copy is the one that is found.
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+    bool load() {
+        if (lib) return true;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!lib) { err = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return false; }
+        auto sym = [&](const char *n) { void *p = dlsym(lib, n); if (!p) err = std::string("librccl lacks ") + n; return p; };
+        GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
+        CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        AllReduce = reinterpret_cast<decltype(AllReduce)>(sym("ncclAllReduce"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+        if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString) { lib = nullptr; return false; }
+        return true;
+    }
+};
+RcclApi &rccl() { static RcclApi api; return api; }
+void rccl_destroy(ncclComm_t comm) { if (rccl().lib && comm) rccl().CommDestroy(comm); }
+
+#define NCCLCHK(expr)                                                                              \
+    do {                                                                                           \
+        ncclResult_t r_ = (expr);                                                                  \
+        if (r_ != ncclSuccess)                                                                     \
+            return fail(h, BOSSX_E_HIP, std::string(#expr) + ": " + rccl().GetErrorString(r_));    \
+    } while (0)
+
+// in-place all-reduce on the engine's stream (ordered between its kernels)
+int dist_allreduce(bossx_engine *h, void *buf, size_t count, ncclDataType_t dt, ncclRedOp_t op) {
+    NCCLCHK(rccl().AllReduce(buf, buf, count, dt, op, h->comm, h->stream));
+    ++h->n_collectives;
+    return BOSSX_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+int bossx_dist_unique_id(uint8_t *id) {
+    if (!id || !rccl().load()) return BOSSX_E_HIP;
+    ncclUniqueId u;
+    if (rccl().GetUniqueId(&u) != ncclSuccess) return BOSSX_E_HIP;
+    static_assert(sizeof(u) == BOSSX_NCCL_ID_BYTES, "ncclUniqueId size");
+    memcpy(id, &u, sizeof(u));
+    return BOSSX_OK;
+}
+
+int bossx_dist_init(bossx_engine *h, const uint8_t *id, int32_t rank, int32_t world) {
+    if (!h || !h->finalized || !id || world < 1 || rank < 0 || rank >= world) return fail(h, BOSSX_E_INVALID, "bad dist_init call");
+    if (!rccl().load()) return fail(h, BOSSX_E_HIP, rccl().err);
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (h->comm) { rccl_destroy(h->comm); h->comm = nullptr; }
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    NCCLCHK(rccl().CommInitRank(&h->comm, world, u, rank));
+    h->dist_rank = rank; h->dist_world = world; h->dist_armed = false;
+    // the protocol consumes the chain through stage-wise entry points: keep it after the sweep
+    h->overlap_ok = false;
+    return BOSSX_OK;
+}
+
+int64_t bossx_dist_collectives(const bossx_engine *h) { return h ? h->n_collectives : 0; }
+
+int bossx_dist_chain(bossx_engine *h, const int32_t *windows, const double *mult) {
+    if (!h || !h->finalized || !h->comm || !windows || !mult) return fail(h, BOSSX_E_INVALID, "bad dist_chain call (bossx_dist_init first)");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int rc;
+    if (!h->dist_armed && (rc = dist_allreduce(h, &h->d_ctrl->any_on, 1, ncclInt32, ncclMax))) return rc;      // core.py:111 is a global decision
+    return bossx_update_benefit(h, windows, mult);                                                            // gated on the (now global) flag
+}
+
+int bossx_dist_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all, uint8_t *contig_on,
+                      bossx_update_result *res) {
+    if (!h || !h->finalized || !up || !res) return fail(h, BOSSX_E_INVALID, "bad dist_update call");
+    if (!h->comm) return fail(h, BOSSX_E_INVALID, "dist_update before bossx_dist_init");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int rc;
+    if (!(up->flags & BOSSX_UPDATE_SWEEP_DONE) && (rc = bossx_update_begin(h, up->bucket_threshold))) return rc;
+    const bool fhat_resident = (up->flags & BOSSX_UPDATE_FHAT_RESIDENT) != 0 && up->fhat_c == nullptr;
+    const bool have_strategy_inputs = up->fhat_c != nullptr || fhat_resident;
+    if (!(up->flags & BOSSX_UPDATE_BENEFIT_DONE)) {
+        if (!h->dist_armed && (rc = dist_allreduce(h, &h->d_ctrl->any_on, 1, ncclInt32, ncclMax))) return rc;
+        if (have_strategy_inputs && (rc = bossx_update_benefit(h, up->windows, up->mult))) return rc;
+    }
+    if (have_strategy_inputs) {
+        // halo rows + the normaliser behind them: ONE MAX all-reduce (non-negative, one contributor each: exact)
+        if ((rc = bossx_dist_tails(h))) return rc;
+        const size_t n_t = h->filt.size() * h->filt.size() * 2 * size_t(h->nb) + 1;
+        if ((rc = dist_allreduce(h, h->d_tails, n_t, ncclFloat64, ncclMax))) return rc;
+        bossx_fhat_desc fh{up->fhat_c, up->n_windows, 20, up->target_rs, h->n_sites_all / kWindow};
+        if (fhat_resident && (rc = bossx_fhat_build(h, up->n_windows, up->target_rs, up->fhat_alpha, up->fhat_den, up->fhat_expected, up->fhat_on_target))) return rc;
+        if ((rc = bossx_dist_hist(h, &fh))) return rc;
+        if ((rc = dist_allreduce(h, h->d_limbs, size_t(BOSSX_HIST_BINS + 1) * 5, ncclInt64, ncclSum))) return rc;
+        if ((rc = bossx_dist_pick(h, up->tc))) return rc;
+    }
+    rc = dist_finish_impl(h, strat_all, contig_on, res, (up->flags & BOSSX_UPDATE_STRAT_BITS) != 0);
+    if (rc) return rc;
+    if (res->any_on) h->dist_armed = true;
+    if (!have_strategy_inputs) res->updated = 0;
     return BOSSX_OK;
 }
 

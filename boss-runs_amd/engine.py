@@ -398,9 +398,36 @@ class Engine:
         if k.size:
             self._ck(self.lib.bossx_fhat_add(self.h, k.ctypes.data, int(k.size)))
 
+    # ---- native multi-GPU driver: RCCL called by the library on the engine's stream (bossx_dist_*) --------
+    def dist_unique_id(self):
+        """bossx_dist_unique_id: the communicator id rank 0 shares with the other ranks (uint8[128])."""
+        buf = np.zeros(128, dtype=np.uint8)
+        rc = self.lib.bossx_dist_unique_id(buf.ctypes.data)
+        if rc:
+            raise _lib.BossxError("bossx_dist_unique_id failed (%d): librccl could not be loaded" % rc)
+        return buf
+
+    def dist_init(self, uid, rank, world):
+        uid = np.ascontiguousarray(uid, dtype=np.uint8)
+        assert uid.size == 128
+        self._ck(self.lib.bossx_dist_init(self.h, uid.ctypes.data, int(rank), int(world)))
+        self.dist_native = True
+
+    def dist_chain(self, windows, mult):
+        """bossx_dist_chain: the global "some strategy is on" exchange (until it is) + the move_sum chain."""
+        w = np.ascontiguousarray(windows, dtype=np.int32)
+        m = np.ascontiguousarray(mult, dtype=np.float64)
+        assert w.shape == (_lib.NWIN,) and m.shape == (10,)
+        self._ck(self.lib.bossx_dist_chain(self.h, w.ctypes.data, m.ctypes.data))
+        self._benefit_done = tuple(w.tolist())
+
+    @property
+    def dist_collectives(self):
+        return int(self.lib.bossx_dist_collectives(self.h))
+
     def update(self, bucket_threshold, windows=None, mult=None, tc=0.0, fhat_c=None, target_rs=0,
-               want_stats=False, bits=False, fhat_model=None):
-        """bossx_update: one fused decision update.  Without `fhat_c` only the sweep and the
+               want_stats=False, bits=False, fhat_model=None, dist=False):
+        """bossx_update (`dist`: bossx_dist_update): one fused decision update.  Without `fhat_c` only the sweep and the
         bucket switches run.  Returns dict(updated, any_on, threshold, normaliser, ubar0,
         strat_size, n_bins, contig_on[, counts, fgrid_fx, ubar_fx]); masks land in
         `self.strat_all` (bytes of every non-rejected contig, add order) or, with `bits`,
@@ -458,10 +485,13 @@ class Engine:
             counts = np.zeros(_lib.HIST_BINS, dtype=np.int64)
             fg = np.zeros((_lib.HIST_BINS, 2), dtype=np.uint64)
             ub = np.zeros(2, dtype=np.uint64)
-        self._ck(self.lib.bossx_update(self.h, C.byref(up), masks.ctypes.data, on.ctypes.data,
-                                       C.byref(res), None if counts is None else counts.ctypes.data,
-                                       None if fg is None else fg.ctypes.data,
-                                       None if ub is None else ub.ctypes.data))
+        if dist:        # bossx_dist_update: the same update with the library's own RCCL collectives between the stages
+            self._ck(self.lib.bossx_dist_update(self.h, C.byref(up), masks.ctypes.data, on.ctypes.data, C.byref(res)))
+        else:
+            self._ck(self.lib.bossx_update(self.h, C.byref(up), masks.ctypes.data, on.ctypes.data,
+                                           C.byref(res), None if counts is None else counts.ctypes.data,
+                                           None if fg is None else fg.ctypes.data,
+                                           None if ub is None else ub.ctypes.data))
         out = dict(updated=bool(res.updated), any_on=bool(res.any_on), threshold=res.threshold,
                    normaliser=res.normaliser, ubar0=res.ubar0, strat_size=res.strat_size,
                    n_bins=res.n_bins, contig_on=on.astype(bool))

@@ -171,8 +171,16 @@ class DistributedBossRuns(BossRuns):
         # RCCL path: the engine shares torch's stream and its statistics buffers are wrapped as
         # tensors, so the update's collectives run in-stream (no host round trips)
         import os
-        self.instream = (engine is None and self.comm.on and self.comm.device != "cpu"
-                         and not os.environ.get("BOSSX_HOST_COLLECTIVES"))
+        on_gpu = engine is None and self.comm.on and self.comm.device != "cpu" and not os.environ.get("BOSSX_HOST_COLLECTIVES")
+        # native driver (default on GPUs): the LIBRARY issues the update's all-reduces (RCCL, on the engine's own
+        # stream, between its kernels): one C call per update.  BOSSX_TORCH_COLLECTIVES=1 keeps the form in which
+        # torch.distributed issues them in-stream on tensors that alias the engine's buffers.
+        self.native = on_gpu and not os.environ.get("BOSSX_TORCH_COLLECTIVES")
+        self.instream = on_gpu and not self.native
+        if self.native:
+            from .engine import Engine
+            engine = Engine(nbarcodes=nb, device=self.comm.torch.cuda.current_device(),
+                            track_entropy=self.args.gpu.track_entropy)
         if self.instream:
             from .engine import Engine
             torch = self.comm.torch
@@ -185,6 +193,11 @@ class DistributedBossRuns(BossRuns):
                             track_entropy=self.args.gpu.track_entropy,
                             stream=self.tstream.cuda_stream)
         super().init(contigs=contigs, engine=engine, is_local=lambda name, k: self.owner[k] == rank)
+        if self.native:
+            # rank 0 makes the RCCL id; it travels to the others as an all-reduce of zeros elsewhere
+            uid = self.engine.dist_unique_id() if rank == 0 else np.zeros(128, dtype=np.uint8)
+            uid = self.comm.allreduce(uid.astype(np.int64), "sum").astype(np.uint8)
+            self.engine.dist_init(uid, rank, self.comm.world)
         if self.instream:
             torch = self.comm.torch
             eng = self.engine
@@ -209,6 +222,11 @@ class DistributedBossRuns(BossRuns):
         self.armed = False
         self._begun = False
         self.filt_names = list(self.contigs_filt.keys())
+
+    @property
+    def n_collectives(self):
+        """Collectives of this rank so far: torch.distributed's plus the library's own (native driver)."""
+        return self.comm.n_collectives + (self.engine.dist_collectives if getattr(self, "native", False) else 0)
 
     # ---- batch -----------------------------------------------------------------------------
     def process_batch_paf(self, paf_text, new_reads, barcodes=None, min_len=200, read_lengths=None,
@@ -278,6 +296,11 @@ class DistributedBossRuns(BossRuns):
         are known, exchange the "some strategy is on" flag (until it is) and enqueue the chain, so
         that it runs while the host still counts read starts and builds f-hat."""
         self._chain_early = False
+        if getattr(self, "native", False) and self._begun and hasattr(self.rl_dist, "time_cost") and getattr(self, "early_chain", True):
+            windows = np.concatenate(([400 // 100], self.rl_dist.approx_ccl // 100)).astype(np.int32)
+            self.engine.dist_chain(windows, MULT)
+            self._chain_early = True
+            return
         if not (getattr(self, "instream", False) and self._begun and hasattr(self.rl_dist, "time_cost")
                 and getattr(self, "early_chain", True) and self.comm.dist is not None):
             return
@@ -341,7 +364,46 @@ class DistributedBossRuns(BossRuns):
         if self.write_masks and self.comm.rank == 0:
             self._write_contig_strategies(contig_strats=self.ref.get_strategy_dict())
 
+    def _update_native(self) -> None:
+        """The update as ONE library call (bossx_dist_update): RCCL all-reduces issued by the library between its
+        own kernels — MAX of the armed flag (until some strategy is on), MAX over halo rows + normaliser, SUM of
+        the exact histogram limbs — one synchronisation at the end."""
+        eng = self.engine
+        self.begin_update()
+        self._begun = False
+        self._chain_early = False
+        thr_b = self.args.optional.bucket_threshold
+        if hasattr(self.rl_dist, "time_cost"):
+            windows = np.concatenate(([400 // 100], self.rl_dist.approx_ccl // 100)).astype(np.int32)
+            if self.read_starts._engine is not None:
+                res = eng.update(thr_b, windows, MULT, tc=self.rl_dist.time_cost // 100,
+                                 fhat_model=self.read_starts.fhat_model(), dist=True)
+            else:
+                fhat_c, target_rs = self.read_starts.fhat_compact()
+                res = eng.update(thr_b, windows, MULT, tc=self.rl_dist.time_cost // 100, fhat_c=fhat_c, target_rs=target_rs, dist=True)
+        else:
+            res = eng.update(thr_b, dist=True)
+        for cont in self.local_filt.values():
+            if res["contig_on"][cont.index]:
+                cont.switched_on[:] = True
+        self.armed = res["any_on"]
+        if not self.armed:
+            return
+        if not hasattr(self.rl_dist, "time_cost"):
+            raise AttributeError("'ReadlengthDist' object has no attribute 'time_cost'")
+        self.threshold = res["threshold"]
+        self.last_stats = dict(normaliser=res["normaliser"], ubar0=res["ubar0"],
+                               strat_size=res["strat_size"], n_bins=res["n_bins"])
+        for cont in self.local_filt.values():
+            cont.strat = eng.strat_view(cont.index)
+        if self.gather_masks and (self.comm.world > 1 or self.comm.force):
+            self._gather_masks()
+        if self.write_masks and self.comm.rank == 0:
+            self._write_contig_strategies(contig_strats=self.ref.get_strategy_dict())
+
     def update_wrapper(self) -> None:
+        if getattr(self, "native", False):
+            return self._update_native()
         if getattr(self, "instream", False):
             return self._update_instream()
         eng, comm = self.engine, self.comm

@@ -303,6 +303,26 @@ int bossx_dist_hist(bossx_engine *h, const bossx_fhat_desc *fh);
 int bossx_dist_pick(bossx_engine *h, double tc);
 int bossx_dist_tails(bossx_engine *h);
 int bossx_dist_finish(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, bossx_update_result *res);
+/* ---- the same update with the collectives issued by the LIBRARY: RCCL (ncclAllReduce) on the engine's
+ *      own stream, between its kernels — one call per update, no interpreter between the stages.
+ *      bossx_dist_unique_id (rank 0) makes the id every rank passes to bossx_dist_init (share it through
+ *      any channel: a file, MPI, torch.distributed); bossx_dist_init creates the communicator for this
+ *      engine's device.  bossx_dist_chain (optional) exchanges the "some strategy is on" flag (until it is)
+ *      and enqueues the move_sum chain as soon as the read-length windows are known; bossx_dist_update
+ *      enqueues whatever is still missing of
+ *          sweep + bucket switches | MAX armed | chain | tails | MAX tails + normaliser | f-hat |
+ *          histogram | SUM limbs | threshold | masks | D2H
+ *      and returns with the masks of the LOCAL contigs and the global threshold.  `up` as for bossx_update
+ *      (BOSSX_UPDATE_SWEEP_DONE / _BENEFIT_DONE / _FHAT_RESIDENT honoured; fhat_c or the resident counts
+ *      must describe the GLOBAL read starts).  librccl is loaded on first use (dlopen).                 */
+#define BOSSX_NCCL_ID_BYTES 128
+int bossx_dist_unique_id(uint8_t *id /*[BOSSX_NCCL_ID_BYTES]*/);
+int bossx_dist_init(bossx_engine *h, const uint8_t *id, int32_t rank, int32_t world);
+int bossx_dist_chain(bossx_engine *h, const int32_t *windows, const double *mult);
+int bossx_dist_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all, uint8_t *contig_on,
+                      bossx_update_result *res);
+/* Collectives issued through this engine's communicator so far (measurement).                         */
+int64_t bossx_dist_collectives(const bossx_engine *h);
 /* Page-locked host memory for the caller's output buffers — the mask buffer of bossx_update above
  * all: a device-to-host copy into it is a direct DMA, into pageable memory it is staged (2.2 MB of
  * masks at 110 Mb: 0.1 ms less per update; registering pageable memory after the fact measured

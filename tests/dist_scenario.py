@@ -63,7 +63,7 @@ def worker(rank, world, port, tmp, nb, ploidy, ret, backend="gloo"):
         out.append(dict(threshold=runs.threshold, stats={k: np.asarray(v) for k, v in runs.last_stats.items()},
                         strat={n: np.array(c.strat, copy=True) for n, c in runs.contigs.items()},
                         approx_ccl=runs.rl_dist.approx_ccl.copy(), starts=runs.read_starts.merge().copy(),
-                        collectives=runs.comm.n_collectives))
+                        collectives=runs.n_collectives))
     ret[rank] = out
     dist.barrier()
     if backend == "nccl":

@@ -144,20 +144,24 @@ def test_export_import_roundtrip(in_tmp):
     assert np.array_equal(c2.entropy, ent)
 
 
-@pytest.mark.parametrize("host_collectives", [False, True])
-def test_distributed_protocol_single_rank_nccl(in_tmp, monkeypatch, host_collectives):
-    """The multi-GPU protocol on one GPU with the collectives forced on (nccl = RCCL), in both
-    forms: in-stream all-reduces on tensors aliasing the engine's device buffers, and the
-    host-staged form; result must equal the fused single-GPU update."""
+@pytest.mark.parametrize("mode", ["native", "torch", "host"])
+def test_distributed_protocol_single_rank_nccl(in_tmp, monkeypatch, mode):
+    """The multi-GPU protocol on one GPU with the collectives forced on (nccl = RCCL), in its three
+    forms: the library's own RCCL calls on the engine's stream (bossx_dist_update, the default),
+    in-stream all-reduces issued by torch.distributed on tensors aliasing the engine's device buffers,
+    and the host-staged form; the result must equal the fused single-GPU update."""
+    host_collectives = mode == "host"
     if host_collectives:
         monkeypatch.setenv("BOSSX_HOST_COLLECTIVES", "1")
+    if mode == "torch":
+        monkeypatch.setenv("BOSSX_TORCH_COLLECTIVES", "1")
     import torch
     import torch.distributed as dist
     from boss_runs_amd.config import BossConfig
     from boss_runs_amd.parallel import DistributedBossRuns
     monkeypatch.setenv("BOSSX_FORCE_COLLECTIVES", "1")
     monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
-    monkeypatch.setenv("MASTER_PORT", "29632" if host_collectives else "29631")
+    monkeypatch.setenv("MASTER_PORT", {"native": "29633", "torch": "29631", "host": "29632"}[mode])
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
@@ -167,7 +171,7 @@ def test_distributed_protocol_single_rank_nccl(in_tmp, monkeypatch, host_collect
         args.optional.reject_refs = E2E_REJECT
         d = DistributedBossRuns(args)
         d.init(contigs=e2e_contig_strings(contigs))
-        assert d.instream == (not host_collectives)
+        assert d.native == (mode == "native") and d.instream == (mode == "torch")
         if d.instream:
             assert d.tstream.cuda_stream != 0      # the engine really shares torch's stream
         f = _product(1, 1, in_tmp)
@@ -179,7 +183,10 @@ def test_distributed_protocol_single_rank_nccl(in_tmp, monkeypatch, host_collect
             assert d.threshold == f.threshold
             for n in f.contigs:
                 assert np.array_equal(d.contigs[n].strat, f.contigs[n].strat), (b, n)
-        assert d.comm.n_collectives >= 6
+        assert d.n_collectives >= 6
+        if d.native:
+            assert d.engine.dist_collectives >= 6      # issued by the library itself
+            d.engine.close()
     finally:
         dist.destroy_process_group()
 
@@ -413,7 +420,7 @@ def test_simulation_decisions(in_tmp):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_two_rank_device_protocol_emulated_on_one_gpu(in_tmp, world):
+def test_two_rank_device_protocol_emulated_on_one_gpu(in_tmp, world, monkeypatch):
     """Cross-rank logic of the device-resident multi-GPU update without a second GPU: two
     engines on cuda:0 own different contigs; the four in-stream all-reduces are emulated by
     reducing the two engines' aliased statistics tensors.  Exercises remote-contig geometry in
@@ -424,6 +431,7 @@ def test_two_rank_device_protocol_emulated_on_one_gpu(in_tmp, world):
     from boss_runs_amd.config import BossConfig
     from boss_runs_amd.parallel import DistributedBossRuns
     from boss_runs_amd.runs import MULT
+    monkeypatch.setenv("BOSSX_TORCH_COLLECTIVES", "1")     # the stage-wise form: the reductions are done by hand below
 
     class FakeComm:
         def __init__(self, rank):
