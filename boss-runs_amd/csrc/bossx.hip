@@ -84,8 +84,8 @@ struct bossx_engine {
     double score0 = 0, ent0 = 0;
 
     // device state
-    uint16_t *d_cov = nullptr;
-    uint8_t *d_meta = nullptr, *d_touched = nullptr, *d_strat = nullptr, *d_bucket_on = nullptr;
+    uint8_t *d_state = nullptr;        // counters + state bytes, tile-major (engine.hpp: kTileStride bytes per (tile, barcode))
+    uint8_t *d_touched = nullptr, *d_strat = nullptr, *d_bucket_on = nullptr;
     uint8_t *d_strat_bits = nullptr;   // packed masks (allocated on first use)
     double *d_entropy = nullptr, *d_ds = nullptr, *d_benefit = nullptr;
     double *d_lut_score = nullptr, *d_lut_ent = nullptr, *d_fhat = nullptr;
@@ -252,7 +252,7 @@ void time_collect(bossx_engine *h) {
 
 SweepParams sweep_params(bossx_engine *h) {
     SweepParams P;
-    P.cov = h->d_cov; P.meta = h->d_meta; P.touched = h->d_touched; P.entropy = h->d_entropy;
+    P.st = SiteState{h->d_state, h->nb}; P.touched = h->d_touched; P.entropy = h->d_entropy;
     P.tile_ref = h->d_tile_ref; P.tiles = nullptr; P.n_groups = 0; P.pieces = nullptr; P.codes = nullptr;
     P.tile_contig = h->d_tile_contig;
     P.err_flag = h->d_err; P.use_touched = h->touched_dirty ? 1 : 0;
@@ -294,12 +294,34 @@ int flush_pending(bossx_engine *h) {
     }
     time_begin(h, BOSSX_K_INGEST);
     hipLaunchKernelGGL(ingest_scatter_kernel, dim3(n_tiles), dim3(256), 0, h->stream, st.d_ops, st.d_tiles,
-                       uint32_t(pb.n_ops), pb.total_emit, st.d_blob, reinterpret_cast<uint32_t *>(h->d_cov),
-                       h->d_touched, uint64_t(h->Gp / 2), h->d_err);
+                       uint32_t(pb.n_ops), pb.total_emit, st.d_blob, SiteState{h->d_state, h->nb},
+                       h->d_touched, h->d_err);
     time_end(h, BOSSX_K_INGEST, 6.0 * double(pb.total_emit) + 16.0 * double(pb.n_ops));
     HIPCHK(hipGetLastError());
     h->pending_slot = -1;
     h->touched_dirty = true;
+    return BOSSX_OK;
+}
+
+// One field of one (contig, barcode) between the tile-major site state and a contiguous host array of
+// c.length elements: `field_off` = byte offset of the field inside a tile record (a counter plane or
+// the state bytes), `elem` = bytes per site.  Whole tiles travel as one 2-D copy (pitch = the
+// record stride), the contig's last, partial tile as a 1-D one.  Synchronous.
+int copy_site_field(bossx_engine *h, const ContigInfo &c, int32_t b, int field_off, int elem, void *host, bool to_device) {
+    const int64_t row = int64_t(kTileSites) * elem;
+    const int64_t full = c.length / kTileSites, rest = c.length - full * kTileSites;
+    uint8_t *dev = h->d_state + (size_t(c.tile_off) * size_t(h->nb) + size_t(b)) * size_t(kTileStride) + size_t(field_off);
+    const size_t dpitch = size_t(h->nb) * size_t(kTileStride);
+    uint8_t *hp = static_cast<uint8_t *>(host);
+    if (full > 0) {
+        if (to_device) HIPCHK(hipMemcpy2D(dev, dpitch, hp, size_t(row), size_t(row), size_t(full), hipMemcpyHostToDevice));
+        else HIPCHK(hipMemcpy2D(hp, size_t(row), dev, dpitch, size_t(row), size_t(full), hipMemcpyDeviceToHost));
+    }
+    if (rest > 0) {
+        uint8_t *d2 = dev + size_t(full) * dpitch;
+        if (to_device) HIPCHK(hipMemcpy(d2, hp + full * row, size_t(rest) * size_t(elem), hipMemcpyHostToDevice));
+        else HIPCHK(hipMemcpy(hp + full * row, d2, size_t(rest) * size_t(elem), hipMemcpyDeviceToHost));
+    }
     return BOSSX_OK;
 }
 
@@ -390,7 +412,7 @@ void bossx_destroy(bossx_engine *h) {
     if (h->d_tile_done) hipFree(h->d_tile_done);
     if (h->d_tile_order) hipFree(h->d_tile_order);
     if (h->d_tile_contig) hipFree(h->d_tile_contig);
-    void *ptrs[] = {h->d_cov, h->d_meta, h->d_touched, h->d_strat, h->d_bucket_on, h->d_entropy, h->d_ds,
+    void *ptrs[] = {h->d_state, h->d_touched, h->d_strat, h->d_bucket_on, h->d_entropy, h->d_ds,
                     h->d_benefit, h->d_lut_score, h->d_lut_ent, h->d_fhat, h->d_bucket_sums, h->d_drop_count,
                     h->d_stats, h->d_tile_cov, h->d_tails /* base of the tails + result block */, h->d_tile_off, h->d_site_off, h->d_length, h->d_bin_off, h->d_row_off,
                     h->d_strat_off, h->d_bucket_off, h->d_drop_thr, h->d_local, h->d_limbs,
@@ -495,8 +517,7 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
     if (uint64_t(h->Gp) >= (1ull << 40)) return fail(h, BOSSX_E_INVALID, "reference too large");
 
     int rc;
-    if ((rc = dev_alloc(h, &h->d_cov, size_t(nb * 5 * h->Gp), true))) return rc;
-    if ((rc = dev_alloc(h, &h->d_meta, size_t(nb * h->Gp), true))) return rc;
+    if ((rc = dev_alloc(h, &h->d_state, size_t(std::max<int64_t>(h->n_tiles, 1)) * size_t(nb) * size_t(kTileStride), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_touched, size_t(h->Gp), true))) return rc;
     if (h->cfg.track_entropy) {
         if ((rc = dev_alloc(h, &h->d_entropy, size_t(nb * h->Gp)))) return rc;
@@ -583,7 +604,7 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
         if (c.remote) continue;
         const std::vector<uint8_t> &codes = h->host_codes[size_t(fi)];
         for (int64_t b = 0; b < nb; ++b)
-            HIPCHK(hipMemcpy(h->d_meta + b * h->Gp + c.site_off, codes.data(), codes.size(), hipMemcpyHostToDevice));
+            if ((rc = copy_site_field(h, c, int32_t(b), kTileMetaOff, 1, const_cast<uint8_t *>(codes.data()), true))) return rc;
     }
     if (h->d_entropy) {
         // fill with ent0 (reference.py:105)
@@ -2222,9 +2243,9 @@ int bossx_export(bossx_engine *h, int32_t contig, int32_t which, void *dst, size
     switch (which) {
         case 0: {
             if (!need(size_t(nb * 5 * L) * 2)) return fail(h, BOSSX_E_INVALID, "export buffer too small");
+            HIPCHK(hipStreamSynchronize(h->stream));
             for (int64_t p = 0; p < nb * 5; ++p)
-                HIPCHK(hipMemcpyAsync(static_cast<uint16_t *>(dst) + p * L, h->d_cov + p * h->Gp + c.site_off,
-                                      size_t(L) * 2, hipMemcpyDeviceToHost, h->stream));
+                if ((rc = copy_site_field(h, c, int32_t(p / 5), int(p % 5) * kTilePlaneBytes, 2, static_cast<uint16_t *>(dst) + p * L, false))) return rc;
             break;
         }
         case 1: {
@@ -2264,9 +2285,9 @@ int bossx_export(bossx_engine *h, int32_t contig, int32_t which, void *dst, size
         }
         case 5: {
             if (!need(size_t(nb * L))) return fail(h, BOSSX_E_INVALID, "export buffer too small");
+            HIPCHK(hipStreamSynchronize(h->stream));
             for (int64_t b = 0; b < nb; ++b)
-                HIPCHK(hipMemcpyAsync(static_cast<uint8_t *>(dst) + b * L, h->d_meta + b * h->Gp + c.site_off,
-                                      size_t(L), hipMemcpyDeviceToHost, h->stream));
+                if ((rc = copy_site_field(h, c, int32_t(b), kTileMetaOff, 1, static_cast<uint8_t *>(dst) + b * L, false))) return rc;
             break;
         }
         case 6: {
@@ -2307,12 +2328,13 @@ int bossx_import(bossx_engine *h, int32_t contig, int32_t which, const void *src
     switch (which) {
         case 0: {
             if (src_bytes != size_t(nb * 5 * L) * 2) return fail(h, BOSSX_E_INVALID, "import size mismatch");
+            HIPCHK(hipStreamSynchronize(h->stream));
             for (int64_t p = 0; p < nb * 5; ++p)
-                HIPCHK(hipMemcpy(h->d_cov + p * h->Gp + c.site_off, static_cast<const uint16_t *>(src) + p * L,
-                                 size_t(L) * 2, hipMemcpyHostToDevice));
+                if ((rc = copy_site_field(h, c, int32_t(p / 5), int(p % 5) * kTilePlaneBytes, 2,
+                                          const_cast<uint16_t *>(static_cast<const uint16_t *>(src) + p * L), true))) return rc;
             unsigned long long *d_tot = h->d_stats;
             HIPCHK(hipMemsetAsync(d_tot, 0, sizeof(unsigned long long), h->stream));
-            hipLaunchKernelGGL(contig_total_kernel, dim3(1024), dim3(256), 0, h->stream, h->d_cov, h->Gp, h->nb,
+            hipLaunchKernelGGL(contig_total_kernel, dim3(1024), dim3(256), 0, h->stream, SiteState{h->d_state, h->nb}, h->nb,
                                c.site_off, L, d_tot);
             unsigned long long tot = 0;
             HIPCHK(hipMemcpyAsync(&tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, h->stream));
@@ -2330,9 +2352,10 @@ int bossx_import(bossx_engine *h, int32_t contig, int32_t which, const void *src
         }
         case 5: {
             if (src_bytes != size_t(nb * L)) return fail(h, BOSSX_E_INVALID, "import size mismatch");
+            HIPCHK(hipStreamSynchronize(h->stream));
             for (int64_t b = 0; b < nb; ++b)
-                HIPCHK(hipMemcpy(h->d_meta + b * h->Gp + c.site_off, static_cast<const uint8_t *>(src) + b * L,
-                                 size_t(L), hipMemcpyHostToDevice));
+                if ((rc = copy_site_field(h, c, int32_t(b), kTileMetaOff, 1,
+                                          const_cast<uint8_t *>(static_cast<const uint8_t *>(src) + b * L), true))) return rc;
             break;
         }
         case 6: {
@@ -2375,11 +2398,11 @@ int bossx_preload_coverage(bossx_engine *h, double depth, uint64_t seed) {
         ContigInfo &c = h->contigs[size_t(fi)];
         if (c.remote) continue;
         const int64_t blocks = std::min<int64_t>((c.length + 255) / 256, 8192);
-        hipLaunchKernelGGL(preload_kernel, dim3(uint32_t(blocks)), dim3(256), 0, h->stream, h->d_cov, h->d_meta,
-                           h->d_touched, h->Gp, h->nb, c.site_off, c.length, depth, seed);
+        hipLaunchKernelGGL(preload_kernel, dim3(uint32_t(blocks)), dim3(256), 0, h->stream, SiteState{h->d_state, h->nb},
+                           h->d_touched, h->nb, c.site_off, c.length, depth, seed);
         unsigned long long *d_tot = h->d_stats;
         HIPCHK(hipMemsetAsync(d_tot, 0, sizeof(unsigned long long), h->stream));
-        hipLaunchKernelGGL(contig_total_kernel, dim3(1024), dim3(256), 0, h->stream, h->d_cov, h->Gp, h->nb,
+        hipLaunchKernelGGL(contig_total_kernel, dim3(1024), dim3(256), 0, h->stream, SiteState{h->d_state, h->nb}, h->nb,
                            c.site_off, c.length, d_tot);
         unsigned long long tot = 0;
         HIPCHK(hipMemcpyAsync(&tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, h->stream));

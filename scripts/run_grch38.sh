@@ -3,7 +3,7 @@
 # with its collectives forced on one rank (what every rank of an N-GPU run executes)
 mkdir -p gpurun_out/grch38
 i=0
-for env in "X=1" "BOSSX_FORCE_COLLECTIVES=1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29571"; do
+for env in "X=1" "BOSSX_FORCE_COLLECTIVES=1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29571" "BOSSX_TORCH_COLLECTIVES=1 BOSSX_FORCE_COLLECTIVES=1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29572"; do
   echo "== $env"
   env $env timeout 600 python bench.py --workload grch38 --steps 8 --warmup 3 > gpurun_out/grch38/out_$i.txt 2> gpurun_out/grch38/err_$i.txt
   python3 -c "
