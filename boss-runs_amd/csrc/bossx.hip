@@ -267,7 +267,7 @@ SweepParams sweep_params(bossx_engine *h) {
     P.score0 = h->score0; P.tiny = std::numeric_limits<double>::min();
     P.tile_done = h->d_tile_done; P.epoch = h->epoch;
     P.publish = h->sweep_published ? 1 : 0;
-    P.dense = 0; P.ingest_only = 0; P.ingest_first = 0;
+    P.dense = 0; P.ingest_only = 0; P.ingest_first = 0; P.tile_base = 0;
     P.order = h->d_tile_order;
     return P;
 }
@@ -1212,7 +1212,13 @@ int launch_sweep(bossx_engine *h) {
     // tile once more when the entropy array is kept — an untouched tile would otherwise hold the
     // entropy (and the SCORED bit) of its freshly zeroed sites back until it next receives a base.
     const bool dz_resweep = h->dz_fresh && h->d_entropy && !getenv("BOSSX_NO_DZ_RESWEEP");
-    const bool full = h->full_sweep_needed || h->touched_dirty || thr_changed || split || !want_inc || dz_resweep;
+    // A contig whose own threshold moved is swept whole; the others keep their untouched tiles (27 contigs
+    // cross int(mean / 8) at 27 different updates: a 150-kb scaffold must not cost a sweep of 3.1 Gb).
+    const bool full = h->full_sweep_needed || h->touched_dirty || split || !want_inc || dz_resweep;
+    std::vector<size_t> resweep;                 // local contigs swept whole although the update is incremental
+    if (!full)
+        for (size_t k = 0; k < thr.size(); ++k)
+            if (thr[k] != h->last_thr[k] && !h->contigs[size_t(h->filt[k])].remote) resweep.push_back(k);
     bool any_thr = false;
     for (int32_t t : thr) any_thr = any_thr || t >= 0;
     h->dz_fresh = any_thr && (h->full_sweep_needed || h->touched_dirty || thr_changed);
@@ -1237,6 +1243,7 @@ int launch_sweep(bossx_engine *h) {
         const double chain_ms = double(longest) * 4.4e-6;
         publish = sweep_ms >= 0.3 * chain_ms;
     }
+    if (!resweep.empty()) publish = false;       // (a chain next to the sweep is told about whole-reference or touched-tile sweeps only)
     {
         // one small launch installs the thresholds and marks the tiles.  The bin sums need no
         // clearing: every bin of a local contig is rewritten by every sweep of its tile, the others stay zero.
@@ -1268,8 +1275,17 @@ int launch_sweep(bossx_engine *h) {
     h->sweep_published = publish;                // tiles are published only if a chain will run next to this sweep
     SweepParams P = sweep_params(h);
     time_begin(h, BOSSX_K_SWEEP);
+    double resweep_sites = 0, resweep_bins = 0;
     if (!full) {
-        // only the tiles that receive bases: one block per (tile, barcode) group, the first group of a tile does the tile
+        // the contigs whose threshold moved, whole (the plain variant leaves the tiles that receive bases to the launch below) ...
+        for (size_t k : resweep) {
+            const ContigInfo &c = h->contigs[size_t(h->filt[k])];
+            P.tile_base = c.tile_off;
+            if (c.n_tiles) LAUNCH_SWEEP(false, dim3(uint32_t(c.n_tiles)), dim3(256), 0, h->stream, P);
+            resweep_sites += double(c.length); resweep_bins += double(c.T + 1);
+        }
+        P.tile_base = 0;
+        // ... and the tiles that receive bases: one block per (tile, barcode) group, the first group of a tile does the tile
         if (n_groups) LAUNCH_SWEEP(true, dim3(uint32_t(n_groups)), dim3(256), 0, h->stream, P);
     } else if (split) {
         P.ingest_only = 1;
@@ -1301,7 +1317,9 @@ int launch_sweep(bossx_engine *h) {
     double sites = 0;
     for (int32_t fi : h->filt) if (!h->contigs[size_t(fi)].remote) sites += double(h->contigs[size_t(fi)].length);
     double bins = double(h->B);
-    if (!full) { sites = double(n_touched) * kTileSites; bins = double(n_touched) * kTileBins; }   // incremental: the swept tiles only
+    if (!full) {       // incremental: the swept tiles only (tiles that are both in a re-swept contig and touched count once too many: an upper bound)
+        sites = double(n_touched) * kTileSites + resweep_sites; bins = double(n_touched) * kTileBins + resweep_bins;
+    }
     double bytes = sites * h->nb * 11.0 + bins * h->nb * 8.0;
     if (h->touched_dirty || split) bytes += sites;
     if (h->pending_slot >= 0) bytes += 3.0 * h->pending_emit;      // (the emit runs are read by expand_codes_kernel, not by the sweep)
