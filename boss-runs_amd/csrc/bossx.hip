@@ -67,6 +67,8 @@ struct bossx_engine {
     bool chain_flow_fits = true;    // its LDS (buffers + the ring for the current windows) fits a CU
     int chain_flow_bufs = 4;        // difference buffers it is launched with (5 when the LDS allows)
     int chain_flow_ce = 2;          // the chain wave stores the carry into every CE-th step, the tail waves rebuild the others (BOSSX_FLOW_CE=1: all of them)
+    bool chain_gc = true;           // carries leave the chain wave through global stores (benefit_chain_flow_kernel<..., GC>); BOSSX_CHAIN_GC=0: through LDS
+    double *d_carry_ring = nullptr; size_t carry_ring_cap = 0;
     int32_t nb = 1;
 
     // native multi-GPU driver (bossx_dist_init): RCCL communicator of this engine's device
@@ -411,6 +413,7 @@ void bossx_destroy(bossx_engine *h) {
     if (h->d_rs_sums) hipFree(h->d_rs_sums);
     if (h->d_tile_done) hipFree(h->d_tile_done);
     if (h->d_tile_order) hipFree(h->d_tile_order);
+    if (h->d_carry_ring) hipFree(h->d_carry_ring);
     if (h->d_tile_contig) hipFree(h->d_tile_contig);
     void *ptrs[] = {h->d_state, h->d_touched, h->d_strat, h->d_bucket_on, h->d_entropy, h->d_ds,
                     h->d_benefit, h->d_lut_score, h->d_lut_ent, h->d_fhat, h->d_bucket_sums, h->d_drop_count,
@@ -563,6 +566,8 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
     h->overlap_ok = getenv("BOSSX_NO_OVERLAP") == nullptr;
     h->chain_flow = getenv("BOSSX_CHAIN_BARRIER") == nullptr;
     if (const char *e = getenv("BOSSX_FLOW_CE")) h->chain_flow_ce = atoi(e) == 1 ? 1 : 2;
+    if (const char *e = getenv("BOSSX_CHAIN_GC")) h->chain_gc = atoi(e) != 0;
+    if (h->chain_flow_ce != 2) h->chain_gc = false;
     if ((rc = dev_alloc(h, &h->d_bucket_on, size_t(nb * h->NBK), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_bucket_sums, size_t(nb * h->NBK), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_drop_count, size_t(h->n_tiles), true))) return rc;
@@ -1411,12 +1416,17 @@ int fill_chain_params(bossx_engine *h, const int32_t *windows, const double *mul
     // (the barrier kernel ran two 128-bin blocks per CU when more blocks than CUs were launched; the
     // barrier-free one hands chunks over through LDS counters, whose latency 128-bin chunks do not amortise)
     // static LDS of the barrier-free kernel: NBD difference buffers, NBD-1 carry buffers, flags
-    auto flow_static = [](int nbd) { return size_t(nbd) * kChainRows * (256 + 2) * 8 + size_t(nbd - 1) * kChainRows * (256 / 4 + 2) * 8 + 2048; };
+    const bool gc = h->chain_gc;
+    auto flow_static = [gc](int nbd) {      // (with the carries in global memory the carry buffers leave the LDS)
+        return size_t(nbd) * kChainRows * (256 + 2) * 8 + (gc ? size_t(1) : size_t(nbd - 1)) * kChainRows * (256 / 4 + 2) * 8 + 2048;
+    };
     {
         int32_t r256 = 0; lds_need(256, r256);
         const size_t cap = size_t(160) * 1024;
-        // (five buffers measured the same as four at 111 Mb: four leave more room for the ring of long-read windows)
-        h->chain_flow_bufs = flow_static(5) + size_t(r256) * 8 <= cap && getenv("BOSSX_FLOW_BUFS5") ? 5 : 4;
+        // (five buffers measured the same as four at 111 Mb with LDS carries: four leave more room for the ring of
+        // long-read windows; with global carries the tails run a chunk further behind the chain wave: five when they fit)
+        const bool want5 = gc ? getenv("BOSSX_FLOW_BUFS4") == nullptr : getenv("BOSSX_FLOW_BUFS5") != nullptr;
+        h->chain_flow_bufs = flow_static(5) + size_t(r256) * 8 <= cap && want5 ? 5 : 4;
         h->chain_flow_fits = flow_static(4) + size_t(r256) * 8 <= cap;
     }
     const bool flow = h->matrix_chain && h->chain_flow && h->chain_flow_fits && !getenv("BOSSX_CHAIN_128");
@@ -1429,6 +1439,20 @@ int fill_chain_params(bossx_engine *h, const int32_t *windows, const double *mul
     P.never_ready = 0;
     P.zero_stats = nullptr; P.n_zero = 0;
     P.probe = getenv("BOSSX_CHAIN_PROBE") ? reinterpret_cast<long long *>(h->d_stats + kStatWords + 8) : nullptr;
+    P.carry_ring = nullptr;
+    if (h->chain_gc) {      // one ring per chain block
+        const size_t need = n_blocks * size_t(kCarryRing) * (256 / 4 / 2) * 64;
+        if (need > h->carry_ring_cap) {
+            HIPCHK(hipStreamSynchronize(h->stream));
+            if (h->stream2) HIPCHK(hipStreamSynchronize(h->stream2));
+            if (h->d_carry_ring) HIPCHK(hipFree(h->d_carry_ring));
+            h->d_carry_ring = nullptr; h->carry_ring_cap = 0;
+            int rc2 = dev_alloc(h, &h->d_carry_ring, need, true);
+            if (rc2) return rc2;
+            h->carry_ring_cap = need;
+        }
+        P.carry_ring = h->d_carry_ring;
+    }
     P.max_limit = std::min<int64_t>(h->B, h->n_sites_all / kWindow);
     lds = size_t(ring) * sizeof(double);
     return BOSSX_OK;
@@ -1456,7 +1480,10 @@ void launch_chain_flow_ce(bossx_engine *h, dim3 grid, dim3 block, size_t lds, hi
 }
 template <bool LIVE, int CH, int NBD>
 void launch_chain_flow(bossx_engine *h, int ce, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const ChainParams &P) {
-    if (ce == 1) launch_chain_flow_ce<LIVE, CH, NBD, 1>(h, grid, block, lds, stream, P);
+    if (P.carry_ring) {
+        grant_lds(h, reinterpret_cast<const void *>(benefit_chain_flow_kernel<LIVE, CH, NBD, 2, true>), lds);
+        hipLaunchKernelGGL((benefit_chain_flow_kernel<LIVE, CH, NBD, 2, true>), grid, block, lds, stream, P);
+    } else if (ce == 1) launch_chain_flow_ce<LIVE, CH, NBD, 1>(h, grid, block, lds, stream, P);
     else launch_chain_flow_ce<LIVE, CH, NBD, 2>(h, grid, block, lds, stream, P);
 }
 }  // extern "C++"
@@ -1468,7 +1495,7 @@ void launch_chain(bossx_engine *h, const ChainParams &P, size_t lds, hipStream_t
     const bool live = P.tile_done != nullptr;
     const int ch = h->chain_ch;
     const bool use_flow = h->matrix_chain && h->chain_flow && ch == 256 && h->chain_flow_fits;
-    const size_t fixed = use_flow ? size_t(h->chain_flow_bufs) * kChainRows * (256 + 2) * 8 + size_t(h->chain_flow_bufs - 1) * kChainRows * (256 / 4 + 2) * 8 + 2048
+    const size_t fixed = use_flow ? size_t(h->chain_flow_bufs) * kChainRows * (256 + 2) * 8 + (P.carry_ring ? size_t(1) : size_t(h->chain_flow_bufs - 1)) * kChainRows * (256 / 4 + 2) * 8 + 2048
                                   : 2 * 2 * size_t(kChainRows) * size_t(ch + 2) * 8;     // static tiles of this instantiation
     if (live && grid.x <= 8 && fixed + lds < size_t(140) * 1024) {
         // A few long chains next to a running sweep: ask for enough LDS that no sweep block fits on
