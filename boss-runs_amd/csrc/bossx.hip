@@ -67,7 +67,7 @@ struct bossx_engine {
     bool chain_flow_fits = true;    // its LDS (buffers + the ring for the current windows) fits a CU
     int chain_flow_bufs = 4;        // difference buffers it is launched with (5 when the LDS allows)
     int chain_flow_ce = 2;          // the chain wave stores the carry into every CE-th step, the tail waves rebuild the others (BOSSX_FLOW_CE=1: all of them)
-    bool chain_gc = true;           // carries leave the chain wave through global stores (benefit_chain_flow_kernel<..., GC>); BOSSX_CHAIN_GC=0: through LDS
+    bool chain_gc = false;          // BOSSX_CHAIN_GC=1: carries leave the chain wave through global stores (benefit_chain_flow_kernel<..., GC>) — measured slower (profiles/r03_chain_gc_experiment.txt), kept as an experiment
     double *d_carry_ring = nullptr; size_t carry_ring_cap = 0;
     int32_t nb = 1;
 

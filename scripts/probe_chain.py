@@ -6,7 +6,7 @@ from boss_runs_amd import synth
 from boss_runs_amd.config import BossConfig
 from boss_runs_amd.runs import BossRuns, MULT
 os.chdir(tempfile.mkdtemp())
-contigs = synth.make_reference([4_641_652], seed=1, names=["e"])
+contigs = synth.make_reference([int(os.environ.get("PROBE_L", "4641652"))], seed=1, names=["e"])
 a = BossConfig(); a.optional.bucket_threshold = 0
 r = BossRuns(a); r.write_masks = False
 r.init(contigs=[(n, synth.codes_to_str(c)) for n, c in contigs])
