@@ -250,13 +250,32 @@ class Runner:
         self.w, self.runs, self.nb, self.batches, self.dist = workload, runs, nb, batches, distributed
         self.eng = runs.engine
 
-    def step_e2e(self, b):
+    def ahead(self, nxt):
+        """`lookahead` argument naming batch `nxt` (None: none)."""
+        if nxt is None or os.environ.get("BOSSX_NO_LOOKAHEAD"):
+            return None
+        return (nxt["paf"], nxt["seqs"], nxt["barcodes"] if self.nb > 1 else None)
+
+    def step_e2e(self, b, nxt=None):
+        """One decision update, PAF text + read strings in host memory -> masks in host memory.  `nxt`: the
+        batch of the next step — parsed / uploaded / walked while the GPU runs this step's chain
+        (BossRuns.process_batch_paf(lookahead=...)); every step then still does one parse and one update."""
         bcs = b["barcodes"] if self.nb > 1 else None
         if self.dist:
-            self.runs.process_batch_paf(b["paf"], b["seqs"], barcodes=bcs, read_lengths=b["read_lengths_arr"])
+            self.runs.process_batch_paf(b["paf"], b["seqs"], barcodes=bcs, read_lengths=b["read_lengths_arr"], lookahead=self.ahead(nxt))
         else:
             self.runs.rl_dist.update(b["read_lengths_arr"])        # boss/core.py:106
-            self.runs.process_batch_paf(b["paf"], b["seqs"], barcodes=bcs)
+            self.runs.process_batch_paf(b["paf"], b["seqs"], barcodes=bcs, lookahead=self.ahead(nxt))
+
+    def run_e2e(self, sel, tail=None):
+        """The steps of `sel`, each staging its successor ahead (`tail` behind the last one)."""
+        for i, b in enumerate(sel):
+            self.step_e2e(b, sel[i + 1] if i + 1 < len(sel) else tail)
+
+    def prime(self, b):
+        """What the step before `b` would have done for it (untimed): stage it ahead."""
+        if self.ahead(b) is not None:
+            self.runs._stage_ahead(self.ahead(b))
 
     def stage(self, batches):
         """Parse + upload into numbered slots (untimed): inputs resident in HBM."""
@@ -342,7 +361,8 @@ def other_workload(name, device, batches, steps, warmup, track_entropy):
     eng.enable_timing(True)
     base = eng.kernel_stats()
     sel = batches[warmup:warmup + steps]
-    dt = timed(eng.synchronize, lambda: [R.step_e2e(b) for b in sel])
+    R.prime(sel[0])
+    dt = timed(eng.synchronize, lambda: R.run_e2e(sel, tail=batches[0]))
     kern = kernel_table(eng.kernel_stats(), base)
     summ, _ = R.stage(sel)
     dtr = timed(eng.synchronize, lambda: [R.step_resident(i, b, s) for i, (b, s) in enumerate(zip(sel, summ))])
@@ -439,7 +459,8 @@ def run_grch38(a, rank, world, local_rank, steps=None, warmup=None):
     eng.enable_timing(True)
     base = eng.kernel_stats()
     sel = batches[warmup:]
-    elapsed = timed(barrier, lambda: [R.step_e2e(b) for b in sel])
+    R.prime(sel[0])
+    elapsed = timed(barrier, lambda: R.run_e2e(sel, tail=batches[0]))
     kern = kernel_table(eng.kernel_stats(), base)
     eng.enable_timing(False)
     shard = torch.tensor([float(G_mine), float(n_reads), elapsed], dtype=torch.float64, device="cuda")
@@ -621,7 +642,8 @@ def main():
     eng.enable_timing(True)          # HIP events on the engine's own streams, collected after the region
     base = eng.kernel_stats()
     sel = batches[a.warmup:]
-    elapsed = timed(barrier, lambda: [R.step_e2e(b) for b in sel])
+    R.prime(sel[0])                  # (the step before the region stages the region's first batch, as every step in it does for its successor)
+    elapsed = timed(barrier, lambda: R.run_e2e(sel, tail=extra))
     stats = eng.kernel_stats()
     kern = kernel_table(stats, base)
     # ---- the same updates with the inputs already resident in HBM (parse + upload outside) --------
@@ -640,6 +662,10 @@ def main():
     # event overhead check: the resident loop once more without events
     elapsed_res_noev = timed(barrier, lambda: [R.step_resident(i, b, s) for i, (b, s) in enumerate(zip(sel, summ))])
     aligned = float(np.mean([s["aligned"] for s in summ]))
+    # ---- latency of a lone update: the same end-to-end step with nothing staged ahead (a live run whose
+    # next batch does not exist yet); the region's batches once more, events off
+    n_lat = min(len(sel), 10)
+    elapsed_lone = timed(barrier, lambda: [R.step_e2e(b) for b in sel[:n_lat]])
 
     if world > 1:
         t = torch.tensor([elapsed, elapsed_res], dtype=torch.float64, device="cuda")
@@ -681,6 +707,12 @@ def main():
                        "collectives_per_update": (runs.n_collectives / max(n_b + 2 * a.steps, 1)) if distributed else 0},
             "commit": commit,
             "timed_region_s": elapsed,
+            "lookahead": not os.environ.get("BOSSX_NO_LOOKAHEAD"),
+            "lone_update_ms": 1e3 * elapsed_lone / n_lat,
+            "lone_update_note": "the same step with nothing staged ahead (parse -> upload -> walk -> sweep -> chain -> masks, "
+                                "strictly one after the other): the latency of one update; ms_per_step is the steady state of "
+                                "back-to-back updates, where step i parses / uploads / walks batch i+1 (process_batch_paf(lookahead=...)) "
+                                "while the GPU runs the chain of batch i — one parse and one update per step either way",
             "kernels_only_ms": 1e3 * elapsed_res / a.steps,
             "kernels_only_note": "the same K updates with every batch already parsed and resident in HBM "
                                  "(ingest + sweep + buckets + chain + histogram + masks + D2H); "

@@ -40,6 +40,12 @@ struct bossx_engine {
     hipEvent_t ev_ups[kUpStreams] = {nullptr, nullptr, nullptr, nullptr};         // [0] = ev_up
     hipStream_t stream_txt = nullptr;  // the PAF text goes up on its own: the device walk needs nothing else
     hipEvent_t ev_txt = nullptr;
+    // Everything a batch being staged runs on the device (plan upload, CIGAR walk, code expansion) has a stream of
+    // its own: it touches the slot's buffers and the staging scratch only, never the site state, so the NEXT batch
+    // can be staged while the update of the current one (sweep, chain) is still running on `stream`.  The consumer
+    // (bossx_ingest_staged) makes `stream` wait for the slot's `ev_ready`.
+    hipStream_t stream_stage = nullptr;
+    int32_t busy_slot = -1;            // slot whose buffers work enqueued on `stream` may still read
     hipEvent_t ev_begin = nullptr, ev_chain = nullptr, ev_sweep = nullptr, ev_fhat = nullptr;
     double *h_fhat_pin = nullptr;      // page-locked staging of the compact f-hat
     double *d_rs_counts = nullptr; int64_t rs_windows = 0;     // read-start counts resident in HBM (bossx_fhat_reset / _add)
@@ -117,6 +123,7 @@ struct bossx_engine {
         uint8_t *d_codes = nullptr; size_t codes_cap = 0;          // per emitted base (expand_codes_kernel)
         TilePiece *d_pieces = nullptr; size_t pieces_cap = 0;      // per segment
         uint32_t n_segs = 0;
+        hipEvent_t ev_ready = nullptr;   // recorded on stream_stage behind the slot's last staging kernel
         ParsedBatch pb;
         bool valid = false;
         bool emit_tiles_built = false;
@@ -376,6 +383,7 @@ int bossx_create(const bossx_config *cfg, bossx_engine **out) {
         hipStreamCreateWithFlags(&h->stream_up, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&h->stream_txt, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->stream_stage, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_txt, hipEventDisableTiming) != hipSuccess) return BOSSX_E_HIP;
     h->stream_ups[0] = h->stream_up; h->ev_ups[0] = h->ev_up;
     for (int i = 1; i < bossx_engine::kUpStreams; ++i)
@@ -400,6 +408,7 @@ void bossx_destroy(bossx_engine *h) {
         if (h->ev_ups[i]) hipEventDestroy(h->ev_ups[i]);
     }
     if (h->stream_txt) { hipStreamSynchronize(h->stream_txt); hipStreamDestroy(h->stream_txt); }
+    if (h->stream_stage) { hipStreamSynchronize(h->stream_stage); hipStreamDestroy(h->stream_stage); }
     if (h->ev_txt) hipEventDestroy(h->ev_txt);
     if (h->ev_begin) hipEventDestroy(h->ev_begin);
     if (h->ev_chain) hipEventDestroy(h->ev_chain);
@@ -421,7 +430,7 @@ void bossx_destroy(bossx_engine *h) {
                     h->d_strat_off, h->d_bucket_off, h->d_drop_thr, h->d_local, h->d_limbs,
                     h->d_strat_bits};
     for (void *p : ptrs) if (p) hipFree(p);
-    for (auto &st : h->slots) { if (st.d_ops) hipFree(st.d_ops); if (st.d_tiles) hipFree(st.d_tiles); if (st.d_blob) hipFree(st.d_blob); if (st.d_segs) hipFree(st.d_segs); if (st.d_tilerefs) hipFree(st.d_tilerefs); if (st.d_codes) hipFree(st.d_codes); if (st.d_pieces) hipFree(st.d_pieces); }
+    for (auto &st : h->slots) { if (st.ev_ready) hipEventDestroy(st.ev_ready); if (st.d_ops) hipFree(st.d_ops); if (st.d_tiles) hipFree(st.d_tiles); if (st.d_blob) hipFree(st.d_blob); if (st.d_segs) hipFree(st.d_segs); if (st.d_tilerefs) hipFree(st.d_tilerefs); if (st.d_codes) hipFree(st.d_codes); if (st.d_pieces) hipFree(st.d_pieces); }
     if (h->d_tile_ref) hipFree(h->d_tile_ref);
     if (h->h_pin) hipHostFree(h->h_pin);
     if (h->h_paf_pin) hipHostFree(h->h_paf_pin);
@@ -762,12 +771,12 @@ int stage_host_walk(bossx_engine *h, bossx_engine::Staged &st, ParseInput in, bo
     if ((rc = grow_dev(h, &st.d_segs, &st.segs_cap, pb.segs.size(), 64))) return rc;
     if ((rc = grow_dev(h, &st.d_tilerefs, &st.tilerefs_cap, pb.tiles.size(), 64))) return rc;
     if (pb.n_ops) {
-        HIPCHK(hipMemcpyAsync(st.d_segs, pb.segs.data(), pb.segs.size() * sizeof(TileSeg), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(st.d_tilerefs, pb.tiles.data(), pb.tiles.size() * sizeof(TileRef), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(st.d_segs, pb.segs.data(), pb.segs.size() * sizeof(TileSeg), hipMemcpyHostToDevice, h->stream_stage));
+        HIPCHK(hipMemcpyAsync(st.d_tilerefs, pb.tiles.data(), pb.tiles.size() * sizeof(TileRef), hipMemcpyHostToDevice, h->stream_stage));
         for (const OpsChunk &ck : pb.chunks)
-            HIPCHK(hipMemcpyAsync(st.d_ops + ck.dev_off, ck.host, ck.n * sizeof(EmitOp), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(st.d_ops + ck.dev_off, ck.host, ck.n * sizeof(EmitOp), hipMemcpyHostToDevice, h->stream_stage));
     }
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream_stage));
     return BOSSX_OK;
 }
 
@@ -825,8 +834,10 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
     const bool timing = getenv("BOSSX_STAGE_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     int rc;
-    // the previous batch's uploads / an ingest kernel may still read the staging buffers
-    HIPCHK(hipStreamSynchronize(h->stream));
+    // the previous batch's uploads and walk may still use the staging scratch; a sweep enqueued on the main
+    // stream may still read THIS slot's buffers (not when the caller stages ahead into another slot)
+    HIPCHK(hipStreamSynchronize(h->stream_stage));
+    if (h->busy_slot == h->slot) { HIPCHK(hipStreamSynchronize(h->stream)); h->busy_slot = -1; }
     const size_t blob_bytes = n_reads > 0 ? size_t(seq_off[n_reads]) : 0;
     if (blob_bytes >= (size_t(1) << 32)) return fail(h, BOSSX_E_RANGE, "read blob larger than 4 GiB");
     if (paf_len >= (size_t(1) << 32)) return fail(h, BOSSX_E_RANGE, "PAF text larger than 4 GiB");
@@ -846,7 +857,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
             if (ok) return;
             hipStreamSynchronize(h->stream_txt);
             for (int i = 0; i < bossx_engine::kUpStreams; ++i) hipStreamSynchronize(h->stream_ups[i]);
-            hipStreamSynchronize(h->stream);
+            hipStreamSynchronize(h->stream_stage);
         }
     } upload_guard{h};
     // slack: the ingest prologue reads a 384-byte window that may start at the last base
@@ -907,14 +918,14 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
     bool reads_awaited = false;
     auto await_reads = [&]() {
         if (reads_awaited || up_err != hipSuccess) return;
-        for (int i = 0; i < bossx_engine::kUpStreams && up_err == hipSuccess; ++i) up_err = hipStreamWaitEvent(h->stream, h->ev_ups[i], 0);
+        for (int i = 0; i < bossx_engine::kUpStreams && up_err == hipSuccess; ++i) up_err = hipStreamWaitEvent(h->stream_stage, h->ev_ups[i], 0);
         reads_awaited = true;
     };
     const bool defer_reads = seq_ptrs != nullptr && !host_walk && !getenv("BOSSX_NO_DEFER_READS");
     in.after_pass1 = [&]() {      // everything staged on the upload streams precedes what follows on the main one
         if (up_fail.load()) { up_err = hipErrorUnknown; return; }
         up_err = hipEventRecord(h->ev_txt, h->stream_txt);
-        if (up_err == hipSuccess) up_err = hipStreamWaitEvent(h->stream, h->ev_txt, 0);
+        if (up_err == hipSuccess) up_err = hipStreamWaitEvent(h->stream_stage, h->ev_txt, 0);
         for (int i = 0; i < bossx_engine::kUpStreams && up_err == hipSuccess; ++i) up_err = hipEventRecord(h->ev_ups[i], h->stream_ups[i]);
         if (!defer_reads || any_dirty.load()) await_reads();
     };
@@ -947,7 +958,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                 while (txt_done.load(std::memory_order_acquire) < n_c) _mm_pause();     // the text slices have been handed to the DMA engine
                 if (up_fail.load()) return fail(h, BOSSX_E_HIP, "upload of the PAF text failed");
                 HIPCHK(hipEventRecord(h->ev_txt, h->stream_txt));
-                HIPCHK(hipStreamWaitEvent(h->stream, h->ev_txt, 0));
+                HIPCHK(hipStreamWaitEvent(h->stream_stage, h->ev_txt, 0));
                 if ((rc2 = grow_dev(h, &st.d_ops, &st.ops_cap, pbe.ops_cap, 1024))) return rc2;
                 if ((rc2 = grow_dev(h, &st.d_segs, &st.segs_cap, pbe.segs_cap, 64))) return rc2;
                 if ((rc2 = grow_dev(h, &st.d_tilerefs, &st.tilerefs_cap, size_t(n_groups), 64))) return rc2;
@@ -960,9 +971,9 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                 if ((rc2 = grow_pin(h, &h->h_plan_pin, &h->plan_pin_cap, plan_bytes + group_bytes + size_t(n_plans) * 4 + 64))) return rc2;
                 memcpy(h->h_plan_pin, pbe.plans.data(), plan_bytes);
                 memcpy(h->h_plan_pin + plan_bytes, pbe.tiles.data(), group_bytes);
-                HIPCHK(hipMemcpyAsync(h->d_plans, h->h_plan_pin, plan_bytes, hipMemcpyHostToDevice, h->stream));
-                HIPCHK(hipMemcpyAsync(st.d_tilerefs, h->h_plan_pin + plan_bytes, group_bytes, hipMemcpyHostToDevice, h->stream));
-                HIPCHK(hipMemsetAsync(h->d_walk, 0, n_walk * sizeof(uint32_t), h->stream));
+                HIPCHK(hipMemcpyAsync(h->d_plans, h->h_plan_pin, plan_bytes, hipMemcpyHostToDevice, h->stream_stage));
+                HIPCHK(hipMemcpyAsync(st.d_tilerefs, h->h_plan_pin + plan_bytes, group_bytes, hipMemcpyHostToDevice, h->stream_stage));
+                HIPCHK(hipMemsetAsync(h->d_walk, 0, n_walk * sizeof(uint32_t), h->stream_stage));
                 W.plans = h->d_plans; W.n_plans = n_plans; W.paf = h->d_paf; W.blob = st.d_blob;
                 W.n_runs = h->d_walk; W.walk_err = W.n_runs + n_plans; W.ops_off = W.walk_err + n_plans;
                 W.group_count = W.ops_off + n_plans + 1; W.group_cursor = W.group_count + n_groups;
@@ -970,12 +981,12 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                 W.ops = st.d_ops; W.groups = st.d_tilerefs; W.n_groups = n_groups; W.segs = st.d_segs;
                 W.emit_tile_op = st.d_tiles; W.lane_scan = h->d_lane_scan; W.nb = h->nb;
                 const dim3 grid((n_plans + 3) / 4), block(256);
-                hipLaunchKernelGGL(cigar_walk_kernel<false>, grid, block, 0, h->stream, W);
-                hipLaunchKernelGGL(walk_scan_kernel, dim3(1), dim3(1024), 0, h->stream, W);
-                hipLaunchKernelGGL(cigar_walk_kernel<true>, grid, block, 0, h->stream, W);
+                hipLaunchKernelGGL(cigar_walk_kernel<false>, grid, block, 0, h->stream_stage, W);
+                hipLaunchKernelGGL(walk_scan_kernel, dim3(1), dim3(1024), 0, h->stream_stage, W);
+                hipLaunchKernelGGL(cigar_walk_kernel<true>, grid, block, 0, h->stream_stage, W);
                 HIPCHK(hipGetLastError());
                 back = reinterpret_cast<uint32_t *>(h->h_plan_pin + plan_bytes + group_bytes);
-                HIPCHK(hipMemcpyAsync(back, W.totals, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipMemcpyAsync(back, W.totals, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream_stage));
                 return BOSSX_OK;
             };
             early_rc = go();
@@ -994,14 +1005,14 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                 // some read holds a byte other than A/C/G/T: look at the bases of its aligned runs, now that the
                 // reads are on their way (the plans go up again, with their flags)
                 await_reads(); HIPCHK(up_err);
-                HIPCHK(hipStreamSynchronize(h->stream));              // the first copy of the plans has left the staging buffer
+                HIPCHK(hipStreamSynchronize(h->stream_stage));              // the first copy of the plans has left the staging buffer
                 memcpy(h->h_plan_pin, pb.plans.data(), plan_bytes);
-                HIPCHK(hipMemcpyAsync(h->d_plans, h->h_plan_pin, plan_bytes, hipMemcpyHostToDevice, h->stream));
-                hipLaunchKernelGGL(check_bases_kernel, dim3((n_plans + 3) / 4), dim3(256), 0, h->stream, W);
+                HIPCHK(hipMemcpyAsync(h->d_plans, h->h_plan_pin, plan_bytes, hipMemcpyHostToDevice, h->stream_stage));
+                hipLaunchKernelGGL(check_bases_kernel, dim3((n_plans + 3) / 4), dim3(256), 0, h->stream_stage, W);
                 HIPCHK(hipGetLastError());
-                HIPCHK(hipMemcpyAsync(back, W.totals, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipMemcpyAsync(back, W.totals, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream_stage));
             }
-            HIPCHK(hipStreamSynchronize(h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream_stage));
             memcpy(totals, back, sizeof(totals));
             await_reads(); HIPCHK(up_err);                 // (ordered before the kernels that read the bases)
             if (totals[2]) {
@@ -1010,7 +1021,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
             }
         } else {
             await_reads(); HIPCHK(up_err);
-            HIPCHK(hipStreamSynchronize(h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream_stage));
         }
         // ---- failures: the first ValueError / KeyError class one in record order; the IndexError
         // class (raised later in the reference, inside _effect_increments) only if nothing else failed
@@ -1062,14 +1073,16 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
         X.code_blocks = (X.total_emit + uint32_t(kExpandTile) - 1u) / uint32_t(kExpandTile);
         if (host_walk) {        // (the device walk's second pass wrote the tile -> run table itself)
             if ((rc = grow_dev(h, &st.d_tiles, &st.tiles_cap, size_t(X.code_blocks) + 2, 64))) return rc;
-            hipLaunchKernelGGL(emit_tiles_kernel, dim3(X.code_blocks / 256 + 1), dim3(256), 0, h->stream, st.d_ops, X.n_ops, X.code_blocks, st.d_tiles);
+            hipLaunchKernelGGL(emit_tiles_kernel, dim3(X.code_blocks / 256 + 1), dim3(256), 0, h->stream_stage, st.d_ops, X.n_ops, X.code_blocks, st.d_tiles);
         }
         X.tile_op = st.d_tiles;
-        hipLaunchKernelGGL(expand_codes_kernel, dim3(X.code_blocks + (X.n_segs + 255u) / 256u), dim3(256), 0, h->stream, X);
+        hipLaunchKernelGGL(expand_codes_kernel, dim3(X.code_blocks + (X.n_segs + 255u) / 256u), dim3(256), 0, h->stream_stage, X);
         HIPCHK(hipGetLastError());
     }
     if (n_rec) *n_rec = pb.n_rec;
     if (aligned_bases) *aligned_bases = int64_t(pb.total_emit);
+    if (!st.ev_ready) HIPCHK(hipEventCreateWithFlags(&st.ev_ready, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(st.ev_ready, h->stream_stage));
     st.pb = std::move(pb);
     st.valid = true;
     upload_guard.ok = true;
@@ -1107,7 +1120,7 @@ int bossx_stage_batch_ptrs(bossx_engine *h, const char *paf, size_t paf_len, con
     // the sequences are gathered into pinned memory inside stage_core's parallel region: one pass,
     // and the H2D copy runs at full PCIe rate
     const size_t blob_bytes = size_t(seq_off[size_t(n_reads)]);
-    HIPCHK(hipStreamSynchronize(h->stream));           // the pinned buffer may still feed a copy
+    HIPCHK(hipStreamSynchronize(h->stream_stage));     // the pinned buffer may still feed a copy (its uploads are ordered before the stage stream's last kernel)
     if (blob_bytes + 64 > h->blob_pin_cap) {
         if (h->h_blob_pin) HIPCHK(hipHostFree(h->h_blob_pin));
         h->h_blob_pin = nullptr; h->blob_pin_cap = 0;
@@ -1154,6 +1167,8 @@ int bossx_ingest_staged(bossx_engine *h) {
     const ParsedBatch &pb = st.pb;
     for (size_t i = 0; i < h->contigs.size(); ++i) h->contigs[i].cov_total += pb.emitted_per_contig[i];
     if (pb.total_emit == 0) return BOSSX_OK;
+    if (st.ev_ready) HIPCHK(hipStreamWaitEvent(h->stream, st.ev_ready, 0));     // staged on stream_stage, consumed on the main stream
+    h->busy_slot = h->slot;
     // the increments are applied by the next sweep, tile by tile (site_sweep_kernel prologue);
     // its prep launch marks the touched tiles
     h->pending_slot = h->slot;

@@ -235,11 +235,12 @@ class DistributedBossRuns(BossRuns):
         and read-start summaries are all-gathered so every rank holds the global
         distributions.  Replicated reads (`sharded_reads=False`): every rank passes the whole
         batch and no exchange is needed."""
-        summ = self.engine.ingest_paf(paf_text, new_reads, barcodes=barcodes, min_len=min_len)
+        summ = self._ingest_batch(paf_text, new_reads, barcodes, min_len)
         if read_lengths is None:
             read_lengths = np.array([len(s) for s in new_reads.values()], dtype=np.int64)
         self.begin_update()
-        self.account_batch(summ, read_lengths, len(new_reads))
+        self.account_batch(summ, read_lengths, len(new_reads))      # (launches the chain once the global read lengths are known)
+        self._stage_ahead(kw.get("lookahead"))       # the next batch, staged while this one's chain runs (runs.py)
         self.update_wrapper()
 
     def account_batch(self, summ, read_lengths, n_reads):

@@ -203,15 +203,62 @@ class BossRuns(Boss):
         self.process_batch_paf(paf_text, new_reads, min_len=min_len)
 
     def process_batch_paf(self, paf_text, new_reads, barcodes=None, min_len=200, starts_filter=None,
-                          n_reads_total=None) -> None:
+                          n_reads_total=None, lookahead=None) -> None:
         """convert_records + _effect_increments + tracker + count_read_starts + update_wrapper
-        (core.py:214-224).  `barcodes`: {read id: barcode index} as in simulation.py:148."""
-        summ = self.engine.ingest_paf(paf_text, new_reads, barcodes=barcodes, min_len=min_len)
+        (core.py:214-224).  `barcodes`: {read id: barcode index} as in simulation.py:148.
+
+        `lookahead`: the NEXT batch, if the caller already holds it (a replay, `process_batch_sim`,
+        a mapper that runs ahead) — `(paf_text, new_reads[, barcodes[, min_len]])` or a dict with those
+        keys.  It is parsed, uploaded and walked (Engine.stage_batch, into the other slot, on the
+        engine's staging stream) while the GPU runs this batch's sweep and chain; nothing of it
+        touches the site state before the call that processes it — passing the same objects as
+        `paf_text` / `new_reads` then — and results are bit-identical with and without.  A batch the
+        reference would reject raises when IT is processed, not while it is staged ahead."""
+        summ = self._ingest_batch(paf_text, new_reads, barcodes, min_len)
         if self._fused:       # the GPU sweeps / runs the chain while the host does its bookkeeping
             self.engine.update_begin(self.args.optional.bucket_threshold)
             self.launch_benefit()
+        self._stage_ahead(lookahead)
         self._account_reads(summ, len(new_reads) if n_reads_total is None else n_reads_total, starts_filter)
         self.update_wrapper()
+
+    _ahead = None        # the batch staged ahead by the previous call (dict), or None
+    _cur_slot = 0        # engine slot of the batch being processed
+
+    def _ingest_batch(self, paf_text, new_reads, barcodes, min_len):
+        """This batch's increments become pending (Engine.ingest_paf) — taken from the slot it was
+        staged ahead into when the previous call's `lookahead` named exactly these objects."""
+        a, self._ahead = self._ahead, None
+        eng = self.engine
+        if a is not None and a["paf_text"] is paf_text and a["new_reads"] is new_reads and \
+                a["barcodes"] is barcodes and a["min_len"] == min_len:
+            if a["error"] is not None:
+                raise a["error"]
+            eng.ingest_staged(slot=a["slot"])
+            self._cur_slot = a["slot"]
+            return a["summ"]
+        return eng.ingest_paf(paf_text, new_reads, barcodes=barcodes, min_len=min_len)
+
+    def _stage_ahead(self, lookahead) -> None:
+        if lookahead is None or not hasattr(self.engine, "select_batch"):
+            return
+        if isinstance(lookahead, dict):
+            a = dict(paf_text=lookahead["paf_text"], new_reads=lookahead["new_reads"],
+                     barcodes=lookahead.get("barcodes"), min_len=lookahead.get("min_len", 200))
+        else:
+            t = tuple(lookahead)
+            a = dict(paf_text=t[0], new_reads=t[1], barcodes=t[2] if len(t) > 2 else None,
+                     min_len=t[3] if len(t) > 3 else 200)
+        a.update(slot=1 - self._cur_slot, summ=None, error=None)
+        eng = self.engine
+        try:
+            eng.select_batch(a["slot"])
+            a["summ"] = eng.stage_batch(a["paf_text"], a["new_reads"], barcodes=a["barcodes"], min_len=a["min_len"])
+        except (ValueError, KeyError, IndexError, TypeError, AssertionError) as e:     # the reference's rejects
+            a["error"] = e
+        finally:
+            eng.select_batch(self._cur_slot)
+        self._ahead = a
 
     def _account_reads(self, summ, n_reads, starts_filter=None):
         # AbundanceTracker.update (abundance_tracker.py:58-69)

@@ -1187,3 +1187,74 @@ def test_device_front_end_error_classes_equal_the_reference():
         eng.close()
     assert not bad, bad
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb,ploidy", [(1, 2), (3, 1)])
+def test_lookahead_staging_vs_oracle(in_tmp, nb, ploidy):
+    """process_batch_paf(lookahead=next batch): the next batch is parsed, uploaded and walked on the
+    engine's staging stream while this batch's sweep and chain run.  Every update must still equal the
+    oracle bit for bit; a batch staged ahead but never processed leaves no trace; a batch the reference
+    rejects raises its exception class when IT is processed, not while it is staged ahead, and the
+    update during which it was staged completes."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.runs import BossRuns
+    from oracle.pipeline import OracleRuns
+    lens = [260_000, 141_000, 90_500]
+    names = ["la0", "la1", "la2"]
+    contigs = synth.make_reference(lens, seed=77, names=names)
+    strs = [(n, synth.codes_to_str(c)) for n, c in contigs]
+    args = BossConfig()
+    args.general.name = "la%d" % nb
+    args.optional.ploidy = ploidy
+    if nb > 1:
+        args.general.barcodes = ["barcode%02d" % (i + 1) for i in range(nb)]
+    runs = BossRuns(args)
+    runs.init(contigs=strs)
+    o = OracleRuns(strs, ploidy=ploidy, nbarcodes=nb)
+    batches = [synth.make_batch(contigs, 700 + 90 * b, seed=7700 + b, mean_len=3000.0, nbarcodes=nb) for b in range(7)]
+    bad = dict(batches[5])
+    bad["paf"] = bad["paf"].replace("\tcg:Z:", "\tcg:Q:", 1)          # unknown tag type: KeyError in the reference (paf.py:107)
+    stray = batches[6]                                                  # staged ahead after batch 1, never processed
+
+    def check(b):
+        assert runs.threshold == o.threshold, b
+        for n, oc in o.contigs.items():
+            pc = runs.contigs[n]
+            assert np.array_equal(pc.coverage, oc.coverage), (b, n)
+            assert np.array_equal(pc.scores, oc.scores), (b, n)
+            assert np.array_equal(pc.entropy, oc.entropy), (b, n)
+            assert np.array_equal(pc.bucket_switches, oc.bucket_switches), (b, n)
+            assert np.array_equal(pc.strat, oc.strat), (b, n)
+            if o.threshold is not None:
+                assert np.array_equal(pc.additional_benefit, oc.additional_benefit), (b, n)
+
+    def ahead(x):
+        return None if x is None else (x["paf"], x["seqs"], x["barcodes"] if nb > 1 else None)
+
+    # order of processing: 0 1 2 3 4 [bad: raises] 4-again?  no — 0 1 (stray staged) 2 3 4 (bad staged) bad
+    plan = [(batches[0], batches[1]), (batches[1], stray), (batches[2], batches[3]), (batches[3], batches[4]),
+            (batches[4], bad)]
+    for b, (cur, nxt) in enumerate(plan):
+        bcs = cur["barcodes"] if nb > 1 else None
+        o.process_batch(cur["paf"], cur["seqs"], read_lengths=cur["read_lengths"], barcodes=bcs)
+        runs.rl_dist.update(cur["read_lengths"])
+        runs.process_batch_paf(cur["paf"], cur["seqs"], barcodes=bcs, lookahead=ahead(nxt))
+        staged = runs._ahead
+        assert staged is not None and staged["paf_text"] is nxt["paf"]
+        if nxt is bad:
+            assert isinstance(staged["error"], KeyError)             # held back ...
+        else:
+            assert staged["error"] is None and staged["summ"] is not None
+        check(b)
+    with pytest.raises(KeyError):                                      # ... until the batch itself is processed
+        runs.process_batch_paf(bad["paf"], bad["seqs"], barcodes=bad["barcodes"] if nb > 1 else None)
+    check("after the reject")                                          # nothing of it was applied
+    # and the engine goes on: one more update, staged ahead by nobody
+    cur = batches[5]
+    bcs = cur["barcodes"] if nb > 1 else None
+    o.process_batch(cur["paf"], cur["seqs"], read_lengths=cur["read_lengths"], barcodes=bcs)
+    runs.rl_dist.update(cur["read_lengths"])
+    runs.process_batch_paf(cur["paf"], cur["seqs"], barcodes=bcs)
+    check("last")
