@@ -75,6 +75,11 @@ struct bossx_engine {
     int chain_flow_ce = 2;          // the chain wave stores the carry into every CE-th step, the tail waves rebuild the others (BOSSX_FLOW_CE=1: all of them)
     bool chain_gc = false;          // BOSSX_CHAIN_GC=1: carries leave the chain wave through global stores (benefit_chain_flow_kernel<..., GC>) — measured slower (profiles/r03_chain_gc_experiment.txt), kept as an experiment
     double *d_carry_ring = nullptr; size_t carry_ring_cap = 0;
+    // move_sum as an exact parallel scan (movesum_scan_kernel + benefit_combine_kernel): the default chain;
+    // BOSSX_CHAIN_SCAN=0 keeps the serial matrix-core chain.  Scratch: the eleven sums of every (barcode, strand, bin).
+    bool chain_scan = true;
+    double *d_scan_S = nullptr;
+    unsigned long long *d_scan_stats = nullptr;   // stretches | stretches ended early | plain-path rounds (BOSSX_CHAIN_PROBE)
     int32_t nb = 1;
 
     // native multi-GPU driver (bossx_dist_init): RCCL communicator of this engine's device
@@ -399,6 +404,11 @@ void bossx_destroy(bossx_engine *h) {
     if (!h) return;
     hipSetDevice(h->cfg.device);
     hipStreamSynchronize(h->stream);
+    if (h->d_scan_stats && getenv("BOSSX_SCAN_STATS")) {
+        unsigned long long st[4] = {0, 0, 0, 0};
+        if (hipMemcpy(st, h->d_scan_stats, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "[bossx] scan chain: %llu stretches, %llu ended early, %llu plain-path rounds\n", st[0], st[1], st[2]);
+    }
     if (h->comm) { rccl_destroy(h->comm); h->comm = nullptr; }
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
     if (h->stream_up) { hipStreamSynchronize(h->stream_up); hipStreamDestroy(h->stream_up); }
@@ -423,6 +433,8 @@ void bossx_destroy(bossx_engine *h) {
     if (h->d_tile_done) hipFree(h->d_tile_done);
     if (h->d_tile_order) hipFree(h->d_tile_order);
     if (h->d_carry_ring) hipFree(h->d_carry_ring);
+    if (h->d_scan_S) hipFree(h->d_scan_S);
+    if (h->d_scan_stats) hipFree(h->d_scan_stats);
     if (h->d_tile_contig) hipFree(h->d_tile_contig);
     void *ptrs[] = {h->d_state, h->d_touched, h->d_strat, h->d_bucket_on, h->d_entropy, h->d_ds,
                     h->d_benefit, h->d_lut_score, h->d_lut_ent, h->d_fhat, h->d_bucket_sums, h->d_drop_count,
@@ -576,6 +588,14 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
     h->chain_flow = getenv("BOSSX_CHAIN_BARRIER") == nullptr;
     if (const char *e = getenv("BOSSX_FLOW_CE")) h->chain_flow_ce = atoi(e) == 1 ? 1 : 2;
     if (const char *e = getenv("BOSSX_CHAIN_GC")) h->chain_gc = atoi(e) != 0;
+    if (const char *e = getenv("BOSSX_CHAIN_SCAN")) h->chain_scan = atoi(e) != 0;
+    if (h->chain_scan) {
+        // (an allocation failure keeps the serial chain: 176 bytes per bin and barcode)
+        if (hipMalloc(reinterpret_cast<void **>(&h->d_scan_S), size_t(nb) * 2 * BOSSX_NWIN * size_t(h->B) * sizeof(double) + 64) != hipSuccess) {
+            (void)hipGetLastError();
+            h->d_scan_S = nullptr; h->chain_scan = false;
+        } else if ((rc = dev_alloc(h, &h->d_scan_stats, 4, true))) return rc;
+    }
     if (h->chain_flow_ce != 2) h->chain_gc = false;
     if ((rc = dev_alloc(h, &h->d_bucket_on, size_t(nb * h->NBK), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_bucket_sums, size_t(nb * h->NBK), true))) return rc;
@@ -1519,6 +1539,17 @@ void launch_chain(bossx_engine *h, const ChainParams &P, size_t lds, hipStream_t
         lds = size_t(140) * 1024 - fixed;
     }
     h->last_chain_live = live;
+    if (h->chain_scan && !live) {
+        // one block per (contig, barcode, strand, window); then one thread per (barcode, strand, bin)
+        const dim3 sgrid(uint32_t(h->filt.size() * size_t(h->nb) * 2 * BOSSX_NWIN));
+        hipLaunchKernelGGL((movesum_scan_kernel<kScanThreads, kScanG>), sgrid, dim3(kScanThreads), 0, stream, P, h->d_scan_S,
+                           (P.probe || getenv("BOSSX_SCAN_STATS")) ? h->d_scan_stats : nullptr);
+        hipLaunchKernelGGL(benefit_combine_kernel, dim3(uint32_t((h->B + 255) / 256), uint32_t(h->nb * 2)), dim3(256), 0, stream, P, h->d_scan_S);
+        // algorithmic bytes: per bin, barcode and strand the bin sum twice per window (a[j], a[j - w]), the
+        // eleven sums written and read again, the benefit written
+        time_end(h, BOSSX_K_BENEFIT, double(h->B) * h->nb * 2 * (BOSSX_NWIN * 4 * 8.0 + 8.0), stream);
+        return;
+    }
     if (h->matrix_chain && h->chain_flow && ch == 256 && h->chain_flow_fits) {
         // as many buffers between the stages as the LDS holds next to the ring of the current windows
         const int ce = h->chain_flow_ce;

@@ -655,6 +655,20 @@ def test_resident_fhat_and_chain_kernels_agree(in_tmp):
     r_dev.engine.close(); r_host.engine.close()
 
 
+def test_scan_chain_equals_serial_chain(in_tmp):
+    """move_sum as the exact parallel scan (movesum_scan_kernel, the default) against the serial
+    matrix-core recurrence (BOSSX_CHAIN_SCAN=0): benefits, thresholds and masks bit for bit in every
+    update (both are compared with the oracle's sequential move_sum elsewhere)."""
+    scan, r0 = _run_updates(in_tmp, "ch_scan", 6)
+    serial, r1 = _run_updates(in_tmp, "ch_serial", 6, env={"BOSSX_CHAIN_SCAN": "0"})
+    assert scan[-1][0] is not None
+    for k, (a, b) in enumerate(zip(scan, serial)):
+        assert a[0] == b[0], k
+        for x, y in zip(a[1] + a[3], b[1] + b[3]):
+            assert np.array_equal(x, y), k
+    r0.engine.close(); r1.engine.close()
+
+
 def test_chain_next_to_sweep_equals_serial(in_tmp):
     """Once the strategy is on, the benefit chain runs on a second stream NEXT TO the sweep of the
     same update (tile flags, agent-scope stores/loads).  Every update must be bit-identical to the
