@@ -75,9 +75,20 @@ struct bossx_engine {
     int chain_flow_ce = 2;          // the chain wave stores the carry into every CE-th step, the tail waves rebuild the others (BOSSX_FLOW_CE=1: all of them)
     bool chain_gc = false;          // BOSSX_CHAIN_GC=1: carries leave the chain wave through global stores (benefit_chain_flow_kernel<..., GC>) — measured slower (profiles/r03_chain_gc_experiment.txt), kept as an experiment
     double *d_carry_ring = nullptr; size_t carry_ring_cap = 0;
-    // move_sum as an exact parallel scan (movesum_scan_kernel + benefit_combine_kernel): the default chain;
-    // BOSSX_CHAIN_SCAN=0 keeps the serial matrix-core chain.  Scratch: the eleven sums of every (barcode, strand, bin).
-    bool chain_scan = true;
+    // move_sum as an exact parallel scan inside two-binade bands (movesum_scan_kernel + benefit_combine_kernel):
+    // BOSSX_CHAIN_SCAN=1.  Exact, but real bin sums leave a band every 8-500 bins (profiles/r03_chain_parallel.txt):
+    // an experiment, not the default.  Scratch: the eleven sums of every (barcode, strand, bin).
+    bool chain_scan = false;
+    // The serial recurrence chunk-parallel (chain_candidates_kernel -> chain_stitch_kernel -> benefit_chain_kernel<SEG>): the
+    // default where the caller checks ctrl->err & 4 and can rerun (bossx_update); BOSSX_CHAIN_SPEC=0 keeps the serial chain.
+    bool chain_spec = true;
+    bool last_chain_spec = false;      // the last chain launch was the chunk-parallel one
+    int32_t spec_mismatches = 0;       // segments whose end value differed from the stitched one (each costs a serial rerun); 3: off
+    int32_t spec_pause = 0;            // updates left on the serial chain: too many chunks had to be added the plain way last time
+    int64_t spec_plain_total = 0, spec_paused_updates = 0;
+    int64_t *d_chunk_off = nullptr; int64_t spec_total = 0, spec_max_segs = 0;
+    double *d_spec_tab = nullptr, *d_spec_starts = nullptr;
+    unsigned long long *d_spec_stats = nullptr;
     double *d_scan_S = nullptr;
     unsigned long long *d_scan_stats = nullptr;   // stretches | stretches ended early | plain-path rounds (BOSSX_CHAIN_PROBE)
     int32_t nb = 1;
@@ -433,6 +444,16 @@ void bossx_destroy(bossx_engine *h) {
     if (h->d_tile_done) hipFree(h->d_tile_done);
     if (h->d_tile_order) hipFree(h->d_tile_order);
     if (h->d_carry_ring) hipFree(h->d_carry_ring);
+    if (h->d_spec_stats && getenv("BOSSX_SPEC_STATS")) {
+        unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpy(st, h->d_spec_stats, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "[bossx] chunk-parallel chain: %llu (window, chunk) tables, %llu plain, %llu identity, %.1f candidates each; %llu chunks added plainly by the stitch; %lld updates on the serial chain meanwhile; %d mismatches (plain because: climbs more than 4 binades %llu, at most %llu; start not a normal positive number %llu)\n",
+                    st[0], st[1], st[2], st[0] > st[1] + st[2] ? double(st[3]) / double(st[0] - st[1] - st[2]) : 0.0, st[4], (long long)h->spec_paused_updates, h->spec_mismatches, st[5], st[7], st[6]);
+    }
+    if (h->d_chunk_off) hipFree(h->d_chunk_off);
+    if (h->d_spec_tab) hipFree(h->d_spec_tab);
+    if (h->d_spec_starts) hipFree(h->d_spec_starts);
+    if (h->d_spec_stats) hipFree(h->d_spec_stats);
     if (h->d_scan_S) hipFree(h->d_scan_S);
     if (h->d_scan_stats) hipFree(h->d_scan_stats);
     if (h->d_tile_contig) hipFree(h->d_tile_contig);
@@ -589,6 +610,25 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
     if (const char *e = getenv("BOSSX_FLOW_CE")) h->chain_flow_ce = atoi(e) == 1 ? 1 : 2;
     if (const char *e = getenv("BOSSX_CHAIN_GC")) h->chain_gc = atoi(e) != 0;
     if (const char *e = getenv("BOSSX_CHAIN_SCAN")) h->chain_scan = atoi(e) != 0;
+    if (const char *e = getenv("BOSSX_CHAIN_SPEC")) h->chain_spec = atoi(e) != 0;
+    if (h->chain_spec) {
+        std::vector<int64_t> off(h->filt.size() + 1, 0);
+        int64_t max_bins = 0;
+        for (size_t k = 0; k < h->filt.size(); ++k) {
+            const int64_t bins = h->contigs[size_t(h->filt[k])].T + 1;
+            off[k + 1] = off[k] + (bins + kSpecL - 1) / kSpecL;
+            max_bins = std::max(max_bins, bins);
+        }
+        h->spec_total = off.back();
+        h->spec_max_segs = (max_bins + kSpecSeg - 1) / kSpecSeg;
+        const size_t rows = size_t(nb) * 2 * BOSSX_NWIN * size_t(h->spec_total);
+        if ((rc = upload_vec(h, &h->d_chunk_off, off))) return rc;
+        if (hipMalloc(reinterpret_cast<void **>(&h->d_spec_tab), rows * kSpecRow * sizeof(double) + 64) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&h->d_spec_starts), rows * sizeof(double) + 64) != hipSuccess) {
+            (void)hipGetLastError();
+            h->chain_spec = false;          // (the serial chain needs no scratch)
+        } else if ((rc = dev_alloc(h, &h->d_spec_stats, 8, true))) return rc;
+    }
     if (h->chain_scan) {
         // (an allocation failure keeps the serial chain: 176 bytes per bin and barcode)
         if (hipMalloc(reinterpret_cast<void **>(&h->d_scan_S), size_t(nb) * 2 * BOSSX_NWIN * size_t(h->B) * sizeof(double) + 64) != hipSuccess) {
@@ -1523,9 +1563,28 @@ void launch_chain_flow(bossx_engine *h, int ce, dim3 grid, dim3 block, size_t ld
 }
 }  // extern "C++"
 
-void launch_chain(bossx_engine *h, const ChainParams &P, size_t lds, hipStream_t stream = nullptr) {
+void launch_chain(bossx_engine *h, const ChainParams &P0, size_t lds, hipStream_t stream = nullptr, bool checked = false) {
     if (!stream) stream = h->stream;
+    ChainParams P = P0;
     time_begin(h, BOSSX_K_BENEFIT, stream);
+    h->last_chain_spec = false;
+    if (checked && h->chain_spec && h->spec_pause > 0) { --h->spec_pause; ++h->spec_paused_updates; }
+    else if (checked && h->chain_spec && h->matrix_chain && h->chain_ch == 256 && P.tile_done == nullptr && h->spec_total > 0) {
+        // chunk-parallel: candidate tables -> stitched start values -> every segment at once (kernels.hip.inc)
+        SpecParams Q;
+        P.spec_chunk_off = h->d_chunk_off; P.spec_total = h->spec_total; P.spec_starts = h->d_spec_starts;
+        Q.C = P; Q.chunk_off = h->d_chunk_off; Q.total_chunks = h->spec_total; Q.tab = h->d_spec_tab; Q.starts = h->d_spec_starts;
+        Q.stats = getenv("BOSSX_SPEC_STATS") ? h->d_spec_stats : nullptr;
+        hipLaunchKernelGGL(chain_candidates_kernel, dim3(uint32_t((h->spec_total + 3) / 4), BOSSX_NWIN, uint32_t(h->nb * 2)), dim3(256), 0, stream, Q);
+        hipLaunchKernelGGL(chain_stitch_kernel, dim3(uint32_t(h->filt.size() * size_t(h->nb) * 2 * BOSSX_NWIN)), dim3(64), 0, stream, Q);
+        grant_lds(h, reinterpret_cast<const void *>(benefit_chain_kernel<true, false, 256, true>), lds);
+        hipLaunchKernelGGL((benefit_chain_kernel<true, false, 256, true>), dim3(uint32_t(h->spec_max_segs), uint32_t(h->filt.size() * size_t(h->nb) * 2)),
+                           dim3(kChainThreads), lds, stream, P);
+        h->last_chain_spec = true;
+        h->last_chain_live = false;
+        time_end(h, BOSSX_K_BENEFIT, double(h->B) * h->nb * (2 * 8.0 + 2 * 8.0), stream);
+        return;
+    }
     const dim3 grid(uint32_t(h->filt.size() * size_t(h->nb) * 2)), block(kChainThreads);
     const bool live = P.tile_done != nullptr;
     const int ch = h->chain_ch;
@@ -2152,7 +2211,7 @@ int bossx_update_benefit(bossx_engine *h, const int32_t *windows, const double *
         h->last_chain = CP; h->last_chain_lds = lds;
     } else {
         if (!h->max_bits_clear) HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream));
-        launch_chain(h, CP, lds);
+        launch_chain(h, CP, lds, nullptr, /*checked=*/true);      // (the bossx_update that consumes it looks at ctrl->err & 4 and reruns)
     }
     h->max_bits_clear = false;
     HIPCHK(hipGetLastError());
@@ -2205,6 +2264,7 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
         h->stream = h->stream2;
         h->chain_on_stream2 = false;        // same queue now: ordered behind the chain
     }
+    bool spec_ok = true;
     for (int attempt = 0;; ++attempt) {
         if (have_strategy_inputs) {
             if (!chain_done) {
@@ -2212,7 +2272,7 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
                 h->max_bits_clear = false;
                 CP.gate = 1;
                 CP.zero_stats = h->d_stats; CP.n_zero = int32_t(kStatWords);
-                launch_chain(h, CP, lds);
+                launch_chain(h, CP, lds, nullptr, /*checked=*/spec_ok);
             } else if (h->chain_on_stream2) {
                 HIPCHK(hipStreamWaitEvent(h->stream, h->ev_chain, 0));     // the chain ran next to the sweep
             }
@@ -2253,7 +2313,12 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
             const int32_t cleared = 0;      // also drops the pick kernel's 'empty' flag of the aborted attempt
             HIPCHK(hipMemcpyAsync(&h->d_ctrl->err, &cleared, sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
-            if (h->last_chain_live) h->overlap_ok = false; else h->chain_flow = false;
+            if (h->last_chain_spec) {
+                // a segment of the chunk-parallel chain did not end where the next one started: this update's chain
+                // runs again, serially (the same retry as below); three of those and the engine stays serial
+                if (++h->spec_mismatches >= 3) h->chain_spec = false;
+                spec_ok = false;
+            } else if (h->last_chain_live) h->overlap_ok = false; else h->chain_flow = false;
             chain_done = false;
             HIPCHK(hipStreamSynchronize(main_stream));
             h->stream = main_stream;       // rerun on the main stream, after the sweep
@@ -2262,6 +2327,13 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
         break;
     }
     if (hc->any_on) h->host_armed = true;
+    if (h->last_chain_spec && have_strategy_inputs) {
+        // chunks the stitch had to add the plain way (sums that climb more than four binades inside a chunk: capped
+        // next to uncapped regions).  Each costs ~4 us on ONE wave; beyond ~2 % of a chain's chunks the serial kernel wins.
+        const int64_t plain = herr[1];
+        h->spec_plain_total += plain;
+        if (plain * 50 > h->spec_total * int64_t(h->nb) * 2 * BOSSX_NWIN) h->spec_pause = 8;
+    }
     if (*herr) {
         HIPCHK(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
         return fail(h, BOSSX_E_RANGE, "a read contains a base other than A/C/G/T inside an aligned segment");

@@ -656,10 +656,10 @@ def test_resident_fhat_and_chain_kernels_agree(in_tmp):
 
 
 def test_scan_chain_equals_serial_chain(in_tmp):
-    """move_sum as the exact parallel scan (movesum_scan_kernel, the default) against the serial
+    """move_sum as the exact parallel scan (movesum_scan_kernel, BOSSX_CHAIN_SCAN=1) against the serial
     matrix-core recurrence (BOSSX_CHAIN_SCAN=0): benefits, thresholds and masks bit for bit in every
     update (both are compared with the oracle's sequential move_sum elsewhere)."""
-    scan, r0 = _run_updates(in_tmp, "ch_scan", 6)
+    scan, r0 = _run_updates(in_tmp, "ch_scan", 6, env={"BOSSX_CHAIN_SCAN": "1"})
     serial, r1 = _run_updates(in_tmp, "ch_serial", 6, env={"BOSSX_CHAIN_SCAN": "0"})
     assert scan[-1][0] is not None
     for k, (a, b) in enumerate(zip(scan, serial)):
