@@ -80,12 +80,12 @@ struct bossx_engine {
     // an experiment, not the default.  Scratch: the eleven sums of every (barcode, strand, bin).
     bool chain_scan = false;
     // The serial recurrence chunk-parallel (chain_candidates_kernel -> chain_stitch_kernel -> benefit_chain_kernel<SEG>): the
-    // default where the caller checks ctrl->err & 4 and can rerun (bossx_update); BOSSX_CHAIN_SPEC=0 keeps the serial chain.
+    // default chain; the serial kernel is enqueued behind it and runs only if a segment fails its check.  BOSSX_CHAIN_SPEC=0: serial only.
     bool chain_spec = true;
     bool last_chain_spec = false;      // the last chain launch was the chunk-parallel one
     int32_t spec_mismatches = 0;       // segments whose end value differed from the stitched one (each costs a serial rerun); 3: off
     int32_t spec_pause = 0;            // updates left on the serial chain: too many chunks had to be added the plain way last time
-    int64_t spec_plain_total = 0, spec_paused_updates = 0;
+    int64_t spec_plain_total = 0, spec_paused_updates = 0, spec_launches = 0;
     int64_t *d_chunk_off = nullptr; int64_t spec_total = 0, spec_max_segs = 0;
     double *d_spec_tab = nullptr, *d_spec_starts = nullptr;
     unsigned long long *d_spec_stats = nullptr;
@@ -611,6 +611,7 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
     if (const char *e = getenv("BOSSX_CHAIN_GC")) h->chain_gc = atoi(e) != 0;
     if (const char *e = getenv("BOSSX_CHAIN_SCAN")) h->chain_scan = atoi(e) != 0;
     if (const char *e = getenv("BOSSX_CHAIN_SPEC")) h->chain_spec = atoi(e) != 0;
+    if (h->chain_scan) h->chain_spec = false;
     if (h->chain_spec) {
         std::vector<int64_t> off(h->filt.size() + 1, 0);
         int64_t max_bins = 0;
@@ -1467,6 +1468,18 @@ namespace {
 
 int launch_sweep(bossx_engine *h);
 
+// What the chunk-parallel chain left in the error block of the result (words 1 and 2), read by whoever fetched it.
+void note_spec_result(bossx_engine *h, const int32_t *herr) {
+    if (!h->last_chain_spec) return;
+    // chunks the stitch had to add the plain way (sums that climb more than four binades inside a chunk: capped
+    // next to uncapped regions).  Each costs ~4 us on ONE wave; beyond ~2 % of a chain's chunks the serial kernel wins.
+    const int64_t plain = herr[1];
+    h->spec_plain_total += plain;
+    if (plain * 50 > h->spec_total * int64_t(h->nb) * 2 * BOSSX_NWIN) h->spec_pause = 8;
+    h->spec_mismatches = herr[2];                   // (cumulative: launches whose serial fallback ran)
+    if (h->spec_mismatches >= 3) h->chain_spec = false;
+}
+
 int fill_chain_params(bossx_engine *h, const int32_t *windows, const double *mult, ChainParams &P, size_t &lds) {
     int32_t wmax = 0;
     for (int k = 0; k < BOSSX_NWIN; ++k) { P.w[k] = windows[k]; wmax = std::max(wmax, windows[k]); }
@@ -1563,13 +1576,15 @@ void launch_chain_flow(bossx_engine *h, int ce, dim3 grid, dim3 block, size_t ld
 }
 }  // extern "C++"
 
-void launch_chain(bossx_engine *h, const ChainParams &P0, size_t lds, hipStream_t stream = nullptr, bool checked = false) {
+void launch_chain(bossx_engine *h, const ChainParams &P0, size_t lds, hipStream_t stream = nullptr) {
     if (!stream) stream = h->stream;
     ChainParams P = P0;
+    P.rerun_bit = 0;
     time_begin(h, BOSSX_K_BENEFIT, stream);
     h->last_chain_spec = false;
-    if (checked && h->chain_spec && h->spec_pause > 0) { --h->spec_pause; ++h->spec_paused_updates; }
-    else if (checked && h->chain_spec && h->matrix_chain && h->chain_ch == 256 && P.tile_done == nullptr && h->spec_total > 0) {
+    const bool live0 = P.tile_done != nullptr;
+    if (!live0 && h->chain_spec && h->spec_pause > 0) { --h->spec_pause; ++h->spec_paused_updates; }
+    else if (!live0 && h->chain_spec && h->matrix_chain && h->chain_ch == 256 && h->spec_total > 0) {
         // chunk-parallel: candidate tables -> stitched start values -> every segment at once (kernels.hip.inc)
         SpecParams Q;
         P.spec_chunk_off = h->d_chunk_off; P.spec_total = h->spec_total; P.spec_starts = h->d_spec_starts;
@@ -1577,13 +1592,16 @@ void launch_chain(bossx_engine *h, const ChainParams &P0, size_t lds, hipStream_
         Q.stats = getenv("BOSSX_SPEC_STATS") ? h->d_spec_stats : nullptr;
         hipLaunchKernelGGL(chain_candidates_kernel, dim3(uint32_t((h->spec_total + 3) / 4), BOSSX_NWIN, uint32_t(h->nb * 2)), dim3(256), 0, stream, Q);
         hipLaunchKernelGGL(chain_stitch_kernel, dim3(uint32_t(h->filt.size() * size_t(h->nb) * 2 * BOSSX_NWIN)), dim3(64), 0, stream, Q);
+        if (getenv("BOSSX_SPEC_SELFTEST") && h->spec_total > kSpecSegChunks)      // (the first contig needs a second segment)
+            hipLaunchKernelGGL(chain_spoil_kernel, dim3(1), dim3(1), 0, stream, h->d_spec_starts, int64_t(kSpecSegChunks));
         grant_lds(h, reinterpret_cast<const void *>(benefit_chain_kernel<true, false, 256, true>), lds);
         hipLaunchKernelGGL((benefit_chain_kernel<true, false, 256, true>), dim3(uint32_t(h->spec_max_segs), uint32_t(h->filt.size() * size_t(h->nb) * 2)),
                            dim3(kChainThreads), lds, stream, P);
         h->last_chain_spec = true;
-        h->last_chain_live = false;
-        time_end(h, BOSSX_K_BENEFIT, double(h->B) * h->nb * (2 * 8.0 + 2 * 8.0), stream);
-        return;
+        ++h->spec_launches;
+        // ... and behind them the serial chain, which does nothing unless a segment failed its check
+        hipLaunchKernelGGL(chain_rerun_kernel, dim3(1), dim3(1), 0, stream, h->d_ctrl, 0);
+        P.rerun_bit = kSpecMismatch;
     }
     const dim3 grid(uint32_t(h->filt.size() * size_t(h->nb) * 2)), block(kChainThreads);
     const bool live = P.tile_done != nullptr;
@@ -1621,6 +1639,7 @@ void launch_chain(bossx_engine *h, const ChainParams &P0, size_t lds, hipStream_
         if (ch == 256) { if (live) launch_chain_variant<false, true, 256>(h, grid, block, lds, stream, P); else launch_chain_variant<false, false, 256>(h, grid, block, lds, stream, P); }
         else { if (live) launch_chain_variant<false, true, 128>(h, grid, block, lds, stream, P); else launch_chain_variant<false, false, 128>(h, grid, block, lds, stream, P); }
     }
+    if (P.rerun_bit) hipLaunchKernelGGL(chain_rerun_kernel, dim3(1), dim3(1), 0, stream, h->d_ctrl, 1);
     // algorithmic bytes: read the downsampled scores once per direction, write both strands
     time_end(h, BOSSX_K_BENEFIT, double(h->B) * h->nb * (2 * 8.0 + 2 * 8.0), stream);
 }
@@ -2008,6 +2027,7 @@ int dist_finish_impl(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, bo
     HIPCHK(hipMemcpyAsync(pin, h->d_result, h->result_bytes, hipMemcpyDeviceToHost, h->stream));
     if (strat_all && (rc = copy_masks(h, strat_all, bits))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
+    note_spec_result(h, herr);
     if (*herr) {
         HIPCHK(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
         return fail(h, BOSSX_E_RANGE, "a read contains a base other than A/C/G/T inside an aligned segment");
@@ -2099,6 +2119,12 @@ int bossx_dist_init(bossx_engine *h, const uint8_t *id, int32_t rank, int32_t wo
 }
 
 int64_t bossx_dist_collectives(const bossx_engine *h) { return h ? h->n_collectives : 0; }
+
+int bossx_chain_stats(const bossx_engine *h, int64_t out[4]) {
+    if (!h || !out) return BOSSX_E_INVALID;
+    out[0] = h->spec_launches; out[1] = h->spec_paused_updates; out[2] = h->spec_plain_total; out[3] = h->spec_mismatches;
+    return BOSSX_OK;
+}
 
 int bossx_dist_chain(bossx_engine *h, const int32_t *windows, const double *mult) {
     if (!h || !h->finalized || !h->comm || !windows || !mult) return fail(h, BOSSX_E_INVALID, "bad dist_chain call (bossx_dist_init first)");
@@ -2211,7 +2237,7 @@ int bossx_update_benefit(bossx_engine *h, const int32_t *windows, const double *
         h->last_chain = CP; h->last_chain_lds = lds;
     } else {
         if (!h->max_bits_clear) HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream));
-        launch_chain(h, CP, lds, nullptr, /*checked=*/true);      // (the bossx_update that consumes it looks at ctrl->err & 4 and reruns)
+        launch_chain(h, CP, lds);
     }
     h->max_bits_clear = false;
     HIPCHK(hipGetLastError());
@@ -2264,7 +2290,6 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
         h->stream = h->stream2;
         h->chain_on_stream2 = false;        // same queue now: ordered behind the chain
     }
-    bool spec_ok = true;
     for (int attempt = 0;; ++attempt) {
         if (have_strategy_inputs) {
             if (!chain_done) {
@@ -2272,7 +2297,7 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
                 h->max_bits_clear = false;
                 CP.gate = 1;
                 CP.zero_stats = h->d_stats; CP.n_zero = int32_t(kStatWords);
-                launch_chain(h, CP, lds, nullptr, /*checked=*/spec_ok);
+                launch_chain(h, CP, lds);
             } else if (h->chain_on_stream2) {
                 HIPCHK(hipStreamWaitEvent(h->stream, h->ev_chain, 0));     // the chain ran next to the sweep
             }
@@ -2313,12 +2338,7 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
             const int32_t cleared = 0;      // also drops the pick kernel's 'empty' flag of the aborted attempt
             HIPCHK(hipMemcpyAsync(&h->d_ctrl->err, &cleared, sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
-            if (h->last_chain_spec) {
-                // a segment of the chunk-parallel chain did not end where the next one started: this update's chain
-                // runs again, serially (the same retry as below); three of those and the engine stays serial
-                if (++h->spec_mismatches >= 3) h->chain_spec = false;
-                spec_ok = false;
-            } else if (h->last_chain_live) h->overlap_ok = false; else h->chain_flow = false;
+            if (h->last_chain_live) h->overlap_ok = false; else h->chain_flow = false;
             chain_done = false;
             HIPCHK(hipStreamSynchronize(main_stream));
             h->stream = main_stream;       // rerun on the main stream, after the sweep
@@ -2327,13 +2347,7 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
         break;
     }
     if (hc->any_on) h->host_armed = true;
-    if (h->last_chain_spec && have_strategy_inputs) {
-        // chunks the stitch had to add the plain way (sums that climb more than four binades inside a chunk: capped
-        // next to uncapped regions).  Each costs ~4 us on ONE wave; beyond ~2 % of a chain's chunks the serial kernel wins.
-        const int64_t plain = herr[1];
-        h->spec_plain_total += plain;
-        if (plain * 50 > h->spec_total * int64_t(h->nb) * 2 * BOSSX_NWIN) h->spec_pause = 8;
-    }
+    if (have_strategy_inputs) note_spec_result(h, herr);
     if (*herr) {
         HIPCHK(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
         return fail(h, BOSSX_E_RANGE, "a read contains a base other than A/C/G/T inside an aligned segment");

@@ -425,6 +425,13 @@ class Engine:
     def dist_collectives(self):
         return int(self.lib.bossx_dist_collectives(self.h))
 
+    def chain_stats(self):
+        """Counters of the chunk-parallel benefit chain since finalize (include/bossx.h: bossx_chain_stats)."""
+        out = (C.c_int64 * 4)()
+        self._ck(self.lib.bossx_chain_stats(self.h, out))
+        return dict(chunk_parallel_launches=int(out[0]), serial_launches_while_paused=int(out[1]),
+                    chunks_added_plainly=int(out[2]), failed_checks=int(out[3]))
+
     def update(self, bucket_threshold, windows=None, mult=None, tc=0.0, fhat_c=None, target_rs=0,
                want_stats=False, bits=False, fhat_model=None, dist=False):
         """bossx_update (`dist`: bossx_dist_update): one fused decision update.  Without `fhat_c` only the sweep and the

@@ -323,6 +323,14 @@ int bossx_dist_update(bossx_engine *h, const bossx_update_params *up, uint8_t *s
                       bossx_update_result *res);
 /* Collectives issued through this engine's communicator so far (measurement).                         */
 int64_t bossx_dist_collectives(const bossx_engine *h);
+
+/* The benefit chain (calc_smu + calc_u, reference.py:215-269) runs chunk-parallel by default: candidate start
+ * values per chunk on the matrix core, stitched, every segment recomputed from its exact start and checked against
+ * its successor's (csrc/kernels.hip.inc).  Counters since bossx_finalize:
+ *   out[0] launches of the chunk-parallel form        out[1] launches kept on the serial kernel (too many chunks
+ *   out[2] chunks the stitch added the plain way               needed plain adds in the launch before: 8 launches pause)
+ *   out[3] launches whose check failed (the serial kernel, enqueued behind and gated on the flag, then ran; 3: off) */
+int bossx_chain_stats(const bossx_engine *h, int64_t out[4]);
 /* Page-locked host memory for the caller's output buffers — the mask buffer of bossx_update above
  * all: a device-to-host copy into it is a direct DMA, into pageable memory it is staged (2.2 MB of
  * masks at 110 Mb: 0.1 ms less per update; registering pageable memory after the fact measured

@@ -1272,3 +1272,64 @@ def test_lookahead_staging_vs_oracle(in_tmp, nb, ploidy):
     runs.rl_dist.update(cur["read_lengths"])
     runs.process_batch_paf(cur["paf"], cur["seqs"], barcodes=bcs)
     check("last")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["default", "spoiled", "serial"])
+def test_chunk_parallel_chain_vs_oracle(in_tmp, monkeypatch, mode):
+    """The benefit chain, chunk-parallel (chain_candidates_kernel -> chain_stitch_kernel -> segments, the default):
+    contigs of several 4096-bin segments, a stack of reads that caps a stretch (bin sums 10^5 times smaller
+    than next door: chunks whose sum climbs more than four binades are added the plain way by the stitch)
+    and a stretch without reads.  additional_benefit, thresholds and masks must equal the oracle's
+    sequential move_sum bit for bit in every update.  `spoiled`: BOSSX_SPEC_SELFTEST flips the last bit
+    of one stitched start value — the segment before it must notice and the serial kernel enqueued
+    behind must redo the launch, same results.  `serial`: BOSSX_CHAIN_SPEC=0."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.runs import BossRuns
+    from oracle.pipeline import OracleRuns
+    if mode == "spoiled":
+        monkeypatch.setenv("BOSSX_SPEC_SELFTEST", "1")
+    if mode == "serial":
+        monkeypatch.setenv("BOSSX_CHAIN_SPEC", "0")
+    lens = [1_350_000, 620_000]
+    names = ["cp0", "cp1"]
+    contigs = synth.make_reference(lens, seed=91, names=names)
+    strs = [(n, synth.codes_to_str(c)) for n, c in contigs]
+    args = BossConfig()
+    args.general.name = "cp_" + mode
+    args.optional.bucket_threshold = 0
+    runs = BossRuns(args)
+    runs.init(contigs=strs)
+    o = OracleRuns(strs, ploidy=1, nbarcodes=1, bucket_threshold=0)
+    rng = np.random.default_rng(5)
+    for b in range(4):
+        batch = synth.make_batch(contigs, 2500, seed=9100 + b, mean_len=5000.0, nbarcodes=1)
+        batch = _drop_mappings_into(batch, "cp0", 700_000, 790_000)
+        spans = [(int(s), int(s) + 30_000) for s in rng.integers(200_000, 230_000, size=12)]
+        paf2, seqs2 = _exact_reads(contigs, "cp0", spans, "stack%d" % b)
+        paf = batch["paf"].rstrip("\n") + "\n" + paf2
+        seqs = dict(batch["seqs"]); seqs.update(seqs2)
+        rl = dict(batch["read_lengths"])
+        rl.update({rid: len(sq) for rid, sq in seqs2.items()})
+        o.process_batch(paf, seqs, read_lengths=rl)
+        runs.rl_dist.update(rl)
+        runs.process_batch_paf(paf, seqs)
+        assert runs.threshold == o.threshold, b
+        for n, oc in o.contigs.items():
+            pc = runs.contigs[n]
+            assert np.array_equal(pc.coverage, oc.coverage), (b, n)
+            assert np.array_equal(pc.scores_ds, oc.scores_ds), (b, n)
+            assert np.array_equal(pc.additional_benefit, oc.additional_benefit), (b, n)
+            assert np.array_equal(pc.strat, oc.strat), (b, n)
+    assert o.threshold is not None
+    cov = o.contigs["cp0"].coverage.sum(axis=1)[:, 0] if o.contigs["cp0"].coverage.ndim == 3 else o.contigs["cp0"].coverage.sum(axis=1)
+    assert cov[210_000:225_000].min() >= 30 and cov[720_000:780_000].max() == 0      # the capped and the empty stretch exist
+    st = runs.engine.chain_stats()
+    if mode == "default":
+        assert st["chunk_parallel_launches"] > 0 and st["failed_checks"] == 0, st
+    elif mode == "spoiled":
+        assert st["failed_checks"] >= 1, st              # ... and every result above was still the oracle's
+    else:
+        assert st["chunk_parallel_launches"] == 0, st
+    runs.engine.close()
