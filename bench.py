@@ -751,6 +751,10 @@ def main():
                      "batch_generation_s": t_gen,
                      "note": "stage_batch = native PAF/CIGAR parse + upload of one batch (inside ms_per_step)"},
             "move_sum_on_fp64_matrix_core": eng.matrix_chain,
+            "benefit_chain_form": dict(eng.chain_stats(), note="chunk-parallel, exact (candidate tables on the matrix core -> stitched start "
+                                       "values -> every 4096-bin segment recomputed from its exact start and checked against its "
+                                       "successor's; the serial kernel is enqueued behind, gated on a failed check); counters since "
+                                       "finalize, over every loop of this script"),
         }
         if cpu_cmp is not None:
             o, t_cpu, t_gpu, same = cpu_cmp

@@ -126,6 +126,10 @@ PROTOTYPES = {
     "bossx_get_max": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "bossx_update": (C.c_int, [C.c_void_p, C.POINTER(UpdateParams), C.c_void_p, C.c_void_p,
                                C.POINTER(UpdateResult), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bossx_update_launch": (C.c_int, [C.c_void_p, C.POINTER(UpdateParams), C.c_void_p, C.c_void_p,
+                               C.POINTER(UpdateResult), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bossx_update_collect": (C.c_int, [C.c_void_p, C.POINTER(UpdateParams), C.c_void_p, C.c_void_p,
+                               C.POINTER(UpdateResult), C.c_void_p, C.c_void_p, C.c_void_p]),
     "bossx_strat_bytes": (C.c_int64, [C.c_void_p]),
     "bossx_strat_offset": (C.c_int64, [C.c_void_p, C.c_int32]),
     "bossx_get_strat": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),

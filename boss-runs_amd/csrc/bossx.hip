@@ -84,6 +84,7 @@ struct bossx_engine {
     bool chain_spec = true;
     bool last_chain_spec = false;      // the last chain launch was the chunk-parallel one
     int32_t spec_mismatches = 0;       // segments whose end value differed from the stitched one (each costs a serial rerun); 3: off
+    bool upd_launched = false, upd_done = false, upd_mirrored = false;    // bossx_update_launch / _collect
     int32_t spec_pause = 0;            // updates left on the serial chain: too many chunks had to be added the plain way last time
     int64_t spec_plain_total = 0, spec_paused_updates = 0, spec_launches = 0;
     int64_t *d_chunk_off = nullptr; int64_t spec_total = 0, spec_max_segs = 0;
@@ -2247,12 +2248,18 @@ int bossx_update_benefit(bossx_engine *h, const int32_t *windows, const double *
 // One whole decision update enqueued back to back (no host round trip between kernels):
 // sweep -> bucket switches -> benefit chain -> threshold statistics -> threshold choice ->
 // masks, then one device-to-host copy of all masks and the control block.
-int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all, uint8_t *contig_on,
-                 bossx_update_result *res, int64_t *counts, uint64_t *fgrid_fx, uint64_t *ubar0_fx) {
+namespace {
+// mode 0: the whole update; 1: enqueue it and return (bossx_update_launch); 2: wait for what mode 1 enqueued and
+// read the results (bossx_update_collect).
+int update_run(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all, uint8_t *contig_on,
+               bossx_update_result *res, int64_t *counts, uint64_t *fgrid_fx, uint64_t *ubar0_fx, int mode) {
     if (!h || !h->finalized || !up || !res) return fail(h, BOSSX_E_INVALID, "bad update call");
     if (!h->lut_set) return fail(h, BOSSX_E_INVALID, "update before set_lut");
     HIPCHK(hipSetDevice(h->cfg.device));
     int rc;
+    if (mode == 1 && h->chain_on_stream2) mode = 0;       // a chain next to the sweep has its own retry: no split
+    if (mode == 1) h->upd_done = false;
+    if (mode == 0 && h->upd_launched) return fail(h, BOSSX_E_INVALID, "bossx_update while a launched update has not been collected");
     bossx_fhat_desc fh{up->fhat_c, up->n_windows, 20, up->target_rs, h->n_sites_all / kWindow};
     ChainParams CP;
     size_t lds = 0;
@@ -2261,7 +2268,7 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
     if (have_strategy_inputs) {
         if ((rc = fill_chain_params(h, up->windows, up->mult, CP, lds))) return rc;
     }
-    if (!(up->flags & BOSSX_UPDATE_SWEEP_DONE)) {
+    if (mode != 2 && !(up->flags & BOSSX_UPDATE_SWEEP_DONE)) {
         if ((rc = launch_sweep(h))) return rc;
         launch_buckets(h, up->bucket_threshold);
     }
@@ -2275,6 +2282,7 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
     unsigned long long *hst = reinterpret_cast<unsigned long long *>(pin + ((h->result_bytes + 15) & ~size_t(15)));
     bool chain_done = (up->flags & BOSSX_UPDATE_BENEFIT_DONE) != 0;
     bool mirrored = false;
+    if (mode == 2) { chain_done = true; mirrored = h->upd_mirrored; }
     // A chain that ran next to the sweep lives on stream2: the rest of the update follows it IN THAT
     // QUEUE (no cross-queue signal between the chain and the histogram); the sweep and the bucket
     // switches it also depends on finished long ago (ev_sweep).
@@ -2282,8 +2290,8 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
     struct Restore { bossx_engine *h; hipStream_t s; ~Restore() { h->stream = s; } } restore{h, main_stream};
     // f-hat goes up on the (idle) main stream right away, while the chain still runs
     const FhatModel fm{up->n_windows, up->target_rs, up->fhat_alpha, up->fhat_den, up->fhat_expected, up->fhat_on_target};
-    if (have_strategy_inputs && (rc = fhat_resident ? build_fhat(h, &fm) : upload_fhat(h, &fh))) return rc;
-    if (have_strategy_inputs && chain_done && h->chain_on_stream2 && (up->flags & BOSSX_UPDATE_SWEEP_DONE)) {
+    if (mode != 2 && have_strategy_inputs && (rc = fhat_resident ? build_fhat(h, &fm) : upload_fhat(h, &fh))) return rc;
+    if (mode != 2 && have_strategy_inputs && chain_done && h->chain_on_stream2 && (up->flags & BOSSX_UPDATE_SWEEP_DONE)) {
         // ev_fhat was recorded on the main stream behind the sweep and the bucket switches of this
         // update, so it covers them as well: one (long signalled) cross-queue dependency
         HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fhat, 0));
@@ -2291,7 +2299,8 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
         h->chain_on_stream2 = false;        // same queue now: ordered behind the chain
     }
     for (int attempt = 0;; ++attempt) {
-        if (have_strategy_inputs) {
+        const bool enqueue = !(mode == 2 && attempt == 0);      // (collect: attempt 0 was enqueued by the launch call)
+        if (enqueue && have_strategy_inputs) {
             if (!chain_done) {
                 if (!h->max_bits_clear) HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream));
                 h->max_bits_clear = false;
@@ -2323,10 +2332,16 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
         }
         HIPCHK(hipGetLastError());
         // results
-        if (!have_strategy_inputs)
-            HIPCHK(hipMemcpyAsync(pin, h->d_result, h->result_bytes, hipMemcpyDeviceToHost, h->stream));
-        if (counts) HIPCHK(hipMemcpyAsync(hst, h->d_stats, kStatWords * 8, hipMemcpyDeviceToHost, h->stream));
-        if (strat_all && have_strategy_inputs && !mirrored && (rc = copy_masks(h, strat_all, (up->flags & BOSSX_UPDATE_STRAT_BITS) != 0))) return rc;
+        if (enqueue) {
+            if (!have_strategy_inputs)
+                HIPCHK(hipMemcpyAsync(pin, h->d_result, h->result_bytes, hipMemcpyDeviceToHost, h->stream));
+            if (counts) HIPCHK(hipMemcpyAsync(hst, h->d_stats, kStatWords * 8, hipMemcpyDeviceToHost, h->stream));
+            if (strat_all && have_strategy_inputs && !mirrored && (rc = copy_masks(h, strat_all, (up->flags & BOSSX_UPDATE_STRAT_BITS) != 0))) return rc;
+        }
+        if (mode == 1) {            // everything is in the queue: the caller does other work and collects later
+            h->upd_launched = true; h->upd_mirrored = mirrored;
+            return BOSSX_OK;
+        }
         HIPCHK(hipStreamSynchronize(h->stream));
         if (have_strategy_inputs && *herr == kNoResult) {      // the kernel left early: fetch the block the ordinary way
             HIPCHK(hipMemcpyAsync(pin, h->d_result, h->result_bytes, hipMemcpyDeviceToHost, h->stream));
@@ -2371,6 +2386,30 @@ int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_
         if (ubar0_fx) memcpy(ubar0_fx, hst + BOSSX_HIST_BINS * 3, 2 * sizeof(uint64_t));
     }
     return BOSSX_OK;
+}
+}  // namespace
+
+int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all, uint8_t *contig_on,
+                 bossx_update_result *res, int64_t *counts, uint64_t *fgrid_fx, uint64_t *ubar0_fx) {
+    return update_run(h, up, strat_all, contig_on, res, counts, fgrid_fx, ubar0_fx, 0);
+}
+
+int bossx_update_launch(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all, uint8_t *contig_on,
+                        bossx_update_result *res, int64_t *counts, uint64_t *fgrid_fx, uint64_t *ubar0_fx) {
+    if (h && h->upd_launched) return fail(h, BOSSX_E_INVALID, "an update is already launched: collect it first");
+    int rc = update_run(h, up, strat_all, contig_on, res, counts, fgrid_fx, ubar0_fx, 1);
+    if (rc == BOSSX_OK && h && !h->upd_launched) h->upd_done = true;       // (ran to the end after all: nothing left to collect)
+    if (rc != BOSSX_OK && h) { h->upd_launched = false; h->upd_done = false; }
+    return rc;
+}
+
+int bossx_update_collect(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all, uint8_t *contig_on,
+                         bossx_update_result *res, int64_t *counts, uint64_t *fgrid_fx, uint64_t *ubar0_fx) {
+    if (!h) return BOSSX_E_INVALID;
+    if (h->upd_done) { h->upd_done = false; return BOSSX_OK; }          // the launch call already filled everything
+    if (!h->upd_launched) return fail(h, BOSSX_E_INVALID, "no launched update to collect");
+    h->upd_launched = false;
+    return update_run(h, up, strat_all, contig_on, res, counts, fgrid_fx, ubar0_fx, 2);
 }
 
 int bossx_get_strat(bossx_engine *h, int32_t contig, uint8_t *dst) {

@@ -433,12 +433,14 @@ class Engine:
                     chunks_added_plainly=int(out[2]), failed_checks=int(out[3]))
 
     def update(self, bucket_threshold, windows=None, mult=None, tc=0.0, fhat_c=None, target_rs=0,
-               want_stats=False, bits=False, fhat_model=None, dist=False):
+               want_stats=False, bits=False, fhat_model=None, dist=False, between=None):
         """bossx_update (`dist`: bossx_dist_update): one fused decision update.  Without `fhat_c` only the sweep and the
         bucket switches run.  Returns dict(updated, any_on, threshold, normaliser, ubar0,
         strat_size, n_bins, contig_on[, counts, fgrid_fx, ubar_fx]); masks land in
         `self.strat_all` (bytes of every non-rejected contig, add order) or, with `bits`,
-        packed 8:1 in `self.strat_bits` (bossx_get_strat_bits layout)."""
+        packed 8:1 in `self.strat_bits` (bossx_get_strat_bits layout).  `between`: host work done while the
+        enqueued update runs (bossx_update_launch -> between() -> bossx_update_collect), e.g. staging the next
+        batch into the other slot; it must not touch this update's inputs or results."""
         up = _lib.UpdateParams()
         f = None
         if fhat_model is not None and fhat_c is None:
@@ -495,10 +497,17 @@ class Engine:
         if dist:        # bossx_dist_update: the same update with the library's own RCCL collectives between the stages
             self._ck(self.lib.bossx_dist_update(self.h, C.byref(up), masks.ctypes.data, on.ctypes.data, C.byref(res)))
         else:
-            self._ck(self.lib.bossx_update(self.h, C.byref(up), masks.ctypes.data, on.ctypes.data,
-                                           C.byref(res), None if counts is None else counts.ctypes.data,
-                                           None if fg is None else fg.ctypes.data,
-                                           None if ub is None else ub.ctypes.data))
+            a = (self.h, C.byref(up), masks.ctypes.data, on.ctypes.data, C.byref(res), None if counts is None else counts.ctypes.data,
+                 None if fg is None else fg.ctypes.data, None if ub is None else ub.ctypes.data)
+            if between is None:
+                self._ck(self.lib.bossx_update(*a))
+            else:
+                self._ck(self.lib.bossx_update_launch(*a))
+                try:
+                    between()
+                finally:
+                    rc = self.lib.bossx_update_collect(*a)
+                self._ck(rc)
         out = dict(updated=bool(res.updated), any_on=bool(res.any_on), threshold=res.threshold,
                    normaliser=res.normaliser, ubar0=res.ubar0, strat_size=res.strat_size,
                    n_bins=res.n_bins, contig_on=on.astype(bool))

@@ -218,9 +218,13 @@ class BossRuns(Boss):
         if self._fused:       # the GPU sweeps / runs the chain while the host does its bookkeeping
             self.engine.update_begin(self.args.optional.bucket_threshold)
             self.launch_benefit()
-        self._stage_ahead(lookahead)
         self._account_reads(summ, len(new_reads) if n_reads_total is None else n_reads_total, starts_filter)
-        self.update_wrapper()
+        if self._fused and lookahead is not None:
+            # the whole update is in the GPU's queue (masks and results included) before the next batch is staged
+            self.update_wrapper(between=lambda: self._stage_ahead(lookahead))
+        else:
+            self._stage_ahead(lookahead)
+            self.update_wrapper()
 
     _ahead = None        # the batch staged ahead by the previous call (dict), or None
     _cur_slot = 0        # engine slot of the batch being processed
@@ -293,7 +297,7 @@ class BossRuns(Boss):
             cont.check_buckets(self.engine.bucket_sums(cont.index), threshold=thr)
         return any(any(c.switched_on) for c in self.contigs.values())
 
-    def update_wrapper(self) -> None:
+    def update_wrapper(self, between=None) -> None:
         """core.py:160-198, enqueued as one fused device update (bossx_update): scores +
         dropout + bucket sums + bin sums, bucket switches, and — once any strategy is switched
         on — benefits, threshold search, masks."""
@@ -310,13 +314,13 @@ class BossRuns(Boss):
             if self.read_starts._engine is not None:
                 # update_f_pointmass on the device, from the counts resident there
                 res = eng.update(thr, windows, MULT, tc=self.rl_dist.time_cost // 100,
-                                 fhat_model=self.read_starts.fhat_model(), want_stats=self.keep_stats, bits=use_bits)
+                                 fhat_model=self.read_starts.fhat_model(), want_stats=self.keep_stats, bits=use_bits, between=between)
             else:
                 fhat_c, target_rs = self.read_starts.fhat_compact()
                 res = eng.update(thr, windows, MULT, tc=self.rl_dist.time_cost // 100, fhat_c=fhat_c,
-                                 target_rs=target_rs, want_stats=self.keep_stats, bits=use_bits)
+                                 target_rs=target_rs, want_stats=self.keep_stats, bits=use_bits, between=between)
         else:
-            res = eng.update(thr)
+            res = eng.update(thr, between=between)
         for cname, cont in self.contigs_filt.items():
             if res["contig_on"][cont.index] and not all(cont.switched_on):
                 cont.switched_on[:] = True

@@ -346,6 +346,16 @@ int bossx_get_max(bossx_engine *h, double *max_benefit);
 int bossx_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all,
                  uint8_t *contig_on, bossx_update_result *res, int64_t *counts,
                  uint64_t *fgrid_fx, uint64_t *ubar0_fx);
+/* The same update in two calls: _launch enqueues everything (masks and results included) and returns; the caller
+ * does host work that needs neither — e.g. stages the NEXT batch into the other slot — and _collect, with the SAME
+ * arguments, waits and fills `res`, `contig_on`, `counts` ...  Buffers and `up` must stay valid in between; one
+ * update at a time; no other engine call but bossx_select_batch / bossx_stage_batch* between the two.          */
+int bossx_update_launch(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all,
+                        uint8_t *contig_on, bossx_update_result *res, int64_t *counts,
+                        uint64_t *fgrid_fx, uint64_t *ubar0_fx);
+int bossx_update_collect(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all,
+                         uint8_t *contig_on, bossx_update_result *res, int64_t *counts,
+                         uint64_t *fgrid_fx, uint64_t *ubar0_fx);
 int64_t bossx_strat_bytes(const bossx_engine *h);
 int64_t bossx_strat_offset(const bossx_engine *h, int32_t contig);
 
