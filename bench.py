@@ -646,6 +646,10 @@ def main():
     elapsed = timed(barrier, lambda: R.run_e2e(sel, tail=extra))
     stats = eng.kernel_stats()
     kern = kernel_table(stats, base)
+    # ---- latency of a lone update: the same end-to-end step with nothing staged ahead (a live run whose
+    # next batch does not exist yet); right behind the region, on its first batches once more
+    n_lat = min(len(sel), 10)
+    elapsed_lone = timed(barrier, lambda: [R.step_e2e(b) for b in sel[:n_lat]])
     # ---- the same updates with the inputs already resident in HBM (parse + upload outside) --------
     summ, t_stage = R.stage(sel)
     base2 = eng.kernel_stats()
@@ -662,10 +666,6 @@ def main():
     # event overhead check: the resident loop once more without events
     elapsed_res_noev = timed(barrier, lambda: [R.step_resident(i, b, s) for i, (b, s) in enumerate(zip(sel, summ))])
     aligned = float(np.mean([s["aligned"] for s in summ]))
-    # ---- latency of a lone update: the same end-to-end step with nothing staged ahead (a live run whose
-    # next batch does not exist yet); the region's batches once more, events off
-    n_lat = min(len(sel), 10)
-    elapsed_lone = timed(barrier, lambda: [R.step_e2e(b) for b in sel[:n_lat]])
 
     if world > 1:
         t = torch.tensor([elapsed, elapsed_res], dtype=torch.float64, device="cuda")
