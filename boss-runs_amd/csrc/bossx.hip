@@ -85,6 +85,7 @@ struct bossx_engine {
     bool last_chain_spec = false;      // the last chain launch was the chunk-parallel one
     int32_t spec_mismatches = 0;       // segments whose end value differed from the stitched one (each costs a serial rerun); 3: off
     bool upd_launched = false, upd_done = false, upd_mirrored = false;    // bossx_update_launch / _collect
+    double spec_est_us = 0, spec_est_serial_us = 0;     // what finalize expects of the two forms of the chain (microseconds)
     int32_t spec_pause = 0;            // updates left on the serial chain: too many chunks had to be added the plain way last time
     int64_t spec_plain_total = 0, spec_paused_updates = 0, spec_launches = 0;
     int64_t *d_chunk_off = nullptr; int64_t spec_total = 0, spec_max_segs = 0;
@@ -623,6 +624,21 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
         }
         h->spec_total = off.back();
         h->spec_max_segs = (max_bins + kSpecSeg - 1) / kSpecSeg;
+        // Does it pay?  Measured on MI355X (profiles/r03_*): the serial kernel walks 3.9 ns per bin of the longest contig, one
+        // block per (contig, barcode, strand) and a CU each; the chunk-parallel form costs 5.2 ns per (window, strand, chunk)
+        // table, 0.27 us per chunk of the longest contig for the stitch and 22 us per round of 256 segments.  Many short
+        // chains (10 x 5 Mb x 8 barcodes: 160 blocks of 50 k bins) are better off serial; BOSSX_CHAIN_SPEC=2 forces the form.
+        {
+            int64_t segs = 0;
+            for (size_t k = 0; k < h->filt.size(); ++k) segs += (h->contigs[size_t(h->filt[k])].T + 1 + kSpecSeg - 1) / kSpecSeg;
+            const double blocks = double(h->filt.size()) * nb * 2;
+            h->spec_est_serial_us = 3.9e-3 * double(max_bins) * std::ceil(blocks / 256.0);
+            h->spec_est_us = 5.2e-3 * double(h->spec_total) * nb * 2 * BOSSX_NWIN + 0.27 * double((max_bins + kSpecL - 1) / kSpecL) +
+                             22.0 * std::ceil(double(segs) * nb * 2 / 256.0) + 30.0;
+            const char *e = getenv("BOSSX_CHAIN_SPEC");
+            if (!(e && atoi(e) == 2) && h->spec_est_us > 0.7 * h->spec_est_serial_us) h->chain_spec = false;
+        }
+        if (h->chain_spec) {
         const size_t rows = size_t(nb) * 2 * BOSSX_NWIN * size_t(h->spec_total);
         if ((rc = upload_vec(h, &h->d_chunk_off, off))) return rc;
         if (hipMalloc(reinterpret_cast<void **>(&h->d_spec_tab), rows * kSpecRow * sizeof(double) + 64) != hipSuccess ||
@@ -630,6 +646,7 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
             (void)hipGetLastError();
             h->chain_spec = false;          // (the serial chain needs no scratch)
         } else if ((rc = dev_alloc(h, &h->d_spec_stats, 8, true))) return rc;
+        }
     }
     if (h->chain_scan) {
         // (an allocation failure keeps the serial chain: 176 bytes per bin and barcode)

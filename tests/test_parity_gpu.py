@@ -740,10 +740,13 @@ def test_default_schedule_at_40mb_equals_serial(in_tmp):
 
 
 @pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
-def test_random_scenarios_vs_oracle(in_tmp, seed):
+def test_random_scenarios_vs_oracle(in_tmp, seed, monkeypatch):
     """Seeded random scenarios — contig count and lengths, barcodes (fused, ingest-first and split
     sweep forms), ploidy, bucket threshold, batch size, read length — against the oracle: coverage,
-    scores, bucket switches, bin sums, benefits, threshold and masks bit for bit, every update."""
+    scores, bucket switches, bin sums, benefits, threshold and masks bit for bit, every update.
+    Even seeds force the chunk-parallel form of the benefit chain (contigs this small would get the
+    serial kernel), odd seeds the serial one."""
+    monkeypatch.setenv("BOSSX_CHAIN_SPEC", "2" if seed % 2 == 0 else "0")
     from boss_runs_amd import synth
     from boss_runs_amd.config import BossConfig
     from boss_runs_amd.runs import BossRuns
@@ -1288,10 +1291,10 @@ def test_chunk_parallel_chain_vs_oracle(in_tmp, monkeypatch, mode):
     from boss_runs_amd.config import BossConfig
     from boss_runs_amd.runs import BossRuns
     from oracle.pipeline import OracleRuns
+    # (at 1.35 Mb the engine's own estimate keeps the serial kernel: 2 forces the chunk-parallel form)
+    monkeypatch.setenv("BOSSX_CHAIN_SPEC", "0" if mode == "serial" else "2")
     if mode == "spoiled":
         monkeypatch.setenv("BOSSX_SPEC_SELFTEST", "1")
-    if mode == "serial":
-        monkeypatch.setenv("BOSSX_CHAIN_SPEC", "0")
     lens = [1_350_000, 620_000]
     names = ["cp0", "cp1"]
     contigs = synth.make_reference(lens, seed=91, names=names)
