@@ -1175,6 +1175,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
     if (aligned_bases) *aligned_bases = int64_t(pb.total_emit);
     if (!st.ev_ready) HIPCHK(hipEventCreateWithFlags(&st.ev_ready, hipEventDisableTiming));
     HIPCHK(hipEventRecord(st.ev_ready, h->stream_stage));
+    if (timing) fprintf(stderr, "[bossx] stage_batch: %.2f ms inside the staging core\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     st.pb = std::move(pb);
     st.valid = true;
     upload_guard.ok = true;
@@ -1201,6 +1202,8 @@ int bossx_stage_batch_ptrs(bossx_engine *h, const char *paf, size_t paf_len, con
                            bossx_batch_summary *summary, int32_t *n_rec, int64_t *aligned_bases) {
     if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "stage_batch before finalize");
     if (n_reads < 0 || (n_reads > 0 && (!name_ptrs || !name_lens || !seq_ptrs || !seq_lens))) return fail(h, BOSSX_E_INVALID, "bad batch arrays");
+    const auto t_entry = std::chrono::steady_clock::now();
+    struct EntryTimer { std::chrono::steady_clock::time_point t; ~EntryTimer() { if (getenv("BOSSX_STAGE_TIMING")) fprintf(stderr, "[bossx] stage_batch: %.2f ms inside bossx_stage_batch_ptrs\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count()); } } entry_timer{t_entry};
     HIPCHK(hipSetDevice(h->cfg.device));
     std::vector<int64_t> name_off(size_t(n_reads) + 1, 0), seq_off(size_t(n_reads) + 1, 0);
     for (int32_t i = 0; i < n_reads; ++i) {
