@@ -2029,19 +2029,21 @@ static int copy_masks(bossx_engine *h, uint8_t *dst, bool bits) {
     return BOSSX_OK;
 }
 
-namespace { int dist_finish_impl(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, bossx_update_result *res, bool bits); }
+namespace { int dist_finish_impl(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, bossx_update_result *res, bool bits, int mode = 0); }
 
 int bossx_dist_finish(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, bossx_update_result *res) {
     return dist_finish_impl(h, strat_all, contig_on, res, false);
 }
 
 namespace {
-int dist_finish_impl(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, bossx_update_result *res, bool bits) {
+// mode 0: masks + results, waited for; 1: enqueued only (bossx_dist_update_launch); 2: wait and read (bossx_dist_update_collect)
+int dist_finish_impl(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, bossx_update_result *res, bool bits, int mode) {
     if (!h || !h->finalized || !res) return fail(h, BOSSX_E_INVALID, "bad dist_finish call");
     HIPCHK(hipSetDevice(h->cfg.device));
+    int rc = BOSSX_OK;
+    if (mode != 2) {
     { int jrc = settle_chain(h); if (jrc) return jrc; }
     h->sweep_in_flight = false;
-    int rc;
     if (h->dist_pick_fused) {
         PickParams PP;
         PP.counts = h->d_stats; PP.fgrid = h->d_stats + BOSSX_HIST_BINS; PP.ubar = h->d_stats + BOSSX_HIST_BINS * 3;
@@ -2052,14 +2054,18 @@ int dist_finish_impl(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, bo
         rc = launch_mask(h, 1, true);
     }
     if (rc) return rc;
+    }
     const size_t need = h->result_bytes;
     if ((rc = ensure_pin(h, need + 64))) return rc;
     char *pin = static_cast<char *>(h->h_pin);
     Ctrl *hc = reinterpret_cast<Ctrl *>(pin);
     int32_t *herr = reinterpret_cast<int32_t *>(pin + sizeof(Ctrl));
     uint8_t *hon = reinterpret_cast<uint8_t *>(pin + sizeof(Ctrl) + 16);
-    HIPCHK(hipMemcpyAsync(pin, h->d_result, h->result_bytes, hipMemcpyDeviceToHost, h->stream));
-    if (strat_all && (rc = copy_masks(h, strat_all, bits))) return rc;
+    if (mode != 2) {
+        HIPCHK(hipMemcpyAsync(pin, h->d_result, h->result_bytes, hipMemcpyDeviceToHost, h->stream));
+        if (strat_all && (rc = copy_masks(h, strat_all, bits))) return rc;
+    }
+    if (mode == 1) return BOSSX_OK;
     HIPCHK(hipStreamSynchronize(h->stream));
     note_spec_result(h, herr);
     if (*herr) {
@@ -2168,12 +2174,22 @@ int bossx_dist_chain(bossx_engine *h, const int32_t *windows, const double *mult
     return bossx_update_benefit(h, windows, mult);                                                            // gated on the (now global) flag
 }
 
-int bossx_dist_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all, uint8_t *contig_on,
-                      bossx_update_result *res) {
+namespace {
+int dist_update_run(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all, uint8_t *contig_on,
+                    bossx_update_result *res, int mode) {
     if (!h || !h->finalized || !up || !res) return fail(h, BOSSX_E_INVALID, "bad dist_update call");
     if (!h->comm) return fail(h, BOSSX_E_INVALID, "dist_update before bossx_dist_init");
     HIPCHK(hipSetDevice(h->cfg.device));
     int rc;
+    if (mode == 2) {
+        const bool have_inputs = up->fhat_c != nullptr || ((up->flags & BOSSX_UPDATE_FHAT_RESIDENT) != 0);
+        rc = dist_finish_impl(h, strat_all, contig_on, res, (up->flags & BOSSX_UPDATE_STRAT_BITS) != 0, 2);
+        if (rc) return rc;
+        if (res->any_on) h->dist_armed = true;
+        if (!have_inputs) res->updated = 0;
+        return BOSSX_OK;
+    }
+    if (mode == 1 && h->chain_on_stream2) mode = 0;
     if (!(up->flags & BOSSX_UPDATE_SWEEP_DONE) && (rc = bossx_update_begin(h, up->bucket_threshold))) return rc;
     const bool fhat_resident = (up->flags & BOSSX_UPDATE_FHAT_RESIDENT) != 0 && up->fhat_c == nullptr;
     const bool have_strategy_inputs = up->fhat_c != nullptr || fhat_resident;
@@ -2192,11 +2208,38 @@ int bossx_dist_update(bossx_engine *h, const bossx_update_params *up, uint8_t *s
         if ((rc = dist_allreduce(h, h->d_limbs, size_t(BOSSX_HIST_BINS + 1) * 5, ncclInt64, ncclSum))) return rc;
         if ((rc = bossx_dist_pick(h, up->tc))) return rc;
     }
-    rc = dist_finish_impl(h, strat_all, contig_on, res, (up->flags & BOSSX_UPDATE_STRAT_BITS) != 0);
+    rc = dist_finish_impl(h, strat_all, contig_on, res, (up->flags & BOSSX_UPDATE_STRAT_BITS) != 0, mode);
     if (rc) return rc;
+    if (mode == 1) { h->upd_launched = true; return BOSSX_OK; }
     if (res->any_on) h->dist_armed = true;
     if (!have_strategy_inputs) res->updated = 0;
     return BOSSX_OK;
+}
+}  // namespace
+
+int bossx_dist_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all, uint8_t *contig_on,
+                      bossx_update_result *res) {
+    if (h && h->upd_launched) return fail(h, BOSSX_E_INVALID, "bossx_dist_update while a launched update has not been collected");
+    return dist_update_run(h, up, strat_all, contig_on, res, 0);
+}
+
+int bossx_dist_update_launch(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all, uint8_t *contig_on,
+                             bossx_update_result *res) {
+    if (h && h->upd_launched) return fail(h, BOSSX_E_INVALID, "an update is already launched: collect it first");
+    if (h) h->upd_done = false;
+    int rc = dist_update_run(h, up, strat_all, contig_on, res, 1);
+    if (rc == BOSSX_OK && h && !h->upd_launched) h->upd_done = true;
+    if (rc != BOSSX_OK && h) { h->upd_launched = false; h->upd_done = false; }
+    return rc;
+}
+
+int bossx_dist_update_collect(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all, uint8_t *contig_on,
+                              bossx_update_result *res) {
+    if (!h) return BOSSX_E_INVALID;
+    if (h->upd_done) { h->upd_done = false; return BOSSX_OK; }
+    if (!h->upd_launched) return fail(h, BOSSX_E_INVALID, "no launched update to collect");
+    h->upd_launched = false;
+    return dist_update_run(h, up, strat_all, contig_on, res, 2);
 }
 
 int bossx_host_alloc(bossx_engine *h, size_t bytes, void **ptr) {

@@ -495,7 +495,16 @@ class Engine:
             fg = np.zeros((_lib.HIST_BINS, 2), dtype=np.uint64)
             ub = np.zeros(2, dtype=np.uint64)
         if dist:        # bossx_dist_update: the same update with the library's own RCCL collectives between the stages
-            self._ck(self.lib.bossx_dist_update(self.h, C.byref(up), masks.ctypes.data, on.ctypes.data, C.byref(res)))
+            a = (self.h, C.byref(up), masks.ctypes.data, on.ctypes.data, C.byref(res))
+            if between is None:
+                self._ck(self.lib.bossx_dist_update(*a))
+            else:
+                self._ck(self.lib.bossx_dist_update_launch(*a))
+                try:
+                    between()
+                finally:
+                    rc = self.lib.bossx_dist_update_collect(*a)
+                self._ck(rc)
         else:
             a = (self.h, C.byref(up), masks.ctypes.data, on.ctypes.data, C.byref(res), None if counts is None else counts.ctypes.data,
                  None if fg is None else fg.ctypes.data, None if ub is None else ub.ctypes.data)

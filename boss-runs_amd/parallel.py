@@ -240,8 +240,13 @@ class DistributedBossRuns(BossRuns):
             read_lengths = np.array([len(s) for s in new_reads.values()], dtype=np.int64)
         self.begin_update()
         self.account_batch(summ, read_lengths, len(new_reads))      # (launches the chain once the global read lengths are known)
-        self._stage_ahead(kw.get("lookahead"))       # the next batch, staged while this one's chain runs (runs.py)
-        self.update_wrapper()
+        la = kw.get("lookahead")
+        if la is not None and getattr(self, "native", False):
+            # the whole update, collectives included, is in the queue before the next batch is staged (runs.py)
+            self._update_native(between=lambda: self._stage_ahead(la))
+        else:
+            self._stage_ahead(la)       # the next batch, staged while this one's chain runs
+            self.update_wrapper()
 
     def account_batch(self, summ, read_lengths, n_reads):
         """Make the read-length distribution, read-start counts and abundance counts global:
@@ -365,7 +370,7 @@ class DistributedBossRuns(BossRuns):
         if self.write_masks and self.comm.rank == 0:
             self._write_contig_strategies(contig_strats=self.ref.get_strategy_dict())
 
-    def _update_native(self) -> None:
+    def _update_native(self, between=None) -> None:
         """The update as ONE library call (bossx_dist_update): RCCL all-reduces issued by the library between its
         own kernels — MAX of the armed flag (until some strategy is on), MAX over halo rows + normaliser, SUM of
         the exact histogram limbs — one synchronisation at the end."""
@@ -378,12 +383,13 @@ class DistributedBossRuns(BossRuns):
             windows = np.concatenate(([400 // 100], self.rl_dist.approx_ccl // 100)).astype(np.int32)
             if self.read_starts._engine is not None:
                 res = eng.update(thr_b, windows, MULT, tc=self.rl_dist.time_cost // 100,
-                                 fhat_model=self.read_starts.fhat_model(), dist=True)
+                                 fhat_model=self.read_starts.fhat_model(), dist=True, between=between)
             else:
                 fhat_c, target_rs = self.read_starts.fhat_compact()
-                res = eng.update(thr_b, windows, MULT, tc=self.rl_dist.time_cost // 100, fhat_c=fhat_c, target_rs=target_rs, dist=True)
+                res = eng.update(thr_b, windows, MULT, tc=self.rl_dist.time_cost // 100, fhat_c=fhat_c, target_rs=target_rs, dist=True,
+                                 between=between)
         else:
-            res = eng.update(thr_b, dist=True)
+            res = eng.update(thr_b, dist=True, between=between)
         for cont in self.local_filt.values():
             if res["contig_on"][cont.index]:
                 cont.switched_on[:] = True

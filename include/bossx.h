@@ -322,6 +322,12 @@ int bossx_dist_chain(bossx_engine *h, const int32_t *windows, const double *mult
 int bossx_dist_update(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all, uint8_t *contig_on,
                       bossx_update_result *res);
 /* Collectives issued through this engine's communicator so far (measurement).                         */
+/* bossx_dist_update in two calls, like bossx_update_launch / _collect: everything — collectives included — is enqueued
+ * by _launch; the caller stages the next batch; _collect (same arguments) waits and fills the results.              */
+int bossx_dist_update_launch(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all, uint8_t *contig_on,
+                             bossx_update_result *res);
+int bossx_dist_update_collect(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all, uint8_t *contig_on,
+                              bossx_update_result *res);
 int64_t bossx_dist_collectives(const bossx_engine *h);
 
 /* The benefit chain (calc_smu + calc_u, reference.py:215-269) runs chunk-parallel by default: candidate start

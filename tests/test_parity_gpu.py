@@ -175,9 +175,13 @@ def test_distributed_protocol_single_rank_nccl(in_tmp, monkeypatch, mode):
         if d.instream:
             assert d.tstream.cuda_stream != 0      # the engine really shares torch's stream
         f = _product(1, 1, in_tmp)
+        batches = [e2e_batch(contigs, b, 1) for b in range(4)]
         for b in range(3):
-            batch = e2e_batch(contigs, b, 1)
-            d.process_batch_paf(batch["paf"], batch["seqs"], read_lengths=batch["read_lengths"])
+            batch = batches[b]
+            # (every form also stages the next batch ahead; the native one enqueues the whole update, collectives
+            # included, first: bossx_dist_update_launch / _collect)
+            d.process_batch_paf(batch["paf"], batch["seqs"], read_lengths=batch["read_lengths"],
+                                lookahead=(batches[b + 1]["paf"], batches[b + 1]["seqs"]))
             f.rl_dist.update(batch["read_lengths"])
             f.process_batch_paf(batch["paf"], batch["seqs"])
             assert d.threshold == f.threshold
