@@ -642,11 +642,17 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
         // table, 0.27 us per chunk of the longest contig for the stitch and 22 us per round of 256 segments.  Many short
         // chains (10 x 5 Mb x 8 barcodes: 160 blocks of 50 k bins) are better off serial; BOSSX_CHAIN_SPEC=2 forces the form.
         {
-            int64_t segs = 0;
-            for (size_t k = 0; k < h->filt.size(); ++k) segs += (h->contigs[size_t(h->filt[k])].T + 1 + kSpecSeg - 1) / kSpecSeg;
-            const double blocks = double(h->filt.size()) * nb * 2;
-            h->spec_est_serial_us = 3.9e-3 * double(max_bins) * std::ceil(blocks / 256.0);
-            h->spec_est_us = 5.2e-3 * double(h->spec_total) * nb * 2 * BOSSX_NWIN + 0.27 * double((max_bins + kSpecL - 1) / kSpecL) +
+            // (this device's own contigs only: a rank of a multi-GPU run registers every contig but walks its own)
+            int64_t segs = 0, chunks = 0, longest = 0, n_local = 0;
+            for (size_t k = 0; k < h->filt.size(); ++k) {
+                const ContigInfo &c = h->contigs[size_t(h->filt[k])];
+                if (c.remote) continue;
+                segs += (c.T + 1 + kSpecSeg - 1) / kSpecSeg; chunks += (c.T + 1 + kSpecL - 1) / kSpecL;
+                longest = std::max<int64_t>(longest, c.T + 1); ++n_local;
+            }
+            const double blocks = double(n_local) * nb * 2;
+            h->spec_est_serial_us = 3.9e-3 * double(longest) * std::ceil(blocks / 256.0);
+            h->spec_est_us = 5.2e-3 * double(chunks) * nb * 2 * BOSSX_NWIN + 0.27 * double((longest + kSpecL - 1) / kSpecL) +
                              22.0 * std::ceil(double(segs) * nb * 2 / 256.0) + 30.0;
             const char *e = getenv("BOSSX_CHAIN_SPEC");
             if (!(e && atoi(e) == 2) && h->spec_est_us > 0.7 * h->spec_est_serial_us) h->chain_spec = false;
