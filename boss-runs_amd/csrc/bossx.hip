@@ -1515,7 +1515,7 @@ void note_spec_result(bossx_engine *h, const int32_t *herr) {
     // next to uncapped regions).  Each costs ~4 us on ONE wave; beyond ~2 % of a chain's chunks the serial kernel wins.
     const int64_t plain = herr[1];
     h->spec_plain_total += plain;
-    if (plain * 50 > h->spec_total * int64_t(h->nb) * 2 * BOSSX_NWIN) h->spec_pause = 8;
+    if (plain * 50 > h->spec_total * int64_t(h->nb) * 2 * BOSSX_NWIN && !getenv("BOSSX_SPEC_NO_PAUSE")) h->spec_pause = 8;      // (the switch: tests)
     h->spec_mismatches = herr[2];                   // (cumulative: launches whose serial fallback ran)
     if (h->spec_mismatches >= 3) h->chain_spec = false;
 }

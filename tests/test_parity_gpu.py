@@ -1340,3 +1340,46 @@ def test_chunk_parallel_chain_vs_oracle(in_tmp, monkeypatch, mode):
     else:
         assert st["chunk_parallel_launches"] == 0, st
     runs.engine.close()
+
+
+@pytest.mark.gpu
+def test_chunk_parallel_chain_into_saturation_equals_serial(in_tmp, monkeypatch):
+    """Thirty updates of 5x each on a 2.1-Mb genome: coverage passes depth 30 everywhere, bin sums become a mix of
+    `tiny` and ordinary values — chunks that climb dozens of binades, cut chunks, chunks the stitch adds the plain
+    way (the pause that would send such launches to the serial kernel is switched off here).  The chunk-parallel chain (forced) must equal the
+    serial kernel (which the other tests hold against the oracle) in every update: thresholds, benefits, masks."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.runs import BossRuns
+    lens = [1_500_000, 610_000]
+    contigs = synth.make_reference(lens, seed=131, names=["sa0", "sa1"])
+    strs = [(n, synth.codes_to_str(c)) for n, c in contigs]
+
+    monkeypatch.setenv("BOSSX_SPEC_NO_PAUSE", "1")       # every launch chunk-parallel, however many chunks are plain
+
+    def make(name, spec):
+        monkeypatch.setenv("BOSSX_CHAIN_SPEC", spec)
+        args = BossConfig()
+        args.general.name = name
+        args.optional.bucket_threshold = 0
+        r = BossRuns(args)
+        r.init(contigs=strs)
+        return r
+
+    a = make("sat_spec", "2")
+    b = make("sat_serial", "0")
+    for u in range(30):
+        batch = synth.make_batch(contigs, 1800, seed=13100 + u, mean_len=6000.0, nbarcodes=1)
+        for r in (a, b):
+            r.rl_dist.update(batch["read_lengths"])
+            r.process_batch_paf(batch["paf"], batch["seqs"])
+        assert a.threshold == b.threshold, u
+        for n in ("sa0", "sa1"):
+            assert np.array_equal(a.contigs[n].additional_benefit, b.contigs[n].additional_benefit), (u, n)
+            assert np.array_equal(a.contigs[n].strat, b.contigs[n].strat), (u, n)
+    st = a.engine.chain_stats()
+    assert st["failed_checks"] == 0 and st["chunk_parallel_launches"] >= 29 and st["chunks_added_plainly"] > 100, st
+    cov = np.asarray(a.contigs["sa0"].coverage).sum(axis=1).ravel()
+    assert np.median(cov) >= 30                                   # the genome did saturate
+    assert b.engine.chain_stats()["chunk_parallel_launches"] == 0
+    a.engine.close(); b.engine.close()
