@@ -155,8 +155,13 @@ struct bossx_engine {
     bool dz_fresh = false;          // the last sweep may have zeroed sites by dropout for the first time (see launch_sweep)
     std::unordered_map<const void *, size_t> lds_granted;   // dynamic LDS each chain kernel has been cleared for ON THIS DEVICE
     std::vector<int32_t> last_thr;  // dropout threshold each contig was last swept with
-    uint32_t *d_tile_cov = nullptr; // [nb][n_tiles] depth total of each tile at its last sweep
     uint32_t *d_tile_ref = nullptr;
+    // persistent sweep blocks: hand-out counters of the launches of one update (zeroed by its prep launch), behind them
+    // the count of 16-byte counter vectors the ingesting tiles wrote back (8-byte aligned); blocks per launch by instantiation
+    uint32_t *d_work_ctr = nullptr; int32_t n_work_ctr = 0, work_ctr_used = 0;
+    uint32_t sweep_grid[2][2] = {{0, 0}, {0, 0}};      // [INGEST][ENT]: CUs x resident blocks
+    uint32_t sweep_chunk = 0;           // BOSSX_SWEEP_CHUNK: consecutive items per hand-out (0: by launch size)
+    double sweep_bytes_base = 0;        // bytes of the last sweep without its counter write-back (added when the count is read)
     // device CIGAR walk (front_end.hip.inc): staging scratch shared by all slots
     char *h_paf_pin = nullptr; size_t paf_pin_cap = 0;        // PAF text, page-locked
     char *d_paf = nullptr; size_t d_paf_cap = 0;
@@ -288,7 +293,7 @@ SweepParams sweep_params(bossx_engine *h) {
         const bossx_engine::Staged &st = h->slots[size_t(h->pending_slot)];
         P.tiles = st.d_tilerefs; P.n_groups = uint32_t(st.pb.tiles.size()); P.pieces = st.d_pieces; P.codes = st.d_codes;
     }
-    P.ds = h->d_ds; P.bucket_sums = h->d_bucket_sums; P.tile_cov = h->d_tile_cov; P.n_tiles = h->n_tiles;
+    P.ds = h->d_ds; P.bucket_sums = h->d_bucket_sums; P.n_tiles = h->n_tiles;
     P.lut_score = h->d_lut_score; P.lut_ent = h->d_lut_ent; P.ct = table_of(h);
     P.Gp = h->Gp; P.B = h->B; P.NBK = h->NBK; P.nb = h->nb;
     P.score0 = h->score0; P.tiny = std::numeric_limits<double>::min();
@@ -296,6 +301,8 @@ SweepParams sweep_params(bossx_engine *h) {
     P.publish = h->sweep_published ? 1 : 0;
     P.dense = 0; P.ingest_only = 0; P.ingest_first = 0; P.tile_base = 0;
     P.order = h->d_tile_order;
+    P.work_ctr = nullptr; P.n_work = 0; P.chunk = 1;
+    P.wb_count = h->timing ? reinterpret_cast<unsigned long long *>(h->d_work_ctr + h->n_work_ctr) : nullptr;
     return P;
 }
 
@@ -474,12 +481,13 @@ void bossx_destroy(bossx_engine *h) {
     if (h->d_tile_contig) hipFree(h->d_tile_contig);
     void *ptrs[] = {h->d_state, h->d_touched, h->d_strat, h->d_bucket_on, h->d_entropy, h->d_ds,
                     h->d_benefit, h->d_lut_score, h->d_lut_ent, h->d_fhat, h->d_bucket_sums, h->d_drop_count,
-                    h->d_stats, h->d_tile_cov, h->d_tails /* base of the tails + result block */, h->d_tile_off, h->d_site_off, h->d_length, h->d_bin_off, h->d_row_off,
+                    h->d_stats, h->d_tails /* base of the tails + result block */, h->d_tile_off, h->d_site_off, h->d_length, h->d_bin_off, h->d_row_off,
                     h->d_strat_off, h->d_bucket_off, h->d_drop_thr, h->d_local, h->d_limbs,
                     h->d_strat_bits};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &st : h->slots) { if (st.ev_ready) hipEventDestroy(st.ev_ready); if (st.d_ops) hipFree(st.d_ops); if (st.d_tiles) hipFree(st.d_tiles); if (st.d_blob) hipFree(st.d_blob); if (st.d_segs) hipFree(st.d_segs); if (st.d_tilerefs) hipFree(st.d_tilerefs); if (st.d_codes) hipFree(st.d_codes); if (st.d_pieces) hipFree(st.d_pieces); }
     if (h->d_tile_ref) hipFree(h->d_tile_ref);
+    if (h->d_work_ctr) hipFree(h->d_work_ctr);
     if (h->h_pin) hipHostFree(h->h_pin);
     if (h->h_paf_pin) hipHostFree(h->h_paf_pin);
     if (h->h_plan_pin) hipHostFree(h->h_plan_pin);
@@ -577,7 +585,7 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
     if (uint64_t(h->Gp) >= (1ull << 40)) return fail(h, BOSSX_E_INVALID, "reference too large");
 
     int rc;
-    if ((rc = dev_alloc(h, &h->d_state, size_t(std::max<int64_t>(h->n_tiles, 1)) * size_t(nb) * size_t(kTileStride), true))) return rc;
+    if ((rc = dev_alloc(h, &h->d_state, size_t(std::max<int64_t>(h->n_tiles, 1)) * size_t(nb) * size_t(kTileStride) + 256, true))) return rc;
     if ((rc = dev_alloc(h, &h->d_touched, size_t(h->Gp), true))) return rc;
     if (h->cfg.track_entropy) {
         if ((rc = dev_alloc(h, &h->d_entropy, size_t(nb * h->Gp)))) return rc;
@@ -600,7 +608,7 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
         }
         // tile -> contig (one load instead of a binary search over the contig table), and the identity the
         // sweep's early loads rely on: a tile's first site is tile * kTileSites
-        std::vector<uint16_t> tc(size_t(h->n_tiles > 0 ? h->n_tiles : 1), 0);
+        std::vector<uint16_t> tc((size_t(h->n_tiles > 0 ? h->n_tiles : 1) + 3) & ~size_t(1), 0);     // (read as dwords by the sweep)
         if (h->filt.size() > 65535) return fail(h, BOSSX_E_INVALID, "more than 65535 contigs");
         for (size_t k = 0; k < h->filt.size(); ++k) {
             const ContigInfo &c = h->contigs[size_t(h->filt[k])];
@@ -678,8 +686,30 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
     if ((rc = dev_alloc(h, &h->d_bucket_on, size_t(nb * h->NBK), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_bucket_sums, size_t(nb * h->NBK), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_drop_count, size_t(h->n_tiles), true))) return rc;
-    if ((rc = dev_alloc(h, &h->d_tile_cov, size_t(nb) * size_t(h->n_tiles > 0 ? h->n_tiles : 1), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_tile_ref, size_t(h->n_tiles), true))) return rc;
+    h->n_work_ctr = int32_t((h->filt.size() + 8 + 1) & ~size_t(1));       // one per launch of an update: re-swept contigs + the tile / group launches
+    if ((rc = dev_alloc(h, &h->d_work_ctr, size_t(h->n_work_ctr) + 2, true))) return rc;
+    {
+        // persistent sweep blocks: as many as are resident at once (BOSSX_SWEEP_BLOCKS_PER_CU overrides the occupancy query)
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, h->cfg.device));
+        const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        const bool multi = h->nb > 1;
+        const void *fn[2][2] = {{multi ? reinterpret_cast<const void *>(site_sweep_kernel<false, false, true>) : reinterpret_cast<const void *>(site_sweep1_kernel<false, false>),
+                                 multi ? reinterpret_cast<const void *>(site_sweep_kernel<false, true, true>) : reinterpret_cast<const void *>(site_sweep1_kernel<false, true>)},
+                                {multi ? reinterpret_cast<const void *>(site_sweep_kernel<true, false, true>) : reinterpret_cast<const void *>(site_sweep1_kernel<true, false>),
+                                 multi ? reinterpret_cast<const void *>(site_sweep_kernel<true, true, true>) : reinterpret_cast<const void *>(site_sweep1_kernel<true, true>)}};
+        if (const char *ce = getenv("BOSSX_SWEEP_CHUNK")) h->sweep_chunk = uint32_t(std::max(atoi(ce), 0));
+        const char *e = getenv("BOSSX_SWEEP_BLOCKS_PER_CU");
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b) {
+                int per_cu = 0;
+                if (e && atoi(e) > 0) per_cu = atoi(e);
+                else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn[a][b], 256, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 4; }
+                h->sweep_grid[a][b] = uint32_t(cus) * uint32_t(per_cu);
+                if (getenv("BOSSX_SWEEP_DEBUG")) fprintf(stderr, "[bossx] sweep<%d,%d>: %d CUs x %d resident blocks\n", a, b, cus, per_cu);
+            }
+    }
     if ((rc = dev_alloc(h, &h->d_stats, size_t(BOSSX_HIST_BINS * 3 + 4 + 128), true))) return rc;
     // One allocation: [halo tails | control block | error flag | per-contig switches].  The tails sit
     // right before the control block, whose first field is the running maximum: the multi-GPU MAX
@@ -758,8 +788,42 @@ int bossx_set_lut(bossx_engine *h, const double *score, const double *entropy, i
     if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "set_lut before finalize");
     if (n != int64_t(BOSSX_NCOMP) * 4 || !score || !entropy) return fail(h, BOSSX_E_INVALID, "LUT must have NCOMP*4 entries");
     HIPCHK(hipSetDevice(h->cfg.device));
-    HIPCHK(hipMemcpy(h->d_lut_score, score, size_t(n) * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_lut_ent, entropy, size_t(n) * sizeof(double), hipMemcpyHostToDevice));
+    // The caller's tables are indexed like the reference's: rank(A, C, G, T, deletion) * 4 + reference base.  On the device
+    // the counter planes are reference-relative and ranked rare-first (engine.hpp, comp_rank): entry
+    // rank(deletion, plane 3, plane 2, plane 1, plane 0) * 4 + ref with plane k = count of base (ref + k) & 3 holds the
+    // SAME value — a permutation, every entry bit for bit the caller's.  (The four reference bases cannot share one entry:
+    // numpy sums the genotypes in a fixed order, so relabelling the bases changes last bits — 42,122 of the 278,256
+    // haploid rows and 2,610 of the diploid ones are bit-equal across the four bases, tests/test_host_logic.py.)
+    {
+        auto C = [](uint32_t q, uint32_t k) { uint64_t v = 1; if (q < k) return uint64_t(0); for (uint32_t i = 0; i < k; ++i) v = v * (q - i) / (i + 1); return v; };
+        uint64_t bn[6][40];
+        for (uint32_t k = 0; k < 6; ++k) for (uint32_t q = 0; q < 40; ++q) bn[k][q] = C(q, k);
+        auto rank5 = [&](const uint32_t x[5]) {
+            const uint32_t p1 = x[0], p2 = p1 + x[1], p3 = p2 + x[2], p4 = p3 + x[3], p5 = p4 + x[4];
+            return size_t(bn[1][p1] + bn[2][p2 + 1] + bn[3][p3 + 2] + bn[4][p4 + 3] + bn[5][p5 + 4]);
+        };
+        std::vector<double> ds, de;
+        ds.resize(size_t(n)); de.resize(size_t(n));
+        size_t seen = 0;
+        uint32_t c[5];
+        for (c[0] = 0; c[0] < BOSSX_MAXCOV; ++c[0])
+            for (c[1] = 0; c[0] + c[1] < BOSSX_MAXCOV; ++c[1])
+                for (c[2] = 0; c[0] + c[1] + c[2] < BOSSX_MAXCOV; ++c[2])
+                    for (c[3] = 0; c[0] + c[1] + c[2] + c[3] < BOSSX_MAXCOV; ++c[3])
+                        for (c[4] = 0; c[0] + c[1] + c[2] + c[3] + c[4] < BOSSX_MAXCOV; ++c[4]) {
+                            const size_t src = rank5(c);
+                            for (uint32_t r = 0; r < 4; ++r) {
+                                const uint32_t x[5] = {c[4], c[(r + 3) & 3], c[(r + 2) & 3], c[(r + 1) & 3], c[r]};
+                                const size_t dst = rank5(x);
+                                ds[dst * 4 + r] = score[src * 4 + r];
+                                de[dst * 4 + r] = entropy[src * 4 + r];
+                                ++seen;
+                            }
+                        }
+        if (seen != size_t(n)) return fail(h, BOSSX_E_INVALID, "internal: composition count");
+        HIPCHK(hipMemcpy(h->d_lut_score, ds.data(), size_t(n) * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_lut_ent, de.data(), size_t(n) * sizeof(double), hipMemcpyHostToDevice));
+    }
     // the three values of the scores array that are not table entries (site_sweep_kernel selects an index, not a value)
     const double extra[4] = {h->score0, std::numeric_limits<double>::min(), 0.0, 0.0};
     HIPCHK(hipMemcpy(h->d_lut_score + size_t(n), extra, sizeof(extra), hipMemcpyHostToDevice));
@@ -1290,10 +1354,24 @@ int bossx_ingest_paf(bossx_engine *h, const char *paf, size_t paf_len, const cha
 
 namespace {
 // the entropy-tracking variant is a separate instantiation: the default (no entropy array) carries no code for it
+// One launch over `n_items` work items (tiles or groups): persistent blocks that take items from a counter, except
+// when the launch publishes tiles to a chain running next to it (those keep one block per item, in walk order).
 #define LAUNCH_SWEEP(ING, grid, block, lds, stream, P)                                                    \
     do {                                                                                                  \
-        if (h->d_entropy) hipLaunchKernelGGL((site_sweep_kernel<ING, true>), grid, block, lds, stream, P); \
-        else hipLaunchKernelGGL((site_sweep_kernel<ING, false>), grid, block, lds, stream, P);            \
+        const uint32_t n_items_ = (grid).x;                                                               \
+        const bool ent_ = h->d_entropy != nullptr;                                                        \
+        (P).n_work = n_items_;                                                                            \
+        (P).work_ctr = ((P).publish || getenv("BOSSX_SWEEP_ONE_PER_BLOCK") || h->work_ctr_used >= h->n_work_ctr) ? nullptr : h->d_work_ctr + h->work_ctr_used++; \
+        const uint32_t res_ = h->sweep_grid[ING ? 1 : 0][ent_ ? 1 : 0];                                   \
+        (P).chunk = h->sweep_chunk ? h->sweep_chunk : std::min<uint32_t>(8u, std::max<uint32_t>(1u, n_items_ / (2u * res_))); \
+        const uint32_t blocks_ = (P).work_ctr ? std::min((n_items_ + (P).chunk - 1u) / (P).chunk, res_) : n_items_; \
+        if (h->nb > 1) {                                                                                  \
+            if (ent_) hipLaunchKernelGGL((site_sweep_kernel<ING, true, true>), dim3(blocks_), block, lds, stream, P); \
+            else hipLaunchKernelGGL((site_sweep_kernel<ING, false, true>), dim3(blocks_), block, lds, stream, P); \
+        } else {                                                                                          \
+            if (ent_) hipLaunchKernelGGL((site_sweep1_kernel<ING, true>), dim3(blocks_), block, lds, stream, P); \
+            else hipLaunchKernelGGL((site_sweep1_kernel<ING, false>), dim3(blocks_), block, lds, stream, P); \
+        }                                                                                                 \
     } while (0)
 int launch_sweep(bossx_engine *h) {
     // dropout thresholds of this update: mean depth per contig (reference.py:157-158, 174-176)
@@ -1374,6 +1452,8 @@ int launch_sweep(bossx_engine *h) {
         PR.tiles = nullptr; PR.n_tiles = 0; PR.tile_ref = h->d_tile_ref;
         PR.tile_done = h->d_tile_done; PR.n_all = h->n_tiles; PR.full = full ? 1 : 0;
         PR.mark = publish ? 1 : 0;
+        PR.work_ctr = h->d_work_ctr; PR.n_ctr = h->n_work_ctr + 2;      // (+ the write-back count behind them)
+        h->work_ctr_used = 0;
         if (h->pending_slot >= 0) {
             const bossx_engine::Staged &st = h->slots[size_t(h->pending_slot)];
             PR.tiles = st.d_tilerefs; PR.n_tiles = uint32_t(st.pb.tiles.size());
@@ -1443,18 +1523,21 @@ int launch_sweep(bossx_engine *h) {
     }
     double bytes = sites * h->nb * 11.0 + bins * h->nb * 8.0;
     if (h->touched_dirty || split) bytes += sites;
-    if (h->pending_slot >= 0) bytes += 3.0 * h->pending_emit;      // (the emit runs are read by expand_codes_kernel, not by the sweep)
+    if (h->pending_slot >= 0) bytes += 1.0 * h->pending_emit;      // one code byte per ingested base (the emit runs are read by expand_codes_kernel, not by the sweep)
+    // the counter write-back is counted at the granularity it happens at — 16-byte vectors of changed counters, counted by the
+    // kernel itself while timing is on — and added when the count is read (bossx_kernel_bytes)
+    h->sweep_bytes_base = bytes;
     time_end(h, BOSSX_K_SWEEP, bytes);
     HIPCHK(hipGetLastError());
     if (P.probe) {
         unsigned long long pr[24];
         HIPCHK(hipMemcpy(pr, P.probe, sizeof(pr), hipMemcpyDeviceToHost));
         HIPCHK(hipMemset(P.probe, 0, sizeof(pr)));
-        fprintf(stderr, "[sweep probe] plain: %llu blocks, %.0f cycles each | ingest: %llu blocks, %.0f cycles each (expand %.0f, apply %.0f), %.1f segs/tile\n",
-                pr[0], pr[0] ? double(pr[1]) / pr[0] : 0.0, pr[8], pr[8] ? double(pr[9]) / pr[8] : 0.0,
-                pr[8] ? double(pr[10]) / pr[8] : 0.0, pr[8] ? double(pr[11]) / pr[8] : 0.0, pr[8] ? double(pr[12]) / pr[8] : 0.0);
-        if (pr[16]) fprintf(stderr, "[sweep probe] per wave-round (%llu rounds): stage %.0f, search+issue %.0f, prefetch %.0f, accumulate %.0f cycles\n",
-                            pr[16], double(pr[17]) / pr[16], double(pr[18]) / pr[16], double(pr[19]) / pr[16], double(pr[20]) / pr[16]);
+        for (int o = 0; o <= 8; o += 8)
+            if (pr[o])
+                fprintf(stderr, "[sweep probe] %s: %llu items (wave 0 of each block), cycles per item: top..codes gathered %.0f | ..scored (phase A, next tile's loads issued) %.0f | barrier %.0f | phase B %.0f | tail %.0f | total %.0f\n",
+                        o ? "ingest" : "plain", pr[o], double(pr[o + 1]) / pr[o], double(pr[o + 2]) / pr[o], double(pr[o + 3]) / pr[o], double(pr[o + 4]) / pr[o],
+                        double(pr[o + 5]) / pr[o], double(pr[o + 1] + pr[o + 2] + pr[o + 3] + pr[o + 4] + pr[o + 5]) / pr[o]);
     }
     h->pending_slot = -1;
     h->touched_dirty = false;
@@ -2541,9 +2624,15 @@ int bossx_export(bossx_engine *h, int32_t contig, int32_t which, void *dst, size
     switch (which) {
         case 0: {
             if (!need(size_t(nb * 5 * L) * 2)) return fail(h, BOSSX_E_INVALID, "export buffer too small");
-            HIPCHK(hipStreamSynchronize(h->stream));
-            for (int64_t p = 0; p < nb * 5; ++p)
-                if ((rc = copy_site_field(h, c, int32_t(p / 5), int(p % 5) * kTilePlaneBytes, 2, static_cast<uint16_t *>(dst) + p * L, false))) return rc;
+            // the counter planes are reference-relative on the device: un-rotated into the reference's A C G T deletion order
+            uint16_t *tmp = nullptr;
+            if ((rc = dev_alloc(h, &tmp, size_t(nb * 5 * L)))) return rc;
+            hipLaunchKernelGGL(planes_convert_kernel, dim3(uint32_t(std::min<int64_t>((L + 255) / 256, 8192))), dim3(256), 0, h->stream,
+                               SiteState{h->d_state, h->nb}, h->nb, c.site_off, L, tmp, 0);
+            hipError_t e1 = hipMemcpyAsync(dst, tmp, size_t(nb * 5 * L) * 2, hipMemcpyDeviceToHost, h->stream);
+            hipError_t e2 = hipStreamSynchronize(h->stream);
+            hipFree(tmp);
+            HIPCHK(e1); HIPCHK(e2);
             break;
         }
         case 1: {
@@ -2626,10 +2715,17 @@ int bossx_import(bossx_engine *h, int32_t contig, int32_t which, const void *src
     switch (which) {
         case 0: {
             if (src_bytes != size_t(nb * 5 * L) * 2) return fail(h, BOSSX_E_INVALID, "import size mismatch");
-            HIPCHK(hipStreamSynchronize(h->stream));
-            for (int64_t p = 0; p < nb * 5; ++p)
-                if ((rc = copy_site_field(h, c, int32_t(p / 5), int(p % 5) * kTilePlaneBytes, 2,
-                                          const_cast<uint16_t *>(static_cast<const uint16_t *>(src) + p * L), true))) return rc;
+            {
+                // A C G T deletion planes -> the reference-relative planes of the site state (the state bytes hold the reference bases)
+                uint16_t *tmp = nullptr;
+                if ((rc = dev_alloc(h, &tmp, size_t(nb * 5 * L)))) return rc;
+                hipError_t e1 = hipMemcpyAsync(tmp, src, src_bytes, hipMemcpyHostToDevice, h->stream);
+                hipLaunchKernelGGL(planes_convert_kernel, dim3(uint32_t(std::min<int64_t>((L + 255) / 256, 8192))), dim3(256), 0, h->stream,
+                                   SiteState{h->d_state, h->nb}, h->nb, c.site_off, L, tmp, 1);
+                hipError_t e2 = hipStreamSynchronize(h->stream);
+                hipFree(tmp);
+                HIPCHK(e1); HIPCHK(e2);
+            }
             unsigned long long *d_tot = h->d_stats;
             HIPCHK(hipMemsetAsync(d_tot, 0, sizeof(unsigned long long), h->stream));
             hipLaunchKernelGGL(contig_total_kernel, dim3(1024), dim3(256), 0, h->stream, SiteState{h->d_state, h->nb}, h->nb,
@@ -2732,6 +2828,14 @@ int bossx_kernel_ms(bossx_engine *h, float *ms_last, double *ms_total, int64_t *
 
 int bossx_kernel_bytes(bossx_engine *h, double *bytes_last) {
     if (!h || !bytes_last) return BOSSX_E_INVALID;
+    if (h->timing && h->finalized && h->d_work_ctr) {
+        // the last sweep's counter write-back: 16 bytes per vector it actually wrote
+        HIPCHK(hipSetDevice(h->cfg.device));
+        time_collect(h);
+        unsigned long long wb = 0;
+        HIPCHK(hipMemcpy(&wb, h->d_work_ctr + h->n_work_ctr, sizeof(wb), hipMemcpyDeviceToHost));
+        h->bytes_last[BOSSX_K_SWEEP] = h->sweep_bytes_base + 16.0 * double(wb);
+    }
     for (int k = 0; k < BOSSX_K_COUNT; ++k) bytes_last[k] = h->bytes_last[k];
     return BOSSX_OK;
 }

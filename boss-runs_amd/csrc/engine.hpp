@@ -20,14 +20,23 @@ constexpr int kEmitTile = 2048;            // emitted reference bases per ingest
 constexpr int kSegMax = kTileSites;        // emitted bases per tile segment: one piece per (mapping, tile)
 
 // Per-site state in HBM, TILE-MAJOR: what a sweep block needs of one (tile, barcode) is ONE contiguous
-// record — five planes of kTileSites uint16 counters (A C G T deletion), then kTileSites state bytes —
+// record — five planes of kTileSites uint16 counters, then kTileSites state bytes.  The four base planes are
+// REFERENCE-RELATIVE: plane k (k < 4) of a site counts base (ref + k) & 3, ref = the site's reference base
+// (state bits 0-1); plane 4 counts deletions.  ~93 % of a batch's increments then land in plane 0, so the
+// 16-byte vectors of planes 1-4 mostly stay clean and are not written back, and every site's pattern looks
+// like (depth, few, few, few, few) whatever its base — the score table is indexed in that space (see
+// device_lut_index) and its hot entries are a few kilobytes.  bossx_export / _import un-rotate.
+// One record per (tile, barcode),
 // so a tile that receives bases costs one or two pages / DRAM rows instead of six, one in each of six
 // arrays of gigabytes (at 3.1 Gb the plane-major layout spent its time in address translation:
 // 1.5 ms for 16 k scattered tiles against 0.16 ms for as many tiles of a 110 Mb reference).
 constexpr int kTilePlaneBytes = kTileSites * 2;
 constexpr int kTileMetaOff = 5 * kTilePlaneBytes;
 constexpr int kTileStride = 22016;         // 22,000 bytes rounded up to whole 128-byte lines
-static_assert(kTileStride >= kTileMetaOff + kTileSites && kTileStride % 128 == 0, "tile record");
+// ... and in the 16 spare bytes behind the state bytes: the depth total of the (tile, barcode) at its last sweep (what the
+// sweep adds to a 20-kb bucket total is the CHANGE of it), so that it arrives with the tile's other loads
+constexpr int kTileTotalOff = kTileMetaOff + kTileSites;
+static_assert(kTileStride >= kTileTotalOff + 4 && kTileStride % 128 == 0, "tile record");
 
 // One emitting CIGAR run (M-like or D) of a chosen mapping, 16 bytes, loaded as one uint4.
 //   emit_start : index of its first emitted base in the batch-wide emit order
