@@ -695,9 +695,9 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
         HIPCHK(hipGetDeviceProperties(&prop, h->cfg.device));
         const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         const bool multi = h->nb > 1;
-        const void *fn[2][2] = {{multi ? reinterpret_cast<const void *>(site_sweep_kernel<false, false, true>) : reinterpret_cast<const void *>(site_sweep1_kernel<false, false>),
+        const void *fn[2][2] = {{multi ? reinterpret_cast<const void *>(site_sweep_kernel<false, false, true>) : reinterpret_cast<const void *>(site_sweep1_kernel<false, true>),
                                  multi ? reinterpret_cast<const void *>(site_sweep_kernel<false, true, true>) : reinterpret_cast<const void *>(site_sweep1_kernel<false, true>)},
-                                {multi ? reinterpret_cast<const void *>(site_sweep_kernel<true, false, true>) : reinterpret_cast<const void *>(site_sweep1_kernel<true, false>),
+                                {multi ? reinterpret_cast<const void *>(site_sweep_kernel<true, false, true>) : reinterpret_cast<const void *>(site_sweep1_kernel<true, true>),
                                  multi ? reinterpret_cast<const void *>(site_sweep_kernel<true, true, true>) : reinterpret_cast<const void *>(site_sweep1_kernel<true, true>)}};
         if (const char *ce = getenv("BOSSX_SWEEP_CHUNK")) h->sweep_chunk = uint32_t(std::max(atoi(ce), 0));
         const char *e = getenv("BOSSX_SWEEP_BLOCKS_PER_CU");
@@ -1364,13 +1364,15 @@ namespace {
         (P).work_ctr = ((P).publish || getenv("BOSSX_SWEEP_ONE_PER_BLOCK") || h->work_ctr_used >= h->n_work_ctr) ? nullptr : h->d_work_ctr + h->work_ctr_used++; \
         const uint32_t res_ = h->sweep_grid[ING ? 1 : 0][ent_ ? 1 : 0];                                   \
         (P).chunk = h->sweep_chunk ? h->sweep_chunk : std::min<uint32_t>(8u, std::max<uint32_t>(1u, n_items_ / (2u * res_))); \
-        const uint32_t blocks_ = (P).work_ctr ? std::min((n_items_ + (P).chunk - 1u) / (P).chunk, res_) : n_items_; \
+        /* (the one-barcode kernel splits the items evenly over its resident blocks; the several-barcode one hands runs out) */ \
+        const uint32_t blocks_ = (P).work_ctr ? (h->nb > 1 ? std::min((n_items_ + (P).chunk - 1u) / (P).chunk, res_) : std::min(n_items_, res_)) : n_items_; \
         if (h->nb > 1) {                                                                                  \
             if (ent_) hipLaunchKernelGGL((site_sweep_kernel<ING, true, true>), dim3(blocks_), block, lds, stream, P); \
             else hipLaunchKernelGGL((site_sweep_kernel<ING, false, true>), dim3(blocks_), block, lds, stream, P); \
         } else {                                                                                          \
-            if (ent_) hipLaunchKernelGGL((site_sweep1_kernel<ING, true>), dim3(blocks_), block, lds, stream, P); \
-            else hipLaunchKernelGGL((site_sweep1_kernel<ING, false>), dim3(blocks_), block, lds, stream, P); \
+            /* (one instantiation: the entropy stores are guarded by the array's presence at run time — the variant compiled */ \
+            /* without them came out of the register allocator 25 registers fatter and spilling) */     \
+            hipLaunchKernelGGL((site_sweep1_kernel<ING, true>), dim3(blocks_), block, lds, stream, P);    \
         }                                                                                                 \
     } while (0)
 int launch_sweep(bossx_engine *h) {
