@@ -75,24 +75,20 @@ struct bossx_engine {
     int chain_flow_ce = 2;          // the chain wave stores the carry into every CE-th step, the tail waves rebuild the others (BOSSX_FLOW_CE=1: all of them)
     bool chain_gc = false;          // BOSSX_CHAIN_GC=1: carries leave the chain wave through global stores (benefit_chain_flow_kernel<..., GC>) — measured slower (profiles/r03_chain_gc_experiment.txt), kept as an experiment
     double *d_carry_ring = nullptr; size_t carry_ring_cap = 0;
-    // move_sum as an exact parallel scan inside two-binade bands (movesum_scan_kernel + benefit_combine_kernel):
-    // BOSSX_CHAIN_SCAN=1.  Exact, but real bin sums leave a band every 8-500 bins (profiles/r03_chain_parallel.txt):
-    // an experiment, not the default.  Scratch: the eleven sums of every (barcode, strand, bin).
-    bool chain_scan = false;
     // The serial recurrence chunk-parallel (chain_candidates_kernel -> chain_stitch_kernel -> benefit_chain_kernel<SEG>): the
     // default chain; the serial kernel is enqueued behind it and runs only if a segment fails its check.  BOSSX_CHAIN_SPEC=0: serial only.
     bool chain_spec = true;
     bool last_chain_spec = false;      // the last chain launch was the chunk-parallel one
-    int32_t spec_mismatches = 0;       // segments whose end value differed from the stitched one (each costs a serial rerun); 3: off
+    int32_t spec_mismatches = 0;       // launches in which a segment's end value differed from the stitched one (each costs a serial rerun)
+    int32_t spec_recent_fail = 0, spec_since_decay = 0;      // ... of those, the recent ones (note_spec_result)
     bool upd_launched = false, upd_done = false, upd_mirrored = false;    // bossx_update_launch / _collect
     double spec_est_us = 0, spec_est_serial_us = 0;     // what finalize expects of the two forms of the chain (microseconds)
+    double spec_plain_share = 0;       // of all chunks the stitch adds the plain way, the fraction that falls on the longest chain's wave
     int32_t spec_pause = 0;            // updates left on the serial chain: too many chunks had to be added the plain way last time
     int64_t spec_plain_total = 0, spec_paused_updates = 0, spec_launches = 0;
     int64_t *d_chunk_off = nullptr; int64_t spec_total = 0, spec_max_segs = 0;
     double *d_spec_tab = nullptr, *d_spec_starts = nullptr;
     unsigned long long *d_spec_stats = nullptr;
-    double *d_scan_S = nullptr;
-    unsigned long long *d_scan_stats = nullptr;   // stretches | stretches ended early | plain-path rounds (BOSSX_CHAIN_PROBE)
     int32_t nb = 1;
 
     // native multi-GPU driver (bossx_dist_init): RCCL communicator of this engine's device
@@ -437,11 +433,6 @@ void bossx_destroy(bossx_engine *h) {
     if (!h) return;
     hipSetDevice(h->cfg.device);
     hipStreamSynchronize(h->stream);
-    if (h->d_scan_stats && getenv("BOSSX_SCAN_STATS")) {
-        unsigned long long st[4] = {0, 0, 0, 0};
-        if (hipMemcpy(st, h->d_scan_stats, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess)
-            fprintf(stderr, "[bossx] scan chain: %llu stretches, %llu ended early, %llu plain-path rounds\n", st[0], st[1], st[2]);
-    }
     if (h->comm) { rccl_destroy(h->comm); h->comm = nullptr; }
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
     if (h->stream_up) { hipStreamSynchronize(h->stream_up); hipStreamDestroy(h->stream_up); }
@@ -476,8 +467,6 @@ void bossx_destroy(bossx_engine *h) {
     if (h->d_spec_tab) hipFree(h->d_spec_tab);
     if (h->d_spec_starts) hipFree(h->d_spec_starts);
     if (h->d_spec_stats) hipFree(h->d_spec_stats);
-    if (h->d_scan_S) hipFree(h->d_scan_S);
-    if (h->d_scan_stats) hipFree(h->d_scan_stats);
     if (h->d_tile_contig) hipFree(h->d_tile_contig);
     void *ptrs[] = {h->d_state, h->d_touched, h->d_strat, h->d_bucket_on, h->d_entropy, h->d_ds,
                     h->d_benefit, h->d_lut_score, h->d_lut_ent, h->d_fhat, h->d_bucket_sums, h->d_drop_count,
@@ -632,9 +621,7 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
     h->chain_flow = getenv("BOSSX_CHAIN_BARRIER") == nullptr;
     if (const char *e = getenv("BOSSX_FLOW_CE")) h->chain_flow_ce = atoi(e) == 1 ? 1 : 2;
     if (const char *e = getenv("BOSSX_CHAIN_GC")) h->chain_gc = atoi(e) != 0;
-    if (const char *e = getenv("BOSSX_CHAIN_SCAN")) h->chain_scan = atoi(e) != 0;
     if (const char *e = getenv("BOSSX_CHAIN_SPEC")) h->chain_spec = atoi(e) != 0;
-    if (h->chain_scan) h->chain_spec = false;
     if (h->chain_spec) {
         std::vector<int64_t> off(h->filt.size() + 1, 0);
         int64_t max_bins = 0;
@@ -660,8 +647,10 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
             }
             const double blocks = double(n_local) * nb * 2;
             h->spec_est_serial_us = 3.9e-3 * double(longest) * std::ceil(blocks / 256.0);
-            h->spec_est_us = 5.2e-3 * double(chunks) * nb * 2 * BOSSX_NWIN + 0.27 * double((longest + kSpecL - 1) / kSpecL) +
+            // (round 4: four windows per matrix operation in the candidates, ~0.08 us per chunk in the stitch)
+            h->spec_est_us = 1.6e-3 * double(chunks) * nb * 2 * BOSSX_NWIN + 0.08 * double((longest + kSpecL - 1) / kSpecL) +
                              22.0 * std::ceil(double(segs) * nb * 2 / 256.0) + 30.0;
+            h->spec_plain_share = chunks > 0 ? double((longest + kSpecL - 1) / kSpecL) / (double(chunks) * nb * 2 * BOSSX_NWIN) : 0.0;
             const char *e = getenv("BOSSX_CHAIN_SPEC");
             if (!(e && atoi(e) == 2) && h->spec_est_us > 0.7 * h->spec_est_serial_us) h->chain_spec = false;
         }
@@ -674,13 +663,6 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
             h->chain_spec = false;          // (the serial chain needs no scratch)
         } else if ((rc = dev_alloc(h, &h->d_spec_stats, 8, true))) return rc;
         }
-    }
-    if (h->chain_scan) {
-        // (an allocation failure keeps the serial chain: 176 bytes per bin and barcode)
-        if (hipMalloc(reinterpret_cast<void **>(&h->d_scan_S), size_t(nb) * 2 * BOSSX_NWIN * size_t(h->B) * sizeof(double) + 64) != hipSuccess) {
-            (void)hipGetLastError();
-            h->d_scan_S = nullptr; h->chain_scan = false;
-        } else if ((rc = dev_alloc(h, &h->d_scan_stats, 4, true))) return rc;
     }
     if (h->chain_flow_ce != 2) h->chain_gc = false;
     if ((rc = dev_alloc(h, &h->d_bucket_on, size_t(nb * h->NBK), true))) return rc;
@@ -1598,11 +1580,21 @@ void note_spec_result(bossx_engine *h, const int32_t *herr) {
     if (!h->last_chain_spec) return;
     // chunks the stitch had to add the plain way (sums that climb more than four binades inside a chunk: capped
     // next to uncapped regions).  Each costs ~4 us on ONE wave; beyond ~2 % of a chain's chunks the serial kernel wins.
+    // chunks the stitch had to add the plain way (a start in another binade than the approximation, sums that climb more than
+    // four pieces can follow: capped next to uncapped regions).  Each costs ~2.2 us on ONE wave (matrix core, four bins per
+    // dependent operation); what counts is the longest chain's share of them.  The serial kernel takes over only where the
+    // estimate says it would be faster (round 3 paused at 2 % of the chunks: a fifth of a long run's launches).
     const int64_t plain = herr[1];
     h->spec_plain_total += plain;
-    if (plain * 50 > h->spec_total * int64_t(h->nb) * 2 * BOSSX_NWIN && !getenv("BOSSX_SPEC_NO_PAUSE")) h->spec_pause = 8;      // (the switch: tests)
-    h->spec_mismatches = herr[2];                   // (cumulative: launches whose serial fallback ran)
-    if (h->spec_mismatches >= 3) h->chain_spec = false;
+    const double plain_us = 3.3 * double(herr[3]);          // the most evaluations from the exact value on ONE chain: that wave is what the launch waits for
+    (void)h->spec_plain_share;
+    if (h->spec_est_us + plain_us > 0.9 * h->spec_est_serial_us && !getenv("BOSSX_SPEC_NO_PAUSE")) h->spec_pause = 8;      // (the switch: tests)
+    // launches whose serial fallback ran (cumulative on the device).  A failed check costs one serial chain on top of the
+    // chunk-parallel one: where three of the last sixty-four launches needed it the serial kernel is the faster form
+    // (BOSSX_SPEC_KEEP=1: tests that want every launch to try)
+    if (herr[2] != h->spec_mismatches) { h->spec_recent_fail += herr[2] - h->spec_mismatches; h->spec_mismatches = herr[2]; }
+    if ((++h->spec_since_decay & 63) == 0 && h->spec_recent_fail > 0) --h->spec_recent_fail;
+    if (h->spec_recent_fail >= 3 && !getenv("BOSSX_SPEC_KEEP")) h->chain_spec = false;
 }
 
 int fill_chain_params(bossx_engine *h, const int32_t *windows, const double *mult, ChainParams &P, size_t &lds) {
@@ -1715,7 +1707,8 @@ void launch_chain(bossx_engine *h, const ChainParams &P0, size_t lds, hipStream_
         P.spec_chunk_off = h->d_chunk_off; P.spec_total = h->spec_total; P.spec_starts = h->d_spec_starts;
         Q.C = P; Q.chunk_off = h->d_chunk_off; Q.total_chunks = h->spec_total; Q.tab = h->d_spec_tab; Q.starts = h->d_spec_starts;
         Q.stats = getenv("BOSSX_SPEC_STATS") ? h->d_spec_stats : nullptr;
-        hipLaunchKernelGGL(chain_candidates_kernel, dim3(uint32_t((h->spec_total + 3) / 4), BOSSX_NWIN, uint32_t(h->nb * 2)), dim3(256), 0, stream, Q);
+        Q.strict = getenv("BOSSX_SPEC_STRICT") ? atoi(getenv("BOSSX_SPEC_STRICT")) : 0;
+        hipLaunchKernelGGL(chain_candidates_kernel, dim3(uint32_t(h->spec_total), (BOSSX_NWIN + kCandWin - 1) / kCandWin, uint32_t(h->nb * 2)), dim3(64), 0, stream, Q);
         hipLaunchKernelGGL(chain_stitch_kernel, dim3(uint32_t(h->filt.size() * size_t(h->nb) * 2 * BOSSX_NWIN)), dim3(64), 0, stream, Q);
         if (getenv("BOSSX_SPEC_SELFTEST") && h->spec_total > kSpecSegChunks)      // (the first contig needs a second segment)
             hipLaunchKernelGGL(chain_spoil_kernel, dim3(1), dim3(1), 0, stream, h->d_spec_starts, int64_t(kSpecSegChunks));
@@ -1741,17 +1734,6 @@ void launch_chain(bossx_engine *h, const ChainParams &P0, size_t lds, hipStream_
         lds = size_t(140) * 1024 - fixed;
     }
     h->last_chain_live = live;
-    if (h->chain_scan && !live) {
-        // one block per (contig, barcode, strand, window); then one thread per (barcode, strand, bin)
-        const dim3 sgrid(uint32_t(h->filt.size() * size_t(h->nb) * 2 * BOSSX_NWIN));
-        hipLaunchKernelGGL((movesum_scan_kernel<kScanThreads, kScanG>), sgrid, dim3(kScanThreads), 0, stream, P, h->d_scan_S,
-                           (P.probe || getenv("BOSSX_SCAN_STATS")) ? h->d_scan_stats : nullptr);
-        hipLaunchKernelGGL(benefit_combine_kernel, dim3(uint32_t((h->B + 255) / 256), uint32_t(h->nb * 2)), dim3(256), 0, stream, P, h->d_scan_S);
-        // algorithmic bytes: per bin, barcode and strand the bin sum twice per window (a[j], a[j - w]), the
-        // eleven sums written and read again, the benefit written
-        time_end(h, BOSSX_K_BENEFIT, double(h->B) * h->nb * 2 * (BOSSX_NWIN * 4 * 8.0 + 8.0), stream);
-        return;
-    }
     if (h->matrix_chain && h->chain_flow && ch == 256 && h->chain_flow_fits) {
         // as many buffers between the stages as the LDS holds next to the ring of the current windows
         const int ce = h->chain_flow_ce;

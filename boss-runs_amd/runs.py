@@ -131,7 +131,12 @@ class BossRuns(Boss):
         self.contigs = self.ref.contigs
         self.contigs_filt = {n: c for n, c in self.contigs.items() if not c.rej}
         self.contig_names = list(self.contigs.keys())
-        self.mapper = mapper           # minimap2 itself is upstream of this path: the caller attaches its Mapper
+        # minimap2 itself is upstream of this path: the caller attaches its Mapper; without one, the reference's
+        # `Mapper(ref=self.ref.mmi)` (core.py:41-43) where it can be built (mapper.default_mapper)
+        if mapper is None and contigs is None:
+            from .mapper import default_mapper
+            mapper = default_mapper(getattr(self.ref, "mmi", None) or a.general.mmi)
+        self.mapper = mapper
         self.read_counts = {n: 0 for n in self.contigs}          # AbundanceTracker
         self.total_reads = 0
         self.read_starts = ReadStartDist(contigs=self.contigs_filt)

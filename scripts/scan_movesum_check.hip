@@ -1,5 +1,5 @@
 // movesum_scan_kernel against the sequential recurrence (= oracle/movesum.c), on adversarial arrays:
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I include -I boss-runs_amd/csrc scripts/scan_movesum_check.hip -o scripts/scan_movesum_check.bin
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I include -I boss-runs_amd/csrc -I scripts scripts/scan_movesum_check.hip -o scripts/scan_movesum_check.bin
 // Prints, per case, the number of (window, strand, bin) values that differ and the kernel's stretch statistics.
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -9,6 +9,7 @@
 #include <vector>
 #include "engine.hpp"
 #include "kernels.hip.inc"
+#include "experiments/movesum_scan.hip.inc"
 using namespace bossx;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 

@@ -102,3 +102,62 @@ def test_candidate_tables_predict_chunk_ends_exactly(w):
     # the parity of the start matters: one candidate per 2^rise is NOT enough (this is what the residues are for)
     chunks1, wrong1, _ = _predict_chunk_ends(a, w, 1024, kmul=1)
     assert wrong1 > chunks1 // 8, (chunks1, wrong1)
+
+
+def _saturated_bins(rng, n):
+    """Bin sums of a genome part of which is capped: ordinary bins (a gamma around 0.6) with long stretches of 100 x tiny
+    (fully capped), stretches with deep sites only (1e-44 .. 1e-36), and a few bins with a handful of uncapped sites."""
+    a = rng.gamma(2.0, 0.3, size=n)
+    i = int(rng.integers(200, 3000))
+    while i < n:
+        kind = rng.integers(0, 4)
+        ln = int(rng.integers(150, 2500))
+        if kind <= 1:
+            a[i:i + ln] = 2.2250738585072014e-306
+        elif kind == 2:
+            a[i:i + ln] = rng.uniform(1e-44, 1e-36, size=len(a[i:i + ln]))
+        else:
+            a[i:i + ln] = 10.0 ** rng.uniform(-3, 0, size=len(a[i:i + ln]))
+        i += ln + int(rng.integers(1500, 6000))
+    return a
+
+
+@pytest.mark.parametrize("w", [4, 11, 27, 127])
+def test_chunk_values_from_tables_pieces_and_bands_are_exact(w):
+    """movesum_pieces_model (= chain_candidates_kernel / candidates_cut / chain_stitch_kernel / stitch_eval_range): the value
+    behind every chunk — from an ordinary table, from RUN / ONE / CAND pieces, from the one-grid integer sum of a stretch
+    the exact value dominates, or from plain adds — is the sequential recurrence's, bit for bit, over window sums that
+    drop from 1 to 1e-306 and to the rounding residue of what went before, and climb back; and the tables and the
+    one-grid sums (not plain adds) carry most of the chunks."""
+    from movesum_pieces_model import stitch_chunk
+    rng = np.random.default_rng(100 + w)
+    a = _saturated_bins(rng, 60000)
+    d = a.copy(); d[w:] = a[w:] - a[:-w]
+    true = move_sum_serial(a, w)
+    cs = np.concatenate([[0.0], np.cumsum(a)])
+    L = 1024
+    st = {}
+    chunks = 0
+    for lo in range(L, len(a), L):
+        hi = min(len(a), lo + L)
+        A = cs[lo] - cs[max(lo - w, 0)]
+        pred = stitch_chunk(true[lo - 1], d[lo:hi], A, st)
+        assert pred == true[hi - 1], (w, lo, st)
+        chunks += 1
+    assert chunks >= 50 and st.get("table", 0) > 10 and st.get("band", 0) > 0, st
+
+
+def test_band_eval_is_the_recurrence_where_the_start_dominates():
+    """One grid: a value of 1e-13 (the residue of earlier adds) through a thousand differences of 1e-20 .. 1e-30."""
+    from movesum_pieces_model import band_eval, run_plain
+    rng = np.random.default_rng(5)
+    hits = 0
+    for trial in range(300):
+        s = np.float64(rng.uniform(-1, 1) * 10.0 ** rng.uniform(-16, -10))
+        d = rng.uniform(-1, 1, size=1000) * 10.0 ** rng.uniform(-45, -18, size=1000)
+        got = band_eval(s, d)
+        if got is None:
+            continue
+        hits += 1
+        assert got == run_plain(s, d), trial
+    assert hits > 150, hits
