@@ -58,9 +58,14 @@ def parse_args():
                     help="skip the short runs of the other single-GPU workloads (`workloads` object)")
     ap.add_argument("--prepare-only", action="store_true",
                     help="generate the batches (into BOSSX_BATCH_CACHE) and exit: no GPU is touched")
-    ap.add_argument("--track-entropy", action="store_true",
-                    help="keep the reference's per-site entropy array current (dead state on the strategy path)")
-    return ap.parse_args()
+    ap.add_argument("--no-entropy", action="store_true",
+                    help="do not keep the reference's per-site entropy array current (it is dead state on the strategy path; the "
+                         "reference maintains it every update, sequences.py:443,450, and so does the headline)")
+    ap.add_argument("--no-entropy-off-run", action="store_true",
+                    help="skip the short second run without the entropy array (`track_entropy_false` object)")
+    a = ap.parse_args()
+    a.track_entropy = not a.no_entropy
+    return a
 
 
 # ---- synthetic inputs (generated before the GPU is touched: worker processes are forked) -------
@@ -232,6 +237,30 @@ def large_sweep(device, L=200_000_000, reps=5, depth=8.0):
     return out
 
 
+def entropy_off_run(workload, contigs, device, batches, warmup, steps):
+    """The headline step once more on an engine that does not keep the entropy array (config.gpu.track_entropy = False):
+    what the per-site entropy costs an update."""
+    runs, nb = make_runs(workload, contigs, 0, 1, device, False)
+    R = Runner(workload, runs, nb, batches, False)
+    eng = runs.engine
+    for b in batches[:warmup]:
+        R.step_e2e(b)
+    eng.enable_timing(True)
+    base = eng.kernel_stats()
+    eng.synchronize()
+    t0 = time.perf_counter()
+    for b in batches[warmup:warmup + steps]:
+        R.step_e2e(b)
+    eng.synchronize()
+    dt = time.perf_counter() - t0
+    kern = kernel_table(eng.kernel_stats(), base)
+    eng.close()
+    return {"ms_per_step": 1e3 * dt / steps, "steps": steps, "site_sweep_avg_ms": kern["site_sweep"]["avg_ms"],
+            "site_sweep_frac": (kern["site_sweep"]["gbs"] or 0.0) / HBM_PEAK_GBS,
+            "note": "same batches, same lone step; the entropy array is an a7 output the reference keeps (sequences.py:443,450) "
+                    "and nothing on the strategy path reads"}
+
+
 def kernel_table(stats, base):
     kern = {}
     for k, v in stats.items():
@@ -361,8 +390,7 @@ def other_workload(name, device, batches, steps, warmup, track_entropy):
     eng.enable_timing(True)
     base = eng.kernel_stats()
     sel = batches[warmup:warmup + steps]
-    R.prime(sel[0])
-    dt = timed(eng.synchronize, lambda: R.run_e2e(sel, tail=batches[0]))
+    dt = timed(eng.synchronize, lambda: [R.step_e2e(b) for b in sel])          # lone updates, like the headline
     kern = kernel_table(eng.kernel_stats(), base)
     summ, _ = R.stage(sel)
     dtr = timed(eng.synchronize, lambda: [R.step_resident(i, b, s) for i, (b, s) in enumerate(zip(sel, summ))])
@@ -375,7 +403,7 @@ def other_workload(name, device, batches, steps, warmup, track_entropy):
            "value_mbp_per_s": G * nb / 1e6 / (dt / len(sel)),
            "site_sweep": {"avg_ms": kern["site_sweep"]["avg_ms"], "frac_of_hbm_peak": (kern["site_sweep"]["gbs"] or 0.0) / HBM_PEAK_GBS},
            "benefit_chain_ms": kern["benefit_chain"]["avg_ms"],
-           "chain_floor_ms": max(c.length // 100 + 1 for c in runs.contigs_filt.values()) * CHAIN_FLOOR_CYCLES / GPU_CLOCK_GHZ * 1e-6}
+           "benefit_chain_form": {k: v for k, v in eng.chain_stats().items()}}
     eng.close()
     return out
 
@@ -459,8 +487,7 @@ def run_grch38(a, rank, world, local_rank, steps=None, warmup=None):
     eng.enable_timing(True)
     base = eng.kernel_stats()
     sel = batches[warmup:]
-    R.prime(sel[0])
-    elapsed = timed(barrier, lambda: R.run_e2e(sel, tail=batches[0]))
+    elapsed = timed(barrier, lambda: [R.step_e2e(b) for b in sel])          # lone updates, like the headline
     kern = kernel_table(eng.kernel_stats(), base)
     eng.enable_timing(False)
     shard = torch.tensor([float(G_mine), float(n_reads), elapsed], dtype=torch.float64, device="cuda")
@@ -484,9 +511,9 @@ def run_grch38(a, rank, world, local_rank, steps=None, warmup=None):
                "site_sweep_rank0": {"avg_ms": kern["site_sweep"]["avg_ms"], "frac_of_hbm_peak": achieved / HBM_PEAK_GBS,
                                     "algorithmic_bytes": kern["site_sweep"]["bytes"]},
                "benefit_chain_ms_rank0": kern["benefit_chain"]["avg_ms"],
-               "chain_floor_ms": longest * CHAIN_FLOOR_CYCLES / GPU_CLOCK_GHZ * 1e-6,
-               "note": "the update cannot be shorter than the exact move_sum chain of chr1 (chain_floor_ms) on any GPU "
-                       "count: strong scaling of this path is chr1-bound by design",
+               "serial_form_floor_ms": longest * CHAIN_FLOOR_CYCLES / GPU_CLOCK_GHZ * 1e-6,
+               "note": "serial_form_floor_ms: what the SERIAL walk of the longest contig's move_sum would take at the dependent-op "
+                       "latency alone — the bound of the fallback kernel; the chunk-parallel chain is not bound by it",
                "collectives_per_update": (runs.n_collectives / max(n_b, 1)) if distributed else 0,
                "generation_s": t_gen}
     eng.close()
@@ -629,20 +656,22 @@ def main():
         torch.cuda.synchronize()
         eng.synchronize()
 
-    # ---- the timed region: K end-to-end updates on fresh batches ---------------------------------
+    # ---- the timed region: K end-to-end decision updates on fresh batches, ONE AFTER THE OTHER (SURVEY §8d's t_update:
+    # PAF text + read strings in host memory -> masks in host memory; nothing of batch i+1 is touched before update i has
+    # returned — a live run's next batch does not exist yet, and in simulation it is the outcome of this update's masks)
     for b in batches[:a.warmup]:
         R.step_e2e(b)
     eng.enable_timing(True)          # HIP events on the engine's own streams, collected after the region
     base = eng.kernel_stats()
     sel = batches[a.warmup:]
-    R.prime(sel[0])                  # (the step before the region stages the region's first batch, as every step in it does for its successor)
-    elapsed = timed(barrier, lambda: R.run_e2e(sel, tail=extra))
+    elapsed = timed(barrier, lambda: [R.step_e2e(b) for b in sel])
     stats = eng.kernel_stats()
     kern = kernel_table(stats, base)
-    # ---- latency of a lone update: the same end-to-end step with nothing staged ahead (a live run whose
-    # next batch does not exist yet); right behind the region, on its first batches once more
-    n_lat = min(len(sel), 10)
-    elapsed_lone = timed(barrier, lambda: [R.step_e2e(b) for b in sel[:n_lat]])
+    # ---- secondary: the steady state of a REPLAY, where the caller already holds batch i+1 and hands it along
+    # (process_batch_paf(lookahead=...)): step i parses / uploads / walks batch i+1 while the GPU runs update i
+    n_pipe = min(len(sel), 10)
+    R.prime(sel[0])
+    elapsed_pipe = timed(barrier, lambda: R.run_e2e(sel[:n_pipe], tail=extra))
     # the CPU port runs ONE update here, from the state the engine holds now — a regime with scored,
     # unscored and capped sites side by side.  (After the ~95 updates of E. coli that this script performs
     # in total every site is capped at depth 30, all scores equal `tiny`, and the reference's threshold
@@ -707,15 +736,15 @@ def main():
                        "track_entropy": bool(a.track_entropy),
                        "parallelism": "contig-sharded x%d, one global threshold" % world,
                        "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
-                       "collectives_per_update": (runs.n_collectives / max(n_b + 2 * a.steps, 1)) if distributed else 0},
+                       "collectives_per_update": (runs.n_collectives / max(getattr(runs, "n_updates", 0), 1)) if distributed else 0},
             "commit": commit,
             "timed_region_s": elapsed,
-            "lookahead": not os.environ.get("BOSSX_NO_LOOKAHEAD"),
-            "lone_update_ms": 1e3 * elapsed_lone / n_lat,
-            "lone_update_note": "the same step with nothing staged ahead (parse -> upload -> walk -> sweep -> chain -> masks, "
-                                "strictly one after the other): the latency of one update; ms_per_step is the steady state of "
-                                "back-to-back updates, where step i parses / uploads / walks batch i+1 (process_batch_paf(lookahead=...)) "
-                                "while the GPU runs the chain of batch i — one parse and one update per step either way",
+            "ms_per_step_note": "t_update of SURVEY §8d: one decision update from PAF text + reads in host memory to masks in host "
+                                "memory (parse -> upload -> walk -> sweep -> chain -> threshold -> masks), strictly one after the other",
+            "lone_update_ms": ms_per_step,
+            "pipelined_ms_per_step": 1e3 * elapsed_pipe / n_pipe,
+            "pipelined_note": "secondary: a replay that already holds batch i+1 hands it to step i (process_batch_paf(lookahead=...)), "
+                              "which parses / uploads / walks it while the GPU runs update i — one parse and one update per step either way",
             "kernels_only_ms": 1e3 * elapsed_res / a.steps,
             "kernels_only_note": "the same K updates with every batch already parsed and resident in HBM "
                                  "(ingest + sweep + buckets + chain + histogram + masks + D2H); "
@@ -737,19 +766,16 @@ def main():
             "metric_note": "value = Mbp scored/s (reference positions brought up to date per second); "
                            "ms_per_step = decision-update wall-clock, PAF text in host memory -> masks in host memory",
             "kernels": kern, "kernels_resident_loop": kern_res, "dominant_kernel_by_time": dom,
-            # the chain is a serial FP64 recurrence (1 % of the data): its bound is the dependent
-            # matrix-op latency, not HBM — 20.4 cycles per 4 bins measured (scripts/mfma_chain_floor.hip)
-            "chain_latency": {"kernel": "benefit_chain", "bound": "dependent-op latency",
+            # the chain is bottleneck.move_sum's serial FP64 recurrence (1 % of the data), run chunk-parallel and still exact
+            "chain_latency": {"kernel": "benefit_chain", "bound": "matrix-op issue + the stitch's dependent walk over the chunks",
                               "bins_total": int(eng.merged_bins), "bins_longest_contig": int(longest_bins),
                               "ns_per_bin_longest": 1e6 * kern["benefit_chain"]["avg_ms"] / max(longest_bins, 1),
-                              "floor_cycles_per_bin": CHAIN_FLOOR_CYCLES,
-                              "chain_floor_ms": longest_bins * CHAIN_FLOOR_CYCLES / GPU_CLOCK_GHZ * 1e-6,
+                              "serial_form_floor_ms": longest_bins * CHAIN_FLOOR_CYCLES / GPU_CLOCK_GHZ * 1e-6,
                               "on_fp64_matrix_core": eng.matrix_chain,
-                              "runs_next_to_sweep": not os.environ.get("BOSSX_NO_OVERLAP"),
-                              "note": "exact serial recurrence (bottleneck.move_sum): an update cannot be shorter than "
-                                      "chain_floor_ms = bins of the longest contig x 5.1 cycles / 2.4 GHz on any GPU count (the "
-                                      "dependent-op latency alone; feeding operands and taking the carries out of the chain "
-                                      "wave costs 6.5 cycles per bin at best, scripts/mfma_chain_groups.hip)"},
+                              "note": "candidate tables (four windows per v_mfma_f64_4x4x4) -> stitched start values -> every 4096-bin "
+                                      "segment recomputed from its exact start; serial_form_floor_ms is what the SERIAL walk of the "
+                                      "longest contig would take at the dependent-op latency alone (5.1 cycles per bin) — the bound "
+                                      "of the fallback kernel, not of an update"},
             "host": {"stage_batch_ms_mean": 1e3 * float(np.mean(t_stage)),
                      "batch_generation_s": t_gen,
                      "note": "stage_batch = native PAF/CIGAR parse + upload of one batch (inside ms_per_step)"},
@@ -774,6 +800,11 @@ def main():
             out["roofline_large"] = large_sweep(local_rank)
         runs.engine.close()
         del runs, eng, R
+        if world == 1 and a.track_entropy and not a.no_entropy_off_run:
+            try:
+                out["track_entropy_false"] = entropy_off_run(workload, contigs, local_rank, batches, a.warmup, min(a.steps, 10))
+            except Exception as e:      # a side measurement must not lose the main line
+                out["track_entropy_false"] = {"error": repr(e)}
         if others:
             out["workloads"] = {}
             for w in others:

@@ -670,7 +670,7 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
     if ((rc = dev_alloc(h, &h->d_drop_count, size_t(h->n_tiles), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_tile_ref, size_t(h->n_tiles), true))) return rc;
     h->n_work_ctr = int32_t((h->filt.size() + 8 + 1) & ~size_t(1));       // one per launch of an update: re-swept contigs + the tile / group launches
-    if ((rc = dev_alloc(h, &h->d_work_ctr, size_t(h->n_work_ctr) + 2, true))) return rc;
+    if ((rc = dev_alloc(h, &h->d_work_ctr, size_t(h->n_work_ctr) + 4, true))) return rc;
     {
         // persistent sweep blocks: as many as are resident at once (BOSSX_SWEEP_BLOCKS_PER_CU overrides the occupancy query)
         hipDeviceProp_t prop;
@@ -1436,7 +1436,7 @@ int launch_sweep(bossx_engine *h) {
         PR.tiles = nullptr; PR.n_tiles = 0; PR.tile_ref = h->d_tile_ref;
         PR.tile_done = h->d_tile_done; PR.n_all = h->n_tiles; PR.full = full ? 1 : 0;
         PR.mark = publish ? 1 : 0;
-        PR.work_ctr = h->d_work_ctr; PR.n_ctr = h->n_work_ctr + 2;      // (+ the write-back count behind them)
+        PR.work_ctr = h->d_work_ctr; PR.n_ctr = h->n_work_ctr + 4;      // (+ the write-back counts behind them)
         h->work_ctr_used = 0;
         if (h->pending_slot >= 0) {
             const bossx_engine::Staged &st = h->slots[size_t(h->pending_slot)];
@@ -2816,9 +2816,10 @@ int bossx_kernel_bytes(bossx_engine *h, double *bytes_last) {
         // the last sweep's counter write-back: 16 bytes per vector it actually wrote
         HIPCHK(hipSetDevice(h->cfg.device));
         time_collect(h);
-        unsigned long long wb = 0;
-        HIPCHK(hipMemcpy(&wb, h->d_work_ctr + h->n_work_ctr, sizeof(wb), hipMemcpyDeviceToHost));
-        h->bytes_last[BOSSX_K_SWEEP] = h->sweep_bytes_base + 16.0 * double(wb);
+        unsigned long long wb[2] = {0, 0};
+        HIPCHK(hipMemcpy(wb, h->d_work_ctr + h->n_work_ctr, sizeof(wb), hipMemcpyDeviceToHost));
+        // 16 bytes per counter vector written back; per entropy value its table entry read and the value written
+        h->bytes_last[BOSSX_K_SWEEP] = h->sweep_bytes_base + 16.0 * double(wb[0]) + 16.0 * double(wb[1]);
     }
     for (int k = 0; k < BOSSX_K_COUNT; ++k) bytes_last[k] = h->bytes_last[k];
     return BOSSX_OK;

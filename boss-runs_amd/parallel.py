@@ -408,7 +408,13 @@ class DistributedBossRuns(BossRuns):
         if self.write_masks and self.comm.rank == 0:
             self._write_contig_strategies(contig_strats=self.ref.get_strategy_dict())
 
+    n_updates = 0            # updates run since init (bench: collectives per update)
+
     def update_wrapper(self) -> None:
+        self.n_updates += 1
+        return self._update_wrapper()
+
+    def _update_wrapper(self) -> None:
         if getattr(self, "native", False):
             return self._update_native()
         if getattr(self, "instream", False):
