@@ -673,10 +673,11 @@ def main():
     R.prime(sel[0])
     elapsed_pipe = timed(barrier, lambda: R.run_e2e(sel[:n_pipe], tail=extra))
     # the CPU port runs ONE update here, from the state the engine holds now — a regime with scored,
-    # unscored and capped sites side by side.  (After the ~95 updates of E. coli that this script performs
-    # in total every site is capped at depth 30, all scores equal `tiny`, and the reference's threshold
-    # choice becomes an exact tie that its float summation order decides.)  Behind the timed region, not
-    # in front of it: ten seconds of an idle GPU in front of a 50-ms region cost its first steps their clocks.
+    # unscored and capped sites side by side.  (The deeply saturated regime a long run ends in — every site
+    # capped, thresholds of 1e-304 — is compared separately: scripts/ecoli_diff.py at 90 / 120 / 150 updates,
+    # profiles/r04_ecoli_diff.txt, and tests/test_parity_gpu.py::test_deep_saturation_threshold_vs_oracle: equal.)
+    # Behind the timed region, not in front of it: ten seconds of an idle GPU in front of a 50-ms region cost
+    # its first steps their clocks.
     cpu_cmp = None
     if world == 1 and rank == 0 and not a.no_cpu_baseline:
         eng.enable_timing(False)

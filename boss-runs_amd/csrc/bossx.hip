@@ -45,7 +45,6 @@ struct bossx_engine {
     // can be staged while the update of the current one (sweep, chain) is still running on `stream`.  The consumer
     // (bossx_ingest_staged) makes `stream` wait for the slot's `ev_ready`.
     hipStream_t stream_stage = nullptr;
-    int32_t busy_slot = -1;            // slot whose buffers work enqueued on `stream` may still read
     hipEvent_t ev_begin = nullptr, ev_chain = nullptr, ev_sweep = nullptr, ev_fhat = nullptr;
     double *h_fhat_pin = nullptr;      // page-locked staging of the compact f-hat
     double *d_rs_counts = nullptr; int64_t rs_windows = 0;     // read-start counts resident in HBM (bossx_fhat_reset / _add)
@@ -138,6 +137,13 @@ struct bossx_engine {
         TilePiece *d_pieces = nullptr; size_t pieces_cap = 0;      // per segment
         uint32_t n_segs = 0;
         hipEvent_t ev_ready = nullptr;   // recorded on stream_stage behind the slot's last staging kernel
+        // Work enqueued on the MAIN stream may still read this slot's buffers (the sweep that applies it, or the fallback scatter
+        // of flush_pending): `busy` is set by whoever enqueues such work, `ev_free` is recorded behind it, and the next
+        // staging into the slot waits for that event — per slot (one remembered slot was not enough: two ingests before one
+        // sweep leave the first slot's scatter in flight while the second slot is remembered)
+        bool busy = false;
+        hipEvent_t ev_free = nullptr;
+        int32_t *d_err = nullptr;        // the slot's own error word (a base other than A/C/G/T met while ITS codes were expanded)
         ParsedBatch pb;
         bool valid = false;
         bool emit_tiles_built = false;
@@ -328,6 +334,9 @@ int flush_pending(bossx_engine *h) {
                        h->d_touched, h->d_err);
     time_end(h, BOSSX_K_INGEST, 6.0 * double(pb.total_emit) + 16.0 * double(pb.n_ops));
     HIPCHK(hipGetLastError());
+    if (!st.ev_free) HIPCHK(hipEventCreateWithFlags(&st.ev_free, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(st.ev_free, h->stream));      // the scatter is the last reader of this slot's buffers
+    st.busy = true;
     h->pending_slot = -1;
     h->touched_dirty = true;
     return BOSSX_OK;
@@ -474,7 +483,7 @@ void bossx_destroy(bossx_engine *h) {
                     h->d_strat_off, h->d_bucket_off, h->d_drop_thr, h->d_local, h->d_limbs,
                     h->d_strat_bits};
     for (void *p : ptrs) if (p) hipFree(p);
-    for (auto &st : h->slots) { if (st.ev_ready) hipEventDestroy(st.ev_ready); if (st.d_ops) hipFree(st.d_ops); if (st.d_tiles) hipFree(st.d_tiles); if (st.d_blob) hipFree(st.d_blob); if (st.d_segs) hipFree(st.d_segs); if (st.d_tilerefs) hipFree(st.d_tilerefs); if (st.d_codes) hipFree(st.d_codes); if (st.d_pieces) hipFree(st.d_pieces); }
+    for (auto &st : h->slots) { if (st.ev_ready) hipEventDestroy(st.ev_ready); if (st.ev_free) hipEventDestroy(st.ev_free); if (st.d_err) hipFree(st.d_err); if (st.d_ops) hipFree(st.d_ops); if (st.d_tiles) hipFree(st.d_tiles); if (st.d_blob) hipFree(st.d_blob); if (st.d_segs) hipFree(st.d_segs); if (st.d_tilerefs) hipFree(st.d_tilerefs); if (st.d_codes) hipFree(st.d_codes); if (st.d_pieces) hipFree(st.d_pieces); }
     if (h->d_tile_ref) hipFree(h->d_tile_ref);
     if (h->d_work_ctr) hipFree(h->d_work_ctr);
     if (h->h_pin) hipHostFree(h->h_pin);
@@ -981,7 +990,10 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
     // the previous batch's uploads and walk may still use the staging scratch; a sweep enqueued on the main
     // stream may still read THIS slot's buffers (not when the caller stages ahead into another slot)
     HIPCHK(hipStreamSynchronize(h->stream_stage));
-    if (h->busy_slot == h->slot) { HIPCHK(hipStreamSynchronize(h->stream)); h->busy_slot = -1; }
+    {
+        bossx_engine::Staged &cur = h->slots[size_t(h->slot)];
+        if (cur.busy) { if (cur.ev_free) HIPCHK(hipEventSynchronize(cur.ev_free)); else HIPCHK(hipStreamSynchronize(h->stream)); cur.busy = false; }
+    }
     const size_t blob_bytes = n_reads > 0 ? size_t(seq_off[n_reads]) : 0;
     if (blob_bytes >= (size_t(1) << 32)) return fail(h, BOSSX_E_RANGE, "read blob larger than 4 GiB");
     if (paf_len >= (size_t(1) << 32)) return fail(h, BOSSX_E_RANGE, "PAF text larger than 4 GiB");
@@ -1213,7 +1225,10 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
         ExpandParams X;
         X.ops = st.d_ops; X.n_ops = uint32_t(pb.n_ops); X.total_emit = uint32_t(pb.total_emit);
         X.blob = st.d_blob; X.codes = st.d_codes; X.segs = st.d_segs; X.n_segs = st.n_segs; X.pieces = st.d_pieces;
-        X.err_flag = h->d_err;
+        // (the slot's own error word: a batch staged ahead must not raise in the update of the batch before it)
+        if (!st.d_err) { if ((rc = dev_alloc(h, &st.d_err, 1, false))) return rc; }
+        HIPCHK(hipMemsetAsync(st.d_err, 0, sizeof(int32_t), h->stream_stage));
+        X.err_flag = st.d_err;
         X.code_blocks = (X.total_emit + uint32_t(kExpandTile) - 1u) / uint32_t(kExpandTile);
         if (host_walk) {        // (the device walk's second pass wrote the tile -> run table itself)
             if ((rc = grow_dev(h, &st.d_tiles, &st.tiles_cap, size_t(X.code_blocks) + 2, 64))) return rc;
@@ -1315,7 +1330,8 @@ int bossx_ingest_staged(bossx_engine *h) {
     for (size_t i = 0; i < h->contigs.size(); ++i) h->contigs[i].cov_total += pb.emitted_per_contig[i];
     if (pb.total_emit == 0) return BOSSX_OK;
     if (st.ev_ready) HIPCHK(hipStreamWaitEvent(h->stream, st.ev_ready, 0));     // staged on stream_stage, consumed on the main stream
-    h->busy_slot = h->slot;
+    if (st.d_err) hipLaunchKernelGGL(merge_err_kernel, dim3(1), dim3(1), 0, h->stream, st.d_err, h->d_err);
+    h->slots[size_t(h->slot)].busy = true;        // (until the sweep that applies it — or a fallback scatter — is behind ev_free)
     // the increments are applied by the next sweep, tile by tile (site_sweep_kernel prologue);
     // its prep launch marks the touched tiles
     h->pending_slot = h->slot;
@@ -1522,6 +1538,12 @@ int launch_sweep(bossx_engine *h) {
                 fprintf(stderr, "[sweep probe] %s: %llu items (wave 0 of each block), cycles per item: top..codes gathered %.0f | ..scored (phase A, next tile's loads issued) %.0f | barrier %.0f | phase B %.0f | tail %.0f | total %.0f\n",
                         o ? "ingest" : "plain", pr[o], double(pr[o + 1]) / pr[o], double(pr[o + 2]) / pr[o], double(pr[o + 3]) / pr[o], double(pr[o + 4]) / pr[o],
                         double(pr[o + 5]) / pr[o], double(pr[o + 1] + pr[o + 2] + pr[o + 3] + pr[o + 4] + pr[o + 5]) / pr[o]);
+    }
+    if (h->pending_slot >= 0) {
+        bossx_engine::Staged &st = h->slots[size_t(h->pending_slot)];
+        if (!st.ev_free) HIPCHK(hipEventCreateWithFlags(&st.ev_free, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(st.ev_free, h->stream));  // the sweep launches above are the last readers of this slot's buffers
+        st.busy = true;
     }
     h->pending_slot = -1;
     h->touched_dirty = false;

@@ -490,6 +490,7 @@ class Engine:
         on = np.zeros(len(self.names), dtype=np.uint8)
         res = _lib.UpdateResult()
         counts = fg = ub = None
+        between_error = None
         if want_stats:
             counts = np.zeros(_lib.HIST_BINS, dtype=np.int64)
             fg = np.zeros((_lib.HIST_BINS, 2), dtype=np.uint64)
@@ -502,9 +503,9 @@ class Engine:
                 self._ck(self.lib.bossx_dist_update_launch(*a))
                 try:
                     between()
-                finally:
-                    rc = self.lib.bossx_dist_update_collect(*a)
-                self._ck(rc)
+                except BaseException as e:       # the update is collected and applied first (the engine's state has advanced)
+                    between_error = e
+                self._ck(self.lib.bossx_dist_update_collect(*a))
         else:
             a = (self.h, C.byref(up), masks.ctypes.data, on.ctypes.data, C.byref(res), None if counts is None else counts.ctypes.data,
                  None if fg is None else fg.ctypes.data, None if ub is None else ub.ctypes.data)
@@ -514,14 +515,16 @@ class Engine:
                 self._ck(self.lib.bossx_update_launch(*a))
                 try:
                     between()
-                finally:
-                    rc = self.lib.bossx_update_collect(*a)
-                self._ck(rc)
+                except BaseException as e:       # the update is collected and applied first (the engine's state has advanced)
+                    between_error = e
+                self._ck(self.lib.bossx_update_collect(*a))
         out = dict(updated=bool(res.updated), any_on=bool(res.any_on), threshold=res.threshold,
                    normaliser=res.normaliser, ubar0=res.ubar0, strat_size=res.strat_size,
                    n_bins=res.n_bins, contig_on=on.astype(bool))
         if want_stats:
             out.update(counts=counts, fgrid_fx=fg, ubar_fx=ub)
+        if between_error is not None:
+            out["between_error"] = between_error        # re-raised by the caller once it has applied this update's results
         return out
 
     def strat_view(self, contig):

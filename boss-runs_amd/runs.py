@@ -240,7 +240,8 @@ class BossRuns(Boss):
         a, self._ahead = self._ahead, None
         eng = self.engine
         if a is not None and a["paf_text"] is paf_text and a["new_reads"] is new_reads and \
-                a["barcodes"] is barcodes and a["min_len"] == min_len:
+                a["barcodes"] is barcodes and a["min_len"] == min_len and a["n_reads"] == len(new_reads):
+            # (the objects staged ahead are frozen until this call: same objects, same number of reads)
             if a["error"] is not None:
                 raise a["error"]
             eng.ingest_staged(slot=a["slot"])
@@ -258,7 +259,7 @@ class BossRuns(Boss):
             t = tuple(lookahead)
             a = dict(paf_text=t[0], new_reads=t[1], barcodes=t[2] if len(t) > 2 else None,
                      min_len=t[3] if len(t) > 3 else 200)
-        a.update(slot=1 - self._cur_slot, summ=None, error=None)
+        a.update(slot=1 - self._cur_slot, summ=None, error=None, n_reads=len(a["new_reads"]))
         eng = self.engine
         try:
             eng.select_batch(a["slot"])
@@ -332,6 +333,8 @@ class BossRuns(Boss):
                 logging.info(f"Activated strategy for: {cname}")
         switched_on = armed or res["any_on"]
         if not switched_on:
+            if res.get("between_error") is not None:
+                raise res["between_error"]
             return
         if not have_rl:
             # the reference raises AttributeError here (readlengthdist.py:68)
@@ -355,6 +358,8 @@ class BossRuns(Boss):
                 logging.info(f'{cname}: {f_perc}, {r_perc}')
         if self.write_masks:
             self._publish_masks(bits=eng.strat_bits if use_bits else None)
+        if res.get("between_error") is not None:
+            raise res["between_error"]
 
     def _lazy_strat(self, cont):
         bits, off = self.engine.strat_bits, self.engine.strat_offset(cont.index)

@@ -86,6 +86,31 @@ def gen_errors(out):
         json.dump(res, fh, indent=1, sort_keys=True)
 
 
+def gen_errors_fuzz(out):
+    """The same record of the reference's behaviour for the 2,000 seeded random mutations of scenarios.fuzz_error_cases
+    (the mutation set of scripts/fuzz/fuzz_paf.cpp): differential fuzzing of the front end against the reference itself."""
+    import json
+    from boss.paf import Paf
+    from boss.runs.reference import Contig
+    from boss.runs.sequences import CoverageConverter
+    from scenarios import fuzz_error_cases
+    contigs, cases = fuzz_error_cases()
+    res = {}
+    for name, paf_text, seqs in cases:
+        conts = {n: Contig(n, synth.codes_to_str(c)) for n, c in contigs}
+        try:
+            paf = Paf.parse_PAF(StringIO(paf_text), min_len=200)
+            inc = CoverageConverter().convert_records(paf_dict=paf, seqs=seqs,
+                                                      quals={k: "I" * len(v) for k, v in seqs.items()})
+            for n, c in conts.items():          # core.py:77-86: every contig of contigs_filt
+                c.increment_coverage(inc[n])
+            res[name] = {"ok": digest(*[conts[n].coverage for n in sorted(conts)])[:16]}
+        except Exception as e:                  # noqa: BLE001 - the class is the datum
+            res[name] = {"error": type(e).__name__}
+    with open(os.path.join(out, "g_errors_fuzz.json"), "w") as fh:
+        json.dump(res, fh, sort_keys=True, separators=(",", ":"))
+
+
 def gen_cigar(out):
     from boss.paf import Paf
     from boss.runs.sequences import CoverageConverter
@@ -388,6 +413,9 @@ def run_sim_scenario(out, tag, nb, accept_unmapped):
 
 def main():
     out = HERE
+    if os.environ.get("GOLDEN_ONLY") == "errors_fuzz":  # (the other fixtures are not touched)
+        gen_errors_fuzz(out)
+        return
     if os.environ.get("GOLDEN_ONLY") == "errors":       # (the other fixtures are not touched)
         gen_errors(out)
         return
@@ -398,6 +426,7 @@ def main():
     gen_tables(out)
     gen_cigar(out)
     gen_errors(out)
+    gen_errors_fuzz(out)
     gen_dists(out)
     for tag, pl, nb in SCENARIOS:
         d = run_scenario(out, tag, pl, nb)

@@ -179,3 +179,139 @@ def error_cases():
     cases.append(("strand_garbage", set_col(plus, 4, "?"), seqs))
     cases.append(("empty_batch", "", {}))
     return contigs, cases
+
+
+# ---- differential fuzz of the PAF / CIGAR front end against the reference itself ---------------------------------
+FUZZ_N = 2000
+FUZZ_SEED = 20260402
+
+
+def fuzz_error_cases(n=FUZZ_N, seed=FUZZ_SEED):
+    """`n` seeded random mutations of small consistent batches (the mutation set of scripts/fuzz/fuzz_paf.cpp, in Python so
+    that the REFERENCE can be run on the very same inputs): list of (name, paf_text, seqs).  tests/golden/g_errors_fuzz.json
+    holds what the reference does with each (exception class, or a digest of the coverage it ends with;
+    tests/golden/make_golden.py, GOLDEN_ONLY=errors_fuzz); the oracle, the native host front end and the device walk are
+    held to it case by case."""
+    contigs = synth.make_reference(ERR_LENGTHS, seed=5, names=ERR_NAMES)
+    rng = np.random.default_rng(seed)
+    cases = []
+    ints = ["0", "-1", "-7", "1", "9" * 12, "9" * 30, "12x", "abc", "", " 5", "5 ", "+3", "0x10", "1e3", "3.0", "١٢"]
+    tags_bad = ["zz:Z:a:b", "zz:1", "zz:q:1", "de:f:abc", "AS:i:abc", "tp:A:S", "cg:Z:", "cg:Z:10", "cg:Z:M", "NM:i:", "s1:i:x", ":::", "cg:Z:5Q"]
+    ops = "MIDNSHP=XB"
+
+    def mutate(lines, seqs, k):
+        lines = list(lines)
+        seqs = dict(seqs)
+        if not lines:
+            return lines, seqs
+        i = int(rng.integers(0, len(lines)))
+        f = lines[i].split("\t")
+        kind = k
+        if kind == 0:       # truncate a line to j columns
+            lines[i] = "\t".join(f[:int(rng.integers(0, len(f)))])
+        elif kind == 1:     # delete / duplicate / swap fields
+            j = int(rng.integers(0, len(f)))
+            w = int(rng.integers(0, 3))
+            if w == 0 and len(f) > 1:
+                del f[j]
+            elif w == 1:
+                f.insert(j, f[j])
+            else:
+                j2 = int(rng.integers(0, len(f)))
+                f[j], f[j2] = f[j2], f[j]
+            lines[i] = "\t".join(f)
+        elif kind == 2:     # delete / duplicate / swap lines, blank line, trailing newline
+            w = int(rng.integers(0, 5))
+            if w == 0:
+                del lines[i]
+            elif w == 1:
+                lines.insert(i, lines[i])
+            elif w == 2:
+                j2 = int(rng.integers(0, len(lines)))
+                lines[i], lines[j2] = lines[j2], lines[i]
+            elif w == 3:
+                lines.insert(i, "")
+            else:
+                lines.append("")
+        elif kind == 3:     # an integer column replaced
+            col = int(rng.choice([1, 2, 3, 6, 7, 8, 9, 10, 11]))
+            if col < len(f):
+                f[col] = ints[int(rng.integers(0, len(ints)))]
+                lines[i] = "\t".join(f)
+        elif kind == 4:     # strand / contig name / read name replaced
+            col = int(rng.choice([0, 4, 5]))
+            if col < len(f):
+                f[col] = [["rX", "", "7", "007", f[0] + "x"], ["+", "-", "*", "", "++"], ["e1", "e2", "nope", "", "E1"]][[0, 4, 5].index(col)][int(rng.integers(0, 5))]
+                lines[i] = "\t".join(f)
+        elif kind == 5:     # tags: missing / malformed / unknown type / appended junk
+            w = int(rng.integers(0, 3))
+            tag_idx = [j for j in range(12, len(f))]
+            if w == 0 and tag_idx:
+                del f[int(rng.choice(tag_idx))]
+            elif w == 1 and tag_idx:
+                f[int(rng.choice(tag_idx))] = tags_bad[int(rng.integers(0, len(tags_bad)))]
+            else:
+                f.append(tags_bad[int(rng.integers(0, len(tags_bad)))])
+            lines[i] = "\t".join(f)
+        elif kind == 6:     # CIGAR edits: prepend / append / drop an operation, other letters, zero lengths, huge lengths
+            cg = [j for j, x in enumerate(f) if x.startswith("cg:Z:")]
+            if cg:
+                c = f[cg[0]][5:]
+                w = int(rng.integers(0, 7))
+                op = ops[int(rng.integers(0, len(ops)))]
+                ln = str(int(rng.integers(0, 40)))
+                if w == 0:
+                    c = ln + op + c
+                elif w == 1:
+                    c = c + ln + op
+                elif w == 2:
+                    c = c[:max(0, len(c) - int(rng.integers(1, 6)))]
+                elif w == 3:
+                    c = c.replace("M", op, 1)
+                elif w == 4:
+                    c = c + "0M" + "0D"
+                elif w == 5:
+                    c = c + "9" * 11 + "M"
+                else:
+                    c = "x" + c[:len(c) // 2] + "?" + c[len(c) // 2:]
+                f[cg[0]] = "cg:Z:" + c
+                lines[i] = "\t".join(f)
+        elif kind == 7:     # the read: cut short, emptied, other letters, lower case, dropped from the dict
+            name = f[0]
+            if name in seqs:
+                sq = seqs[name]
+                w = int(rng.integers(0, 5))
+                if w == 0:
+                    seqs[name] = sq[:int(rng.integers(0, len(sq) + 1))]
+                elif w == 1:
+                    seqs[name] = ""
+                elif w == 2 and sq:
+                    p = int(rng.integers(0, len(sq)))
+                    seqs[name] = sq[:p] + "NRYacgt-*"[int(rng.integers(0, 9))] + sq[p + 1:]
+                elif w == 3:
+                    seqs[name] = sq.lower()
+                else:
+                    del seqs[name]
+        elif kind == 8:     # garbage bytes inside a line
+            p = int(rng.integers(0, len(lines[i]) + 1))
+            lines[i] = lines[i][:p] + ["\x00", "\t\t", " ", "\r", "\x7f", "é"][int(rng.integers(0, 6))] + lines[i][p:]
+        else:               # coordinates shifted consistently (a mapping that runs past the contig end / before its start)
+            if len(f) > 8:
+                try:
+                    sh = int(rng.choice([-10 ** 6, -50, 50, 5000, 10 ** 6]))
+                    f[7] = str(int(f[7]) + sh)
+                    f[8] = str(int(f[8]) + sh)
+                    lines[i] = "\t".join(f)
+                except ValueError:
+                    pass
+        return lines, seqs
+
+    for c in range(n):
+        k_reads = int(rng.integers(1, 6))
+        b = synth.make_batch(contigs, k_reads, seed=int(rng.integers(0, 2 ** 31)), mean_len=600.0, min_len=250, max_len=1500,
+                             extras=bool(rng.integers(0, 4) == 0))
+        lines, seqs = b["paf"].split("\n"), b["seqs"]
+        for _ in range(int(rng.integers(0, 4))):
+            lines, seqs = mutate(lines, seqs, int(rng.integers(0, 10)))
+        cases.append(("f%04d" % c, "\n".join(lines), seqs))
+    return contigs, cases

@@ -371,6 +371,88 @@ def test_full_size_ecoli_properties(in_tmp):
     assert np.all(scores1[never, 0] == runs.scoring.score0[0])
 
 
+def test_full_size_ecoli_vs_oracle(in_tmp):
+    """BASELINE configs[1] at full size against the ORACLE (not only through properties): E. coli K-12's 4,641,652 bp,
+    ploidy 1, two decision updates of 4000 reads each (~10x: every bucket switches on in the first) — per-site coverage,
+    scores and entropy, bucket switches, bin sums, benefits, the threshold and its bin, and the masks, bit for bit."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.runs import BossRuns
+    from oracle.pipeline import OracleRuns
+    contigs = synth.make_reference([synth.ECOLI_LEN], seed=1, names=["ecoli"])
+    strs = [(n, synth.codes_to_str(c)) for n, c in contigs]
+    args = BossConfig()
+    args.general.name = "ecoli_oracle"
+    runs = BossRuns(args)
+    runs.init(contigs=strs)
+    runs.write_masks = False
+    runs.keep_stats = True
+    o = OracleRuns(strs)
+    for b in range(2):
+        batch = synth.make_batch(contigs, 4000, seed=900 + b, extras=True)
+        o.process_batch(batch["paf"], batch["seqs"], read_lengths=batch["read_lengths"])
+        runs.rl_dist.update(batch["read_lengths"])
+        runs.process_batch_paf(batch["paf"], batch["seqs"])
+        pc, oc = runs.contigs["ecoli"], o.contigs["ecoli"]
+        assert np.array_equal(pc.coverage, oc.coverage), b
+        assert np.array_equal(pc.scores, oc.scores), b
+        assert np.array_equal(pc.entropy, oc.entropy), b
+        assert np.array_equal(pc.bucket_switches, oc.bucket_switches), b
+        assert np.array_equal(pc.switched_on, oc.switched_on), b
+        assert (runs.threshold is None) == (o.threshold is None), b
+        if o.threshold is not None:
+            assert np.array_equal(pc.scores_ds, oc.scores_ds), b
+            assert np.array_equal(pc.additional_benefit, oc.additional_benefit), b
+            assert runs.threshold == o.threshold, b
+            assert runs.last_stats["strat_size"] == o.detail["strat_size"], b
+            assert np.array_equal(runs.last_stats["counts"], o.detail["counts"]), b
+        assert np.array_equal(pc.strat, oc.strat), b
+    assert o.threshold is not None and 0 < runs.contigs["ecoli"].strat.mean() < 1
+    runs.engine.close()
+
+
+def test_deep_saturation_threshold_vs_oracle(in_tmp):
+    """The regime a long E. coli run lives in: every site capped at depth 30 many times over (here 400 kb, sixty updates of
+    ~13x each: depth ~800), every score `tiny` or dropped out, benefits of 1e-304 — where the reference's threshold choice
+    rests on float sums (f_grid, ubar0) it forms in a 12-chunk order and the engine forms exactly.  One more update from
+    the engine's exported state through the ORACLE must give the same threshold, the same bin and the same masks
+    (scripts/ecoli_diff.py is the full-size form: 4.6 Mb, 90 / 120 / 150 updates — equal; profiles/r04_ecoli_diff.txt)."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.runs import BossRuns
+    from oracle.pipeline import OracleRuns
+    contigs = synth.make_reference([400_000], seed=77, names=["deep"])
+    strs = [(n, synth.codes_to_str(c)) for n, c in contigs]
+    args = BossConfig()
+    args.general.name = "deep_sat"
+    args.optional.bucket_threshold = 0
+    runs = BossRuns(args)
+    runs.init(contigs=strs)
+    runs.write_masks = False
+    batches = [synth.make_batch(contigs, 900, seed=7700 + i, mean_len=6000.0, extras=False) for i in range(6)]
+    for u in range(60):
+        b = batches[u % 5]
+        runs.rl_dist.update(b["read_lengths"])
+        runs.process_batch_paf(b["paf"], b["seqs"])
+    o = OracleRuns(strs, bucket_threshold=0)
+    pc, oc = runs.contigs["deep"], o.contigs["deep"]
+    oc.coverage[:] = pc.coverage; oc.scores[:] = pc.scores
+    oc.bucket_switches[:] = pc.bucket_switches; oc.switched_on[:] = pc.switched_on; oc.strat[:] = pc.strat
+    o.read_starts.read_starts["deep"][:] = runs.read_starts.read_starts["deep"]
+    o.rl_dist.read_lengths[:] = runs.rl_dist.read_lengths
+    assert int(np.median(pc.coverage.sum(axis=1))) > 300
+    b = batches[5]
+    o.process_batch(b["paf"], b["seqs"], read_lengths=b["read_lengths"])
+    runs.keep_stats = True
+    runs.rl_dist.update(b["read_lengths"])
+    runs.process_batch_paf(b["paf"], b["seqs"])
+    assert runs.threshold == o.threshold and o.threshold < 1e-290
+    assert runs.last_stats["strat_size"] == o.detail["strat_size"]
+    assert np.array_equal(runs.contigs["deep"].strat, o.contigs["deep"].strat)
+    assert np.array_equal(runs.contigs["deep"].additional_benefit, o.contigs["deep"].additional_benefit)
+    runs.engine.close()
+
+
 def test_checkpoint_resume(in_tmp):
     """save_state / load_state: a resumed run continues bit-identically."""
     contigs = e2e_reference()
