@@ -17,7 +17,7 @@ NWIN = 11
 K_NAMES = ("ingest_scatter", "site_sweep", "benefit_chain", "threshold_hist", "strategy_mask")
 
 ERRORS = {-1: ValueError, -2: RuntimeError, -3: ValueError, -4: KeyError, -5: IndexError,
-          -6: ValueError, -7: ValueError, -8: TypeError, -9: AssertionError}
+          -6: ValueError, -7: ValueError, -8: TypeError, -9: AssertionError, -10: OverflowError}
 
 
 class BossxError(RuntimeError):

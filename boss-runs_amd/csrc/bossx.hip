@@ -1187,10 +1187,16 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
         };
         // (CIGAR text is tokenised like the reference's re.findall: what it skips is skipped; what remains are a
         // shape mismatch — ValueError, sequences.py:790 — and the span assertion, sequences.py:732)
+        // The device walk DETECTS; which exception the reference raises for the mapping — its checks come in a
+        // fixed order — is check_cigar_text's to say (paf_host.cpp), from the same text and plan.
         for (uint32_t i = 0; i < uint32_t(walk_err.size()); ++i)
-            if (walk_err[i] & kWalkParseMask)
-                return fail(h, (walk_err[i] & kWalkParseMask) == kWalkSpanMismatch ? BOSSX_E_ASSERT : BOSSX_E_PARSE,
-                            "read '" + plan_name(i) + "': " + walk_message(walk_err[i] & kWalkParseMask));
+            if (walk_err[i] & kWalkParseMask) {
+                const MapPlan &mp = pb.plans[i];
+                std::string msg;
+                int code = check_cigar_text(in.paf + (size_t(mp.cg_off) - size_t(in.paf_base)), mp.cg_len, int64_t(mp.q_need), int64_t(mp.span), true, true, msg);
+                if (!code) { code = BOSSX_E_INVALID; msg = "internal: the device walk refuses what the host check passes (" + std::string(walk_message(walk_err[i] & kWalkParseMask)) + ")"; }
+                return fail(h, code, "read '" + plan_name(i) + "': " + msg);
+            }
         if (pb.pre_code) return fail(h, pb.pre_code, pb.pre_msg);
         {
             int64_t best_gi = pb.pre_range_gi;

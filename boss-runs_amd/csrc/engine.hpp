@@ -196,6 +196,9 @@ int parse_threads();             // BOSSX_PARSE_THREADS, default min(8, hardware
 
 // Parses the PAF text, picks the best mapping per read and expands CIGARs into emit runs.
 // Returns BOSSX_OK or an error code with `err` filled.  Nothing is produced on error.
+// The class of a CIGAR failure, in the reference's order of checks (paf_host.cpp): BOSSX_OK or the code.
+int check_cigar_text(const char *cg, size_t n, int64_t q_len, int64_t span, bool q_ok, bool t_ok, std::string &msg);
+
 int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs,
                     const std::unordered_map<std::string, int32_t> &contig_index,
                     bossx_batch_summary *summary, ParsedBatch &out, std::string &err);

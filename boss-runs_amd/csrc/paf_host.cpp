@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <climits>
+#include <cmath>
 #include <cstdint>
 #include <atomic>
 #include <condition_variable>
@@ -40,50 +41,160 @@ struct Rec {
     bool rev;
     const char *cg; size_t cg_len;   // points into the PAF text
     bool has_cg;
+    bool cg_not_str = false;         // cg:i: / cg:f: whose value converts: the reference hands an int / float to re.findall (TypeError)
     // columns that are not integers stay strings in the reference (conv_type, paf.py:103-108) and only
     // matter where it computes with them: bit = column index
     uint32_t bad_cols = 0;
+    // what np.array([(mapq, AS), ...], dtype=int) of choose_best_mapper does with this record (paf.py:716-718):
+    // 0, ValueError (mapq stayed a str) or OverflowError (mapq or AS beyond int64)
+    int key_err = 0;
 };
 
-std::string_view strip(std::string_view s);
+// ---- text the way Python sees it -------------------------------------------------------------
+// The PAF text crosses the C-ABI as UTF-8.  str.strip() and int() work on code points: they strip
+// every Unicode whitespace character and take every decimal digit (category Nd), so "١٢" IS 12 for the
+// reference (tests/golden/g_errors_fuzz.json holds such cases).
+int utf8_at(std::string_view s, size_t i, uint32_t &cp) {
+    const unsigned char c = static_cast<unsigned char>(s[i]);
+    if (c < 0x80) { cp = c; return 1; }
+    int n = c >= 0xf0 ? 4 : c >= 0xe0 ? 3 : c >= 0xc0 ? 2 : 0;
+    if (!n || i + size_t(n) > s.size()) { cp = 0xfffd; return 1; }
+    cp = c & (0xffu >> (n + 1));
+    for (int k = 1; k < n; ++k) {
+        const unsigned char d = static_cast<unsigned char>(s[i + size_t(k)]);
+        if ((d & 0xc0) != 0x80) { cp = 0xfffd; return 1; }
+        cp = (cp << 6) | (d & 0x3fu);
+    }
+    return n;
+}
+
+bool py_space(uint32_t cp) {          // str.isspace(), Unicode 13
+    if (cp < 0x80) return cp == ' ' || (cp >= 0x09 && cp <= 0x0d) || (cp >= 0x1c && cp <= 0x1f);
+    return cp == 0x85 || cp == 0xa0 || cp == 0x1680 || (cp >= 0x2000 && cp <= 0x200a) || cp == 0x2028 || cp == 0x2029 ||
+           cp == 0x202f || cp == 0x205f || cp == 0x3000;
+}
+
+// value of a decimal digit (category Nd: 65 runs of ten consecutive code points, Unicode 13), or -1
+int nd_digit(uint32_t cp) {
+    if (cp < 0x80) return cp >= '0' && cp <= '9' ? int(cp - '0') : -1;
+    static constexpr uint32_t zero[] = {
+        0x660, 0x6F0, 0x7C0, 0x966, 0x9E6, 0xA66, 0xAE6, 0xB66, 0xBE6, 0xC66, 0xCE6, 0xD66, 0xDE6, 0xE50, 0xED0, 0xF20, 0x1040,
+        0x1090, 0x17E0, 0x1810, 0x1946, 0x19D0, 0x1A80, 0x1A90, 0x1B50, 0x1BB0, 0x1C40, 0x1C50, 0xA620, 0xA8D0, 0xA900, 0xA9D0,
+        0xA9F0, 0xAA50, 0xABF0, 0xFF10, 0x104A0, 0x10D30, 0x11066, 0x110F0, 0x11136, 0x111D0, 0x112F0, 0x11450, 0x114D0, 0x11650,
+        0x116C0, 0x11730, 0x118E0, 0x11950, 0x11C50, 0x11D50, 0x11DA0, 0x16A60, 0x16B50, 0x1D7CE, 0x1D7D8, 0x1D7E2, 0x1D7EC,
+        0x1D7F6, 0x1E140, 0x1E2F0, 0x1E950, 0x1FBF0};
+    for (uint32_t z : zero) {
+        if (cp < z) return -1;
+        if (cp < z + 10) return int(cp - z);
+    }
+    return -1;
+}
+
+std::string_view strip(std::string_view s) {      // str.strip()
+    size_t b = 0, e = s.size();
+    while (b < e) {
+        uint32_t cp;
+        const int n = utf8_at(s, b, cp);
+        if (!py_space(cp)) break;
+        b += size_t(n);
+    }
+    while (e > b) {
+        size_t k = e - 1;
+        while (k > b && e - k < 4 && (static_cast<unsigned char>(s[k]) & 0xc0) == 0x80) --k;
+        uint32_t cp;
+        const int n = utf8_at(s, k, cp);
+        if (k + size_t(n) != e || !py_space(cp)) break;
+        e = k;
+    }
+    return s.substr(b, e - b);
+}
 
 // Python `int(s)` for a str: surrounding whitespace, optional sign, decimal digits with single
-// underscores between them.  Values beyond +-2^62 saturate (Python's integers do not overflow; nothing
-// on the path can hold such a value either: the checks downstream reject it like the reference does).
-bool parse_int(std::string_view s, int64_t &v) {
+// underscores between them.  Python's integers do not overflow: `v` is clamped to +-2^62 (nothing on the
+// path can hold more, and the checks downstream reject such a value like the reference does), `*big`
+// says that the value does not fit an int64 (where numpy is handed it: OverflowError), `*canon` gets
+// str(int(s)).
+bool parse_int(std::string_view s, int64_t &v, bool *big = nullptr, std::string *canon = nullptr) {
     s = strip(s);
-    size_t i = 0, n = s.size();
+    size_t i = 0;
+    const size_t n = s.size();
     bool neg = false;
     if (i < n && (s[i] == '+' || s[i] == '-')) { neg = s[i] == '-'; ++i; }
-    if (i >= n || s[i] < '0' || s[i] > '9') return false;
-    constexpr int64_t kBig = int64_t(1) << 62;
-    int64_t x = 0;
-    bool prev_us = false;
-    for (; i < n; ++i) {
-        const char c = s[i];
-        if (c == '_') { if (prev_us) return false; prev_us = true; continue; }
-        if (c < '0' || c > '9') return false;
-        prev_us = false;
-        x = x >= kBig / 10 ? kBig : x * 10 + (c - '0');
+    if (i >= n) return false;
+    unsigned __int128 x = 0;
+    const unsigned __int128 cap = static_cast<unsigned __int128>(1) << 100;
+    bool prev_us = true, any = false;           // (an underscore may not lead)
+    std::string digits;
+    while (i < n) {
+        uint32_t cp;
+        const int len = utf8_at(s, i, cp);
+        i += size_t(len);
+        if (cp == '_') { if (prev_us) return false; prev_us = true; continue; }
+        const int d = nd_digit(cp);
+        if (d < 0) return false;
+        prev_us = false; any = true;
+        x = x >= cap ? cap : x * 10 + unsigned(d);
+        if (canon && (d || !digits.empty())) digits.push_back(char('0' + d));
     }
-    if (prev_us) return false;
-    v = neg ? -x : x;
+    if (!any || prev_us) return false;
+    const unsigned __int128 lim = (static_cast<unsigned __int128>(1) << 63) - (neg ? 0 : 1);
+    if (big) *big = x > lim;
+    const int64_t kClamp = int64_t(1) << 62;
+    const int64_t mag = x > static_cast<unsigned __int128>(kClamp) ? kClamp : int64_t(x);
+    v = neg ? -mag : mag;
+    if (canon) *canon = digits.empty() ? std::string("0") : (neg ? "-" + digits : digits);
     return true;
+}
+
+// Python `float(s)` as far as a tag value can reach it: whitespace, sign, inf / infinity / nan, decimal
+// digits with single underscores between them, fraction, exponent.  (No hex floats: strtod takes them,
+// float() does not.)
+bool parse_float(std::string_view s, double &d) {
+    s = strip(s);
+    std::string t;
+    t.reserve(s.size());
+    for (size_t i = 0; i < s.size();) {
+        uint32_t cp;
+        const int len = utf8_at(s, i, cp);
+        i += size_t(len);
+        const int dg = nd_digit(cp);
+        if (dg >= 0) t.push_back(char('0' + dg));
+        else if (cp < 0x80) t.push_back(char(cp >= 'A' && cp <= 'Z' ? cp + 32 : cp));
+        else return false;
+    }
+    size_t k = (!t.empty() && (t[0] == '+' || t[0] == '-')) ? 1 : 0;
+    const std::string_view body = std::string_view(t).substr(k);
+    if (body == "inf" || body == "infinity") { d = t[0] == '-' ? -HUGE_VAL : HUGE_VAL; return true; }
+    if (body == "nan") { d = NAN; return true; }
+    std::string u;
+    u.reserve(t.size());
+    bool digit_before = false;
+    for (size_t i = 0; i < t.size(); ++i) {
+        const char c = t[i];
+        if (c == '_') {
+            if (!digit_before || i + 1 >= t.size() || t[i + 1] < '0' || t[i + 1] > '9') return false;
+            digit_before = false;
+            continue;
+        }
+        if (!((c >= '0' && c <= '9') || c == '.' || c == 'e' || c == '+' || c == '-')) return false;
+        digit_before = c >= '0' && c <= '9';
+        u.push_back(c);
+    }
+    if (u.empty()) return false;
+    bool has_digit = false;
+    for (char c : u) has_digit |= (c >= '0' && c <= '9');
+    if (!has_digit) return false;
+    char *ep = nullptr;
+    d = strtod(u.c_str(), &ep);
+    return ep && *ep == '\0';
 }
 
 // PafLine stores names as str(conv_type(x, int)): "007" becomes "7" (paf.py:55-56, 103-108).
 std::string normalise_name(std::string_view s) {
     int64_t v;
-    if (parse_int(s, v)) return std::to_string(v);
+    std::string canon;
+    if (parse_int(s, v, nullptr, &canon)) return canon;
     return std::string(s);
-}
-
-std::string_view strip(std::string_view s) {
-    size_t b = 0, e = s.size();
-    auto ws = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\f' || c == '\v' || (c >= 0x1c && c <= 0x1f); };   // str.strip()
-    while (b < e && ws(s[b])) ++b;
-    while (e > b && ws(s[e - 1])) --e;
-    return s.substr(b, e - b);
 }
 
 struct Group {
@@ -91,7 +202,7 @@ struct Group {
     int64_t key_q, key_dp;
     int32_t read = -1;       // index of the read in the batch (-1: the name is not in the batch)
     int32_t n_recs = 1;      // kept records of this read
-    bool bad_mapq = false;   // one of them has a mapq that is not an integer (np.array(..., dtype=int) in choose_best_mapper)
+    int key_err = 0;         // first of them (line order) that np.array(..., dtype=int) of choose_best_mapper refuses, and how
 };
 
 struct CigarTable {
@@ -126,12 +237,14 @@ struct LineOut {
 };
 
 // Paf.parse_PAF / PafLine.__init__ over the lines of [p, end) (paf.py:18-75, 631-672), with the
-// reference's exception classes (tests/golden/g_errors.json holds what it does, case by case):
-//   fewer than 12 columns, blank lines included     IndexError  (f[i], paf.py:50-51)
-//   tag that is not key:type:value                  ValueError  (x.split(":") unpacking, paf.py:95-98)
-//   tag type other than i / A / f / Z               KeyError    (c[tag])
-//   AS that int() does not take                     ValueError  (paf.py:62)
-//   alignment block length that is not an integer   TypeError   (str < int, paf.py:666)
+// reference's exception classes (tests/golden/g_errors.json and g_errors_fuzz.json hold what it does,
+// case by case):
+//   fewer than 12 columns, blank lines included     IndexError     (f[i], paf.py:50-51)
+//   tag that is not key:type:value                  ValueError     (x.split(":") unpacking, paf.py:95-98)
+//   tag type other than i / A / f / Z               KeyError       (c[tag])
+//   AS that int() does not take                     ValueError     (paf.py:62; the LAST AS tag of the line counts:
+//                                                                   the tags are a dict), OverflowError for AS:f:inf
+//   alignment block length that is not an integer   TypeError      (str < int, paf.py:666)
 // Other non-integer columns stay strings there and only matter if the path computes with them
 // (Rec::bad_cols; the unused ones — tlen, number of matches — never do).
 void parse_lines(const char *p, const char *end, int64_t min_len, LineOut &lo) {
@@ -154,11 +267,15 @@ void parse_lines(const char *p, const char *end, int64_t min_len, LineOut &lo) {
         if (f.size() < 12) return fail(BOSSX_E_RANGE, ": fewer than 12 columns");
         Rec r;
         r.qlen = r.qstart = r.qend = r.tstart = r.tend = r.alnlen = r.mapq = 0;
-        auto col = [&](size_t k, int64_t &dst) { if (!parse_int(f[k], dst)) { dst = 0; r.bad_cols |= 1u << k; } };
-        col(1, r.qlen); col(2, r.qstart); col(3, r.qend); col(7, r.tstart); col(8, r.tend); col(10, r.alnlen); col(11, r.mapq);
+        bool mapq_big = false;
+        auto col = [&](size_t k, int64_t &dst, bool *big = nullptr) { if (!parse_int(f[k], dst, big)) { dst = 0; r.bad_cols |= 1u << k; } };
+        col(1, r.qlen); col(2, r.qstart); col(3, r.qend); col(7, r.tstart); col(8, r.tend); col(10, r.alnlen); col(11, r.mapq, &mapq_big);
         r.rev = !(f[4].size() == 1 && f[4][0] == '+');   // paf.py:58
         r.as = 0; r.has_cg = false; r.cg = nullptr; r.cg_len = 0;
         bool primary = false;
+        bool has_as = false;
+        char as_typ = 'i';
+        std::string_view as_val;
         for (size_t k = 12; k < f.size(); ++k) {
             std::string_view tag = f[k];
             size_t c1 = tag.find(':');
@@ -169,25 +286,35 @@ void parse_lines(const char *p, const char *end, int64_t min_len, LineOut &lo) {
             std::string_view key = tag.substr(0, c1), typ = tag.substr(c1 + 1, c2 - c1 - 1), val = tag.substr(c2 + 1);
             if (!(typ.size() == 1 && (typ[0] == 'i' || typ[0] == 'A' || typ[0] == 'f' || typ[0] == 'Z')))
                 return fail(BOSSX_E_KEY, ": unknown tag type");
+            // a repeated key replaces the earlier one (the tags are collected in a dict, paf.py:95-101)
             if (key == "AS") {
-                // int(tags_parsed.get("AS", 0)): an int, a float (truncated) or a str that int() has to take
-                bool ok = false;
-                if (typ[0] == 'f') {
-                    const std::string tmp(strip(val));
-                    char *ep = nullptr;
-                    const double d = tmp.empty() ? 0.0 : strtod(tmp.c_str(), &ep);
-                    if (!tmp.empty() && ep && *ep == '\0' && d == d && d > -9e18 && d < 9e18) { r.as = int64_t(d); ok = true; }
-                }
-                if (!ok && !parse_int(val, r.as)) return fail(BOSSX_E_PARSE, ": AS is not an integer");
+                has_as = true; as_typ = typ[0]; as_val = val;
             } else if (key == "cg") {
                 r.has_cg = true; r.cg = val.data(); r.cg_len = val.size();
+                int64_t iv; double dv;
+                r.cg_not_str = (typ[0] == 'i' && parse_int(val, iv)) || (typ[0] == 'f' && parse_float(val, dv));
             } else if (key == "tp") {
                 primary = (val == "P");
             }
         }
+        bool as_big = false;
+        if (has_as) {
+            // int(tags_parsed.get("AS", 0)): an int, a float (truncated) or a str that int() has to take
+            bool ok = false;
+            double d;
+            if (as_typ == 'f' && parse_float(as_val, d)) {
+                if (d != d) return fail(BOSSX_E_PARSE, ": AS is not a number");            // int(nan)
+                if (d == HUGE_VAL || d == -HUGE_VAL) return fail(BOSSX_E_OVERFLOW, ": AS is infinite");   // int(inf)
+                as_big = d >= 9223372036854775808.0 || d < -9223372036854775808.0;
+                r.as = d >= 4e18 ? (int64_t(1) << 62) : d <= -4e18 ? -(int64_t(1) << 62) : int64_t(d);
+                ok = true;
+            }
+            if (!ok && !parse_int(as_val, r.as, &as_big)) return fail(BOSSX_E_PARSE, ": AS is not an integer");
+        }
         if (r.bad_cols & (1u << 10)) return fail(BOSSX_E_TYPE, ": alignment block length is not an integer");   // paf.py:666
         if (r.alnlen < min_len) continue;     // paf.py:666-667
         if (!primary) continue;               // paf.py:668-669
+        r.key_err = (r.bad_cols & (1u << 11)) ? BOSSX_E_PARSE : (mapq_big || as_big) ? BOSSX_E_OVERFLOW : 0;
         r.qname = normalise_name(f[0]);
         r.tname = normalise_name(f[5]);
         lo.recs.push_back(std::move(r));
@@ -205,7 +332,32 @@ struct Plan {
     int32_t read, cidx, bc;
     uint64_t emit0;          // index of its first emitted base in the batch-wide emit order
     size_t ops_at;           // where its emit runs start in the caller's buffer (upper-bound spacing)
+    int64_t tlo, thi;        // the sites it emits to, [tlo, thi) (np's slice of the coverage array: both ends below zero wrap)
+    int64_t q_first, q_len;  // read[q_first] is the first base the walk reads ('-': walks down from there), q_len how many the slice holds
 };
+
+// seq[start:end] of a Python sequence of n elements: first index and length.
+void py_slice(int64_t start, int64_t end, int64_t n, int64_t &first, int64_t &len) {
+    const int64_t s = start < 0 ? std::max<int64_t>(start + n, 0) : std::min(start, n);
+    const int64_t e = end < 0 ? std::max<int64_t>(end + n, 0) : std::min(end, n);
+    first = s;
+    len = e > s ? e - s : 0;
+}
+
+// The stretch of the read a mapping's CIGAR is laid over: int_seq[start:end] of sequences.py:707-716, 790 —
+// of the read itself on '+', of its reverse complement on '-' (qlen - qend : qlen - qstart).  Python slicing:
+// indices past the ends are clipped, negative ones count from the end (a qlen column smaller than the
+// read — 0, 1, -7 — still selects bases; the reference goes on with those).
+void read_slice(const Rec &r, int64_t seq_len, int64_t &q_first, int64_t &q_len) {
+    int64_t first;
+    if (r.rev) {
+        py_slice(r.qlen - r.qend, r.qlen - r.qstart, seq_len, first, q_len);
+        q_first = seq_len - 1 - first;       // element `first` of the reverse complement is base seq_len-1-first of the read
+    } else {
+        py_slice(r.qstart, r.qend, seq_len, first, q_len);
+        q_first = first;
+    }
+}
 
 struct WalkError {
     int64_t group = INT64_MAX;
@@ -224,6 +376,58 @@ struct WalkOut {
     WalkError range_err;    // first IndexError class failure (raised later in the reference: the walk goes on)
 };
 
+}  // namespace
+
+// CoverageConverter._parse_cigar + the span assertion (sequences.py:744-794, 732) as far as the TEXT of a
+// CIGAR decides them, in the order the reference gets to them:
+//   no (\d+)([MIDNSHP=XB]) token at all               ValueError      zip(*[]), :769
+//   a run of 2^32 bases or more                       OverflowError   np.array(lengths, dtype=np.uint32), :770
+//   (a run of 10^9 .. 2^32-1 bases: the reference allocates it and fails on the shape; ValueError here)
+//   [q_ok false: qstart / qend stayed strings]        TypeError       int_seq[start:end], :790
+//   query bases consumed != bases of the read slice   ValueError      cig_rep[notdel] = ..., :790
+//   [t_ok false: tstart / tend stayed strings]        TypeError       min / max, :730-731
+//   reference bases emitted != |tend - tstart|        AssertionError  :732
+// The one authority on the CLASS of a CIGAR failure: the host walk and the device walk detect, this
+// classifies.  A read slice of exactly one base is broadcast by numpy over however many bases the CIGAR
+// consumes — the reference goes on with nonsense; this path refuses it (ValueError).
+int check_cigar_text(const char *cg, size_t n, int64_t q_len, int64_t span, bool q_ok, bool t_ok, std::string &msg) {
+    size_t n_tok = 0;
+    bool overflow = false, huge = false;
+    unsigned __int128 consumed = 0, emitted = 0;
+    const char *cp = cg, *ce = cg + n;
+    while (cp < ce) {
+        unsigned __int128 len = 0;
+        const char *d0 = cp;
+        unsigned d;
+        while (cp < ce && (d = unsigned(*cp) - unsigned('0')) < 10u) { len = len >= (static_cast<unsigned __int128>(1) << 80) ? len : len * 10 + d; ++cp; }
+        if (cp >= ce) break;                         // digits without a letter at the end
+        const char op = *cp++;
+        if (cp - 1 == d0 || !kCigarOp[static_cast<unsigned char>(op)]) continue;
+        ++n_tok;
+        if (len >= (static_cast<unsigned __int128>(1) << 32)) overflow = true;
+        else if (len >= 1000000000u) huge = true;
+        if (op != 'D') consumed += len;
+        if (op != 'I') emitted += len;
+    }
+    if (n_tok == 0) { msg = "no CIGAR operation"; return BOSSX_E_PARSE; }
+    if (overflow) { msg = "CIGAR run of 2^32 bases or more"; return BOSSX_E_OVERFLOW; }
+    if (huge) { msg = "CIGAR run of 10^9 bases or more"; return BOSSX_E_PARSE; }
+    if (!q_ok) { msg = "query coordinate is not an integer"; return BOSSX_E_TYPE; }
+    if (consumed != static_cast<unsigned __int128>(q_len)) {
+        msg = "CIGAR consumes " + std::to_string(uint64_t(consumed)) + " query bases, the PAF columns select " + std::to_string(q_len);
+        if (q_len == 1) msg += " (numpy would broadcast the one base: refused)";
+        return BOSSX_E_PARSE;
+    }
+    if (!t_ok) { msg = "coordinate is not an integer"; return BOSSX_E_TYPE; }
+    if (emitted != static_cast<unsigned __int128>(span)) {
+        msg = "CIGAR spans " + std::to_string(uint64_t(emitted)) + " reference bases, PAF says " + std::to_string(span);
+        return BOSSX_E_ASSERT;
+    }
+    return BOSSX_OK;
+}
+
+namespace {
+
 // CIGAR walk of plans [p0, p1): emit runs written densely from `base`, tile segments collected.
 void walk_plans(const ParseInput &in, const std::vector<ContigInfo> &contigs, const std::vector<Plan> &plans,
                 size_t p0, size_t p1, EmitOp *base, WalkOut &wo) {
@@ -234,7 +438,13 @@ void walk_plans(const ParseInput &in, const std::vector<ContigInfo> &contigs, co
         const Plan &pl = plans[pi];
         if (pl.cidx < 0) continue;           // ignored contig (pre-pass marks it)
         const Rec &r = *pl.rec;
-        auto fail = [&](int code, std::string msg) { wo.err.group = int64_t(pi); wo.err.code = code; wo.err.msg = std::move(msg); };
+        // a failure of the ValueError / OverflowError / AssertionError class: check_cigar_text says which
+        auto fail = [&]() {
+            wo.err.group = int64_t(pi);
+            wo.err.code = check_cigar_text(r.cg, r.cg_len, pl.q_len, pl.thi - pl.tlo, true, true, wo.err.msg);
+            if (!wo.err.code) { wo.err.code = BOSSX_E_INVALID; wo.err.msg = "internal: the CIGAR walk and its check disagree"; }
+            wo.err.msg = "read '" + r.qname + "': " + wo.err.msg;
+        };
         // IndexError class (np.add.at inside Contig.increment_coverage, reference.py:138): the
         // reference raises it after convert_records has gone through every read, so it never hides
         // a parse error of a later read — noted, and the walk continues
@@ -243,13 +453,11 @@ void walk_plans(const ParseInput &in, const std::vector<ContigInfo> &contigs, co
         };
         const ContigInfo &c = contigs[size_t(pl.cidx)];
         const int64_t seq_b = in.seq_off[pl.read], seq_len = in.seq_off[pl.read + 1] - seq_b;
-        const int64_t tlo = r.tstart < r.tend ? r.tstart : r.tend;
-        const int64_t thi = r.tstart < r.tend ? r.tend : r.tstart;
-        // query walk: '+' reads seq[qstart + i]; '-' reads comp(seq[len-1-(qlen-qend) - i])
-        // (sequences.py:707-716: slice [qlen-qend, qlen-qstart) of the reverse complement)
-        int64_t q = r.rev ? (seq_len - 1 - (r.qlen - r.qend)) : r.qstart;
+        const int64_t tlo = pl.tlo, thi = pl.thi;
+        // query walk: '+' reads seq[q_first + i]; '-' reads comp(seq[q_first - i]) (sequences.py:707-716)
+        int64_t q = pl.q_first;
         const int64_t qstep = r.rev ? -1 : 1;
-        const int64_t q_need = r.qend - r.qstart;
+        const int64_t q_need = pl.q_len;
         // quick look at the whole aligned stretch of the read; only a read that holds something
         // other than A/C/G/T there gets the per-run check below (insertions may hold anything)
         bool check_bases = false;
@@ -267,6 +475,7 @@ void walk_plans(const ParseInput &in, const std::vector<ContigInfo> &contigs, co
         // the reference tokenises with re.findall(r"(\d+)([MIDNSHP=XB])") (sequences.py:672,767): whatever
         // is not digits directly followed by one of these letters is skipped, silently
         size_t n_tok = 0;
+        bool failed = false;
         while (cp < ce) {
             int64_t len = 0;
             const char *d0 = cp;
@@ -276,7 +485,7 @@ void walk_plans(const ParseInput &in, const std::vector<ContigInfo> &contigs, co
             const char op = *cp++;
             if (cp - 1 == d0 || !kCigarOp[static_cast<unsigned char>(op)]) continue;
             ++n_tok;
-            if (len >= int64_t(1000000000)) return fail(BOSSX_E_PARSE, "read '" + r.qname + "': CIGAR run of 10^9 bases or more");
+            if (len >= int64_t(1000000000)) { failed = true; break; }
             if (len == 0) continue;
             if (op == 'I') {                       // consumes query, emits nothing (sequences.py:781)
                 consumed += len; q += qstep * len;
@@ -284,9 +493,8 @@ void walk_plans(const ParseInput &in, const std::vector<ContigInfo> &contigs, co
             }
             const bool del = (op == 'D');          // emits code 4, consumes nothing (sequences.py:782,793)
             if (!del) {
+                if (consumed + len > q_need) { failed = true; break; }       // more than the slice holds: a shape mismatch in cig_rep[notdel] = int_seq[start:end]
                 const int64_t q_last = q + qstep * (len - 1);
-                if (q < 0 || q >= seq_len || q_last < 0 || q_last >= seq_len)
-                    return fail(BOSSX_E_PARSE, "read '" + r.qname + "': CIGAR walks outside the read");   // shape mismatch in cig_rep[notdel] = int_seq[start:end]
                 if (check_bases && !all_acgt(in.seqs + seq_b + (r.rev ? q_last : q), size_t(len)))
                     range_fail("read '" + r.qname + "': base other than A/C/G/T inside an aligned segment");
             }
@@ -302,13 +510,7 @@ void walk_plans(const ParseInput &in, const std::vector<ContigInfo> &contigs, co
             ref_pos += len;
             if (!del) { consumed += len; q += qstep * len; }
         }
-        if (n_tok == 0) return fail(BOSSX_E_PARSE, "read '" + r.qname + "': no CIGAR operation");      // zip(*[]), sequences.py:769
-        if (consumed != q_need)
-            return fail(BOSSX_E_PARSE, "read '" + r.qname + "': CIGAR consumes " + std::to_string(consumed) +
-                                       " query bases, PAF says " + std::to_string(q_need));
-        if (ref_pos - tlo != thi - tlo)
-            return fail(BOSSX_E_ASSERT, "read '" + r.qname + "': CIGAR spans " + std::to_string(ref_pos - tlo) +
-                                       " reference bases, PAF says " + std::to_string(thi - tlo));   // sequences.py:732
+        if (failed || n_tok == 0 || consumed != q_need || ref_pos - tlo != thi - tlo) return fail();
         wo.emitted_per_contig[size_t(pl.cidx)] += uint64_t(thi - tlo);
         // split the read's emitted stretch at sweep-tile boundaries (padded site space)
         if (w > first) {
@@ -622,15 +824,15 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
                         if (it != group_of_unknown.end()) unknown_slot = it->second;
                         slot = &unknown_slot;
                     }
-                    const bool bad_q = (r.bad_cols & (1u << 11)) != 0;
+                    const int key_err = r.key_err;
                     if (*slot < 0) {
-                        groups.push_back(Group{std::move(r), r.mapq, r.as, read, 1, bad_q});
+                        groups.push_back(Group{std::move(r), r.mapq, r.as, read, 1, key_err});
                         if (read >= 0) *slot = int32_t(groups.size() - 1);
                         else group_of_unknown.emplace(std::string_view(groups.back().best.qname), int32_t(groups.size() - 1));
                     } else {
                         Group &g = groups[size_t(*slot)];
                         ++g.n_recs;
-                        g.bad_mapq = g.bad_mapq || bad_q;
+                        if (!g.key_err) g.key_err = key_err;
                         // argsort by (mapq, AS), last element wins; stable for ties (paf.py:716-721)
                         if (r.mapq > g.key_q || (r.mapq == g.key_q && r.as >= g.key_dp)) {
                             g.key_q = r.mapq; g.key_dp = r.as;
@@ -664,8 +866,8 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
     for (size_t gi = 0; gi < groups.size(); ++gi) {
         const Rec &r = groups[gi].best;
         auto pre_fail = [&](int code, std::string msg) { pre_err.group = int64_t(gi); pre_err.code = code; pre_err.msg = std::move(msg); };
-        if (groups[gi].n_recs > 1 && groups[gi].bad_mapq) {
-            pre_fail(BOSSX_E_PARSE, "read '" + r.qname + "': mapping quality is not an integer");   // choose_best_mapper, paf.py:716-718
+        if (groups[gi].n_recs > 1 && groups[gi].key_err) {
+            pre_fail(groups[gi].key_err, "read '" + r.qname + "': mapping quality / AS of one of its mappings is not an int64");   // choose_best_mapper, paf.py:716-718
             break;
         }
         if (groups[gi].read < 0) {
@@ -687,20 +889,50 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         ++n_rec;
         if (in.summary_only) continue;
         // columns that stayed strings: the reference computes qlen - qend / qlen - qstart on '-' mappings
-        // (sequences.py:709-710), slices with qstart / qend on '+' ones (:790) and takes min / max of the
-        // target coordinates (:730-731) — a TypeError each; a '+' mapping never looks at qlen
+        // (sequences.py:709-710) before it looks at the CIGAR, slices with qstart / qend on '+' ones only after
+        // tokenising it (:790), and takes min / max of the target coordinates after that (:730-731) — a
+        // TypeError each, at its place in that order (check_cigar_text); a '+' mapping never looks at qlen
         const uint32_t bad_q = r.bad_cols & ((1u << 2) | (1u << 3) | (r.rev ? (1u << 1) : 0u));
+        const uint32_t bad_t = r.bad_cols & ((1u << 7) | (1u << 8));
         if (r.rev && bad_q) { pre_fail(BOSSX_E_TYPE, "read '" + r.qname + "': query coordinate is not an integer"); break; }
         if (!r.has_cg) {
             pre_fail(BOSSX_E_ASSERT, "read '" + r.qname + "': mapping without cg tag");   // assert rec.cigar is not None
             break;
         }
-        if (bad_q || (r.bad_cols & ((1u << 7) | (1u << 8)))) {
-            pre_fail(BOSSX_E_TYPE, "read '" + r.qname + "': coordinate is not an integer");
-            break;
+        if (r.cg_not_str) { pre_fail(BOSSX_E_TYPE, "read '" + r.qname + "': cg tag is not a string"); break; }      // re.findall on an int / float
+        const bool local = cidx >= 0 && !contigs[size_t(cidx)].rejected && !contigs[size_t(cidx)].remote;
+        const bool remote = cidx >= 0 && !contigs[size_t(cidx)].rejected && contigs[size_t(cidx)].remote;
+        Plan pl{&r, int64_t(gi), read, local ? cidx : -1, 0, cur_emit, ops_at, 0, 0, 0, 0};
+        const int64_t seq_len = in.seq_off[read + 1] - in.seq_off[read];
+        if (!bad_q) read_slice(r, seq_len, pl.q_first, pl.q_len);
+        pl.tlo = std::min(r.tstart, r.tend);
+        pl.thi = std::max(r.tstart, r.tend);
+        // Where the increments go (Contig.increment_coverage: np.add.at(coverage[start:end], (arange(end - start), ...)),
+        // reference.py:138): a slice, so an end past the contig clips it (IndexError: the walk reports it) and two
+        // NEGATIVE ends count from the contig's end — inside the contig the reference goes on there, anything
+        // else leaves a slice shorter than the mapping (IndexError)
+        bool range_bad = false;
+        if (local && !bad_t && pl.tlo < 0) {
+            const int64_t clen = contigs[size_t(cidx)].length;
+            if (pl.thi == pl.tlo) range_bad = false;                 // nothing to add
+            else if (pl.thi < 0 && pl.tlo + clen >= 0) { pl.tlo += clen; pl.thi += clen; }
+            else range_bad = true;
         }
-        Plan pl{&r, int64_t(gi), read, cidx, 0, cur_emit, ops_at};
-        if (cidx < 0 || contigs[size_t(cidx)].rejected || contigs[size_t(cidx)].remote) {
+        // A mapping the walk is not given — its contig is not one of ours (the reference converts EVERY
+        // chosen mapping and drops those afterwards, sequences.py:700-735 / core.py:83-86), a coordinate stayed
+        // a string, or its sites lie before the contig's start — is still held to the CIGAR checks, here.
+        // (Mappings on another device's contigs are that device's to check.)
+        const bool walk_it = local && !bad_q && !bad_t && !range_bad && !(pl.thi == pl.tlo && pl.tlo < 0);
+        if (!walk_it && !remote) {
+            std::string msg;
+            const int code = check_cigar_text(r.cg, r.cg_len, pl.q_len, pl.thi - pl.tlo, !bad_q, !bad_t, msg);
+            if (code) { pre_fail(code, "read '" + r.qname + "': " + msg); break; }
+            if (range_bad && !pre_range.code) {
+                pre_range.group = int64_t(gi); pre_range.code = BOSSX_E_RANGE;
+                pre_range.msg = "read '" + r.qname + "': mapping starts before the start of " + contigs[size_t(cidx)].name;
+            }
+        }
+        if (!walk_it) {
             pl.cidx = -1;               // core.py:83-86: only (local) contigs_filt receive coverage
         } else {
             pl.bc = in.barcodes ? in.barcodes[read] : 0;
@@ -708,8 +940,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
                 if (!pre_range.code) { pre_range.group = int64_t(gi); pre_range.code = BOSSX_E_RANGE; pre_range.msg = "read '" + r.qname + "': barcode index out of range"; }
                 pl.bc = 0;
             }
-            const int64_t span = r.tstart < r.tend ? r.tend - r.tstart : r.tstart - r.tend;
-            cur_emit += uint64_t(span);
+            cur_emit += uint64_t(pl.thi - pl.tlo);
             ops_at += r.cg_len / 2 + 1;           // every run is at least one digit + one letter
         }
         plans.push_back(pl);
@@ -733,16 +964,15 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             const Rec &r = *pl.rec;
             const ContigInfo &c = contigs[size_t(pl.cidx)];
             const int64_t seq_b = in.seq_off[pl.read], seq_len = in.seq_off[pl.read + 1] - seq_b;
-            const int64_t tlo = r.tstart < r.tend ? r.tstart : r.tend;
-            const int64_t thi = r.tstart < r.tend ? r.tend : r.tstart;
-            const int64_t q = r.rev ? (seq_len - 1 - (r.qlen - r.qend)) : r.qstart;
-            const int64_t q_need = r.qend - r.qstart;
-            if (tlo < 0 || q_need < 0 || q_need > int64_t(UINT32_MAX) || r.cg_len > size_t(UINT32_MAX) ||
-                q < INT32_MIN || q > INT32_MAX) {
-                // malformed PAF columns (the reference fails on them as well); records after it are not walked
+            const int64_t tlo = pl.tlo, thi = pl.thi;
+            const int64_t q = pl.q_first, q_need = pl.q_len;
+            if (r.cg_len > size_t(UINT32_MAX) || thi - tlo > int64_t(UINT32_MAX)) {
+                // (a span no contig holds: the reference fails on it as well); records after it are not walked
                 if (!pre_err.code || pl.gi < pre_err.group) {
-                    pre_err.group = pl.gi; pre_err.code = BOSSX_E_PARSE;
-                    pre_err.msg = "read '" + r.qname + "': inconsistent PAF coordinates";
+                    pre_err.group = pl.gi;
+                    pre_err.code = check_cigar_text(r.cg, r.cg_len, q_need, thi - tlo, true, true, pre_err.msg);
+                    if (!pre_err.code) { pre_err.code = BOSSX_E_RANGE; pre_err.msg = "mapping of 2^32 bases or more"; }
+                    pre_err.msg = "read '" + r.qname + "': " + pre_err.msg;
                 }
                 break;
             }
@@ -1130,8 +1360,8 @@ extern "C" int bossx_paf_select_lines(const char *paf, size_t paf_len, const cha
         auto it = read_index.find(q);
         if (it == read_index.end()) {
             int64_t v;
-            if (!parse_int(q, v)) continue;
-            const std::string norm = std::to_string(v);         // "007" is stored as "7" (paf.py:55-56)
+            std::string norm;                                   // "007" is stored as "7" (paf.py:55-56)
+            if (!parse_int(q, v, nullptr, &norm)) continue;
             it = read_index.find(std::string_view(norm));
             if (it == read_index.end()) continue;
         }

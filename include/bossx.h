@@ -32,6 +32,7 @@ extern "C" {
 #define BOSSX_E_WINDOW    (-6)  /* move_sum window outside [1, n] (Bottleneck ValueError)      */
 #define BOSSX_E_EMPTY     (-7)  /* no non-zero benefit (np.max of empty array: ValueError)     */
 #define BOSSX_E_TYPE      (-8)  /* a PAF column the path computes with is not an integer (TypeError: paf.py:103-108 keeps it a str) */
+#define BOSSX_E_OVERFLOW  (-10) /* CIGAR run of 2^32 bases or more, AS:f:inf, mapq / AS beyond int64 where several mappings are ranked (OverflowError: numpy / int()) */
 #define BOSSX_E_ASSERT    (-9)  /* mapping without cg tag / CIGAR does not span tend - tstart (AssertionError, sequences.py:718,732) */
 
 #define BOSSX_WINDOW        100     /* strategy / downsampling window, reference.py:109,215   */

@@ -195,8 +195,11 @@ def fuzz_error_cases(n=FUZZ_N, seed=FUZZ_SEED):
     contigs = synth.make_reference(ERR_LENGTHS, seed=5, names=ERR_NAMES)
     rng = np.random.default_rng(seed)
     cases = []
-    ints = ["0", "-1", "-7", "1", "9" * 12, "9" * 30, "12x", "abc", "", " 5", "5 ", "+3", "0x10", "1e3", "3.0", "١٢"]
-    tags_bad = ["zz:Z:a:b", "zz:1", "zz:q:1", "de:f:abc", "AS:i:abc", "tp:A:S", "cg:Z:", "cg:Z:10", "cg:Z:M", "NM:i:", "s1:i:x", ":::", "cg:Z:5Q"]
+    ints = ["0", "-1", "-7", "1", "9" * 12, "9" * 30, "12x", "abc", "", " 5", "5 ", "+3", "0x10", "1e3", "3.0", "١٢",
+            "1_0", "_1", "٣", "2147483648", "4294967296", "-0", "6000", "5000", "-5000", "-6000", "9223372036854775808", "\u20035"]
+    tags_bad = ["zz:Z:a:b", "zz:1", "zz:q:1", "de:f:abc", "AS:i:abc", "tp:A:S", "cg:Z:", "cg:Z:10", "cg:Z:M", "NM:i:", "s1:i:x", ":::", "cg:Z:5Q",
+                "AS:f:inf", "AS:f:-Infinity", "AS:f:nan", "AS:f:1e3", "AS:f:2.7", "AS:f:1_0.5", "AS:f:0x10", "AS:Z:12", "AS:A:7", "AS:Z: 8 ", "AS:i:" + "9" * 25,
+                "AS:f:1e300", "cg:i:5", "cg:f:1.5", "cg:i:x5M", "tp:i:P", "tp:Z:P", "tp:A:p", "AS:i:", "AS:f:"]
     ops = "MIDNSHP=XB"
 
     def mutate(lines, seqs, k):
@@ -295,10 +298,22 @@ def fuzz_error_cases(n=FUZZ_N, seed=FUZZ_SEED):
         elif kind == 8:     # garbage bytes inside a line
             p = int(rng.integers(0, len(lines[i]) + 1))
             lines[i] = lines[i][:p] + ["\x00", "\t\t", " ", "\r", "\x7f", "é"][int(rng.integers(0, 6))] + lines[i][p:]
+        elif kind == 10:    # a second mapping of the same read: the line again with another mapq / AS / strand / target
+            g = list(f)
+            w = int(rng.integers(0, 4))
+            if w == 0 and len(g) > 11:
+                g[11] = ["0", "60", "61", "7", "abc", "9" * 20, "-3"][int(rng.integers(0, 7))]
+            elif w == 1:
+                g = [x if not x.startswith("AS:") else "AS:i:" + ["0", "5000", "abc", "9" * 20, "-1"][int(rng.integers(0, 5))] for x in g]
+            elif w == 2 and len(g) > 4:
+                g[4] = "-" if g[4] == "+" else "+"
+            elif len(g) > 5:
+                g[5] = ["e1", "e2", "nope"][int(rng.integers(0, 3))]
+            lines.insert(i + int(rng.integers(0, 2)), "\t".join(g))
         else:               # coordinates shifted consistently (a mapping that runs past the contig end / before its start)
             if len(f) > 8:
                 try:
-                    sh = int(rng.choice([-10 ** 6, -50, 50, 5000, 10 ** 6]))
+                    sh = int(rng.choice([-10 ** 6, -50, 50, 5000, 10 ** 6, -5000, -6000, -4000]))
                     f[7] = str(int(f[7]) + sh)
                     f[8] = str(int(f[8]) + sh)
                     lines[i] = "\t".join(f)
@@ -312,6 +327,6 @@ def fuzz_error_cases(n=FUZZ_N, seed=FUZZ_SEED):
                              extras=bool(rng.integers(0, 4) == 0))
         lines, seqs = b["paf"].split("\n"), b["seqs"]
         for _ in range(int(rng.integers(0, 4))):
-            lines, seqs = mutate(lines, seqs, int(rng.integers(0, 10)))
+            lines, seqs = mutate(lines, seqs, int(rng.integers(0, 11)))
         cases.append(("f%04d" % c, "\n".join(lines), seqs))
     return contigs, cases

@@ -460,3 +460,32 @@ def test_native_front_end_error_classes_equal_the_reference():
             if got.get("error") != want.get("error") or got.get("ok") != want.get("ok"):
                 bad.append((name, threads, got, {k: want[k] for k in want if k in ("ok", "error")}))
     assert not bad, bad
+
+
+def test_native_front_end_fuzz_error_classes_equal_the_reference():
+    """The native PAF / CIGAR front end (bossx_host_parse: line parser, grouping, pre-pass, host walk, and the plans
+    of the device walk) against tests/golden/g_errors_fuzz.json — what the reference itself does with 2,000 seeded
+    random mutations (scenarios.fuzz_error_cases), case by case: the same exception class where it raises, the same
+    coverage where it goes on (Python slicing of the read and of the coverage array included: a qlen column of 0
+    or -7 on a '-' mapping still selects bases, two negative target coordinates count from the contig's end)."""
+    import json
+    from scenarios import GOLDEN, digest, fuzz_error_cases
+    from boss_runs_amd.engine import host_parse
+    contigs, cases = fuzz_error_cases()
+    gold = json.load(open(os.path.join(GOLDEN, "g_errors_fuzz.json")))
+    clist = [(n, c.shape[0], 0) for n, c in contigs]
+    bad = []
+    for name, paf_text, seqs in cases:
+        for threads in (1, 3):
+            try:
+                out = host_parse(clist, paf_text, seqs, n_threads=threads, min_len=200)
+                cov = {n: np.zeros((c.shape[0], 5, 1), dtype=np.uint16) for n, c in contigs}
+                for k, (n, _) in enumerate(contigs):
+                    sel = out["contig"] == k
+                    np.add.at(cov[n], (out["pos"][sel], out["code"][sel].astype(np.int64), 0), 1)
+                got = {"ok": digest(*[cov[n] for n in sorted(cov)])[:16]}
+            except Exception as e:          # noqa: BLE001
+                got = {"error": type(e).__name__}
+            if got != gold[name]:
+                bad.append((name, threads, got, gold[name]))
+    assert not bad, (len(bad), bad[:10])

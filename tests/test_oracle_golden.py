@@ -235,3 +235,35 @@ def test_oracle_error_classes_equal_the_reference():
             got = {"error": type(e).__name__}
         want = gold[name]
         assert got.get("error") == want.get("error") and got.get("ok") == want.get("ok"), (name, got, want)
+
+
+def test_oracle_fuzz_error_classes_equal_the_reference():
+    """Differential fuzz against the reference itself: tests/golden/g_errors_fuzz.json holds what the REFERENCE does
+    with 2,000 seeded random mutations of small batches (scenarios.fuzz_error_cases: truncated / swapped / garbled
+    columns and lines, integers int() takes and does not take, repeated and malformed tags, CIGAR edits, reads cut
+    short or dropped, coordinates shifted off either end of the contig, second mappings of a read) — exception
+    class or a digest of the coverage it ends with.  The oracle must do the same with every one of them."""
+    import json
+    from scenarios import digest, fuzz_error_cases
+    from oracle.contig import OContig
+    from oracle.pafcigar import parse_paf, convert_records
+    from boss_runs_amd import synth
+    contigs, cases = fuzz_error_cases()
+    gold = json.load(open(os.path.join(GOLDEN, "g_errors_fuzz.json")))
+    assert set(gold) == {n for n, _, _ in cases} and len(gold) >= 2000
+    bad = []
+    for name, paf_text, seqs in cases:
+        conts = {n: OContig(n, synth.codes_to_str(c)) for n, c in contigs}
+        try:
+            paf = parse_paf(paf_text, min_len=200)
+            inc = convert_records(paf, seqs)
+            for n, c in conts.items():
+                c.increment_coverage(inc[n])
+            got = {"ok": digest(*[conts[n].coverage for n in sorted(conts)])[:16]}
+        except Exception as e:          # noqa: BLE001
+            got = {"error": type(e).__name__}
+        if got != gold[name]:
+            bad.append((name, got, gold[name]))
+    assert not bad, (len(bad), bad[:10])
+    classes = {v.get("error", "ok") for v in gold.values()}
+    assert classes >= {"ok", "ValueError", "IndexError", "KeyError", "AssertionError", "TypeError", "OverflowError"}

@@ -1279,6 +1279,46 @@ def test_device_front_end_error_classes_equal_the_reference():
 
 
 @pytest.mark.gpu
+def test_device_front_end_fuzz_error_classes_equal_the_reference():
+    """tests/golden/g_errors_fuzz.json — what the REFERENCE does with 2,000 seeded random mutations of small batches
+    (scenarios.fuzz_error_cases) — through the C-ABI and the DEVICE CIGAR walk: the same exception class where the
+    reference raises, and nothing ingested; the same coverage where it goes on.  One engine for all cases: its
+    counters are exported, compared and zeroed after every batch that passes."""
+    import json
+    from scenarios import digest, fuzz_error_cases
+    from boss_runs_amd.engine import Engine
+    from boss_runs_amd.scoring import SiteScoring
+    from boss_runs_amd import synth
+    contigs, cases = fuzz_error_cases()
+    gold = json.load(open(os.path.join(GOLDEN, "g_errors_fuzz.json")))
+    hap = SiteScoring(1)
+    eng = Engine(nbarcodes=1, track_entropy=False)
+    for n, c in contigs:
+        eng.add_contig(n, synth.codes_to_str(c))
+    eng.finalize(hap.score0[0], hap.ent0[0])
+    eng.set_lut(*hap.tables())
+    order = [k for k, _ in sorted(enumerate(contigs), key=lambda kc: kc[1][0])]
+    bad = []
+    for name, paf_text, seqs in cases:
+        try:
+            eng.stage_batch(paf_text, seqs, ingest=True)
+            eng.sweep()
+            cov = [eng.export(k, "coverage") for k in order]
+            got = {"ok": digest(*cov)[:16]}
+            for k, a in zip(order, cov):
+                if a.any():
+                    eng.import_state(k, "coverage", np.zeros_like(a))
+        except Exception as e:          # noqa: BLE001
+            got = {"error": type(e).__name__}
+            eng.sweep()
+            assert all(int(eng.export(k, "coverage").sum()) == 0 for k in range(len(contigs))), name
+        if got != gold[name]:
+            bad.append((name, got, gold[name]))
+    eng.close()
+    assert not bad, (len(bad), bad[:10])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nb,ploidy", [(1, 2), (3, 1)])
 def test_lookahead_staging_vs_oracle(in_tmp, nb, ploidy):
     """process_batch_paf(lookahead=next batch): the next batch is parsed, uploaded and walked on the
