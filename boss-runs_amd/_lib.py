@@ -120,6 +120,7 @@ PROTOTYPES = {
     "bossx_dist_update_launch": (C.c_int, [C.c_void_p, C.POINTER(UpdateParams), C.c_void_p, C.c_void_p, C.POINTER(UpdateResult)]),
     "bossx_dist_update_collect": (C.c_int, [C.c_void_p, C.POINTER(UpdateParams), C.c_void_p, C.c_void_p, C.POINTER(UpdateResult)]),
     "bossx_dist_collectives": (C.c_int64, [C.c_void_p]),
+    "bossx_dist_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "bossx_chain_stats": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bossx_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "bossx_host_free": (C.c_int, [C.c_void_p]),

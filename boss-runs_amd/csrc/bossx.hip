@@ -95,6 +95,8 @@ struct bossx_engine {
     int32_t dist_rank = 0, dist_world = 1;
     bool dist_armed = false;           // "some strategy is on" has been seen globally (sticky)
     int64_t n_collectives = 0;
+    uint8_t *d_gather = nullptr; size_t gather_cap = 0;         // bossx_dist_allgather: (world + 1) slots in HBM ...
+    uint8_t *h_gather_pin = nullptr; size_t gather_pin_cap = 0; // ... and page-locked on the host
 
     std::vector<ContigInfo> contigs;                    // add order (rejected included)
     std::unordered_map<std::string, int32_t> index;     // name -> add order
@@ -489,6 +491,8 @@ void bossx_destroy(bossx_engine *h) {
     if (h->h_pin) hipHostFree(h->h_pin);
     if (h->h_paf_pin) hipHostFree(h->h_paf_pin);
     if (h->h_plan_pin) hipHostFree(h->h_plan_pin);
+    if (h->h_gather_pin) hipHostFree(h->h_gather_pin);
+    if (h->d_gather) hipFree(h->d_gather);
     if (h->d_paf) hipFree(h->d_paf);
     if (h->d_plans) hipFree(h->d_plans);
     if (h->d_walk) hipFree(h->d_walk);
@@ -2200,20 +2204,28 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
     bool load() {
         if (lib) return true;
-        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char *n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        // BOSSX_RCCL_LIB: another library with RCCL's entry points (tests/rccl_loopback: ranks that are threads of one
+        // process on one device — the native driver's N > 1 path on a one-GPU box)
+        if (const char *e = getenv("BOSSX_RCCL_LIB")) {
+            if (!(lib = dlopen(e, RTLD_NOW | RTLD_LOCAL))) { err = std::string("BOSSX_RCCL_LIB: ") + (dlerror() ? dlerror() : e); return false; }
+        } else {
+            const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+            for (const char *n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        }
         if (!lib) { err = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return false; }
         auto sym = [&](const char *n) { void *p = dlsym(lib, n); if (!p) err = std::string("librccl lacks ") + n; return p; };
         GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
         CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
         AllReduce = reinterpret_cast<decltype(AllReduce)>(sym("ncclAllReduce"));
+        AllGather = reinterpret_cast<decltype(AllGather)>(sym("ncclAllGather"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
-        if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString) { lib = nullptr; return false; }
+        if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !AllGather || !GetErrorString) { lib = nullptr; return false; }
         return true;
     }
 };
@@ -2260,6 +2272,26 @@ int bossx_dist_init(bossx_engine *h, const uint8_t *id, int32_t rank, int32_t wo
 }
 
 int64_t bossx_dist_collectives(const bossx_engine *h) { return h ? h->n_collectives : 0; }
+
+// `bytes` bytes of every rank, in rank order, into recv_all[world * bytes] (host memory on both sides): the per-batch
+// summaries of sharded reads (mapping columns + read lengths, parallel.py account_batch) travel through the engine's
+// own communicator and stream — page-locked staging, one RCCL all-gather, one synchronisation.
+int bossx_dist_allgather(bossx_engine *h, const void *send, void *recv_all, size_t bytes) {
+    if (!h || !h->comm || !send || !recv_all || !bytes) return fail(h, BOSSX_E_INVALID, "bad dist_allgather call (bossx_dist_init first)");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const size_t world = size_t(h->dist_world), total = (world + 1) * bytes;
+    int rc;
+    if ((rc = grow_dev(h, &h->d_gather, &h->gather_cap, total, 256))) return rc;
+    if ((rc = grow_pin(h, &h->h_gather_pin, &h->gather_pin_cap, total))) return rc;
+    memcpy(h->h_gather_pin, send, bytes);
+    HIPCHK(hipMemcpyAsync(h->d_gather, h->h_gather_pin, bytes, hipMemcpyHostToDevice, h->stream));
+    NCCLCHK(rccl().AllGather(h->d_gather, h->d_gather + bytes, bytes, ncclInt8, h->comm, h->stream));
+    ++h->n_collectives;
+    HIPCHK(hipMemcpyAsync(h->h_gather_pin + bytes, h->d_gather + bytes, world * bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    memcpy(recv_all, h->h_gather_pin + bytes, world * bytes);
+    return BOSSX_OK;
+}
 
 int bossx_chain_stats(const bossx_engine *h, int64_t out[4]) {
     if (!h || !out) return BOSSX_E_INVALID;

@@ -412,6 +412,7 @@ class Engine:
         assert uid.size == 128
         self._ck(self.lib.bossx_dist_init(self.h, uid.ctypes.data, int(rank), int(world)))
         self.dist_native = True
+        self.dist_world = int(world)
 
     def dist_chain(self, windows, mult):
         """bossx_dist_chain: the global "some strategy is on" exchange (until it is) + the move_sum chain."""
@@ -420,6 +421,14 @@ class Engine:
         assert w.shape == (_lib.NWIN,) and m.shape == (10,)
         self._ck(self.lib.bossx_dist_chain(self.h, w.ctypes.data, m.ctypes.data))
         self._benefit_done = tuple(w.tolist())
+
+    def dist_allgather(self, arr):
+        """bossx_dist_allgather: same-shape arrays from every rank, stacked on a new leading axis (through the
+        engine's own communicator and stream)."""
+        arr = np.ascontiguousarray(arr)
+        out = np.empty((self.dist_world,) + arr.shape, dtype=arr.dtype)
+        self._ck(self.lib.bossx_dist_allgather(self.h, arr.ctypes.data, out.ctypes.data, arr.nbytes))
+        return out
 
     @property
     def dist_collectives(self):

@@ -269,7 +269,8 @@ class DistributedBossRuns(BossRuns):
             buf[4 + 2 * cap:4 + 2 * cap + k] = summ["tstart"]
             buf[4 + 3 * cap:4 + 3 * cap + k] = summ["tend"]
             buf[4 + 4 * cap:4 + 4 * cap + m] = np.minimum(read_lengths, 2 ** 31 - 1)
-            allb = self.comm.allgather(buf)
+            # (native driver: the library's own communicator and stream; otherwise torch.distributed)
+            allb = self.engine.dist_allgather(buf) if getattr(self, "native", False) else self.comm.allgather(buf)
             # the read lengths first: the move_sum windows (and with them the chain) wait for them
             read_lengths = np.concatenate([b[4 + 4 * cap:4 + 4 * cap + int(b[1])] for b in allb]).astype(np.int64)
             self.rl_dist.update(read_lengths)

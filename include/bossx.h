@@ -330,6 +330,10 @@ int bossx_dist_update_launch(bossx_engine *h, const bossx_update_params *up, uin
 int bossx_dist_update_collect(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_all, uint8_t *contig_on,
                               bossx_update_result *res);
 int64_t bossx_dist_collectives(const bossx_engine *h);
+/* `bytes` bytes from every rank, in rank order, into recv_all[world * bytes] (host memory on both sides): the exchange of
+ * the per-batch summaries when reads are sharded over ranks (the reference has one process and no such step: SURVEY §8e;
+ * boss-runs_amd/parallel.py account_batch).  One RCCL all-gather on the engine's stream; counted by bossx_dist_collectives. */
+int bossx_dist_allgather(bossx_engine *h, const void *send, void *recv_all, size_t bytes);
 
 /* The benefit chain (calc_smu + calc_u, reference.py:215-269) runs chunk-parallel by default: candidate start
  * values per chunk on the matrix core, stitched, every segment recomputed from its exact start and checked against

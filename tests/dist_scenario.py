@@ -17,8 +17,6 @@ def worker(rank, world, port, tmp, nb, ploidy, ret, backend="gloo"):
     sys.path[:0] = [REPO, os.path.join(REPO, "tests")]
     import torch
     import torch.distributed as dist
-    from boss_runs_amd.config import BossConfig
-    from boss_runs_amd.parallel import DistributedBossRuns
     engine = None
     if backend == "nccl":
         # one process per GPU; the engine is created by DistributedBossRuns on torch's stream and the
@@ -30,17 +28,29 @@ def worker(rank, world, port, tmp, nb, ploidy, ret, backend="gloo"):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         engine = FakeEngine(nbarcodes=nb, ploidy=ploidy)
     os.chdir(tempfile.mkdtemp(dir=tmp))
+    out, runs = run_rank(rank, nb, ploidy, engine=engine, device=rank if backend == "nccl" else None)
+    ret[rank] = out
+    dist.barrier()
+    if backend == "nccl":
+        runs.engine.close()
+    dist.destroy_process_group()
+
+
+def run_rank(rank, nb, ploidy, engine=None, device=None, comm=None):
+    """One rank of the scenario: three sharded batches through DistributedBossRuns; what it ends each update with."""
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.parallel import DistributedBossRuns
     contigs = e2e_reference()
     args = BossConfig()
     args.general.name = "dist%d" % rank
     args.optional.ploidy = ploidy
     args.optional.reject_refs = E2E_REJECT
-    if backend == "nccl":
-        args.gpu.device = rank
+    if device is not None:
+        args.gpu.device = device
     if nb > 1:
         args.general.barcodes = ["barcode%02d" % (i + 1) for i in range(nb)]
     runs = DistributedBossRuns(args)
-    runs.init(contigs=e2e_contig_strings(contigs), engine=engine, sharded_reads=True)
+    runs.init(contigs=e2e_contig_strings(contigs), engine=engine, sharded_reads=True, comm=comm)
     out = []
     for b in range(3):
         batch = e2e_batch(contigs, b, nb)
@@ -64,11 +74,7 @@ def worker(rank, world, port, tmp, nb, ploidy, ret, backend="gloo"):
                         strat={n: np.array(c.strat, copy=True) for n, c in runs.contigs.items()},
                         approx_ccl=runs.rl_dist.approx_ccl.copy(), starts=runs.read_starts.merge().copy(),
                         collectives=runs.n_collectives))
-    ret[rank] = out
-    dist.barrier()
-    if backend == "nccl":
-        runs.engine.close()
-    dist.destroy_process_group()
+    return out, runs
 
 
 def oracle_expected(nb, ploidy):
@@ -106,3 +112,70 @@ def check(ret, expected, world, full_stats=True):
                 assert np.allclose(got["stats"]["f_grid"], exp["detail"]["f_grid"], rtol=1e-11)
             for n, st in exp["strat"].items():
                 assert np.array_equal(got["strat"][n], st), (rank, b, n)
+
+
+class ThreadComm:
+    """Stand-in for parallel.Comm when the ranks are THREADS of one process (tests/rccl_loopback): the few host-side
+    exchanges of DistributedBossRuns (the communicator id at init, the finished masks) go through a shared
+    barrier; everything per update goes through the library's own communicator (BOSSX_RCCL_LIB)."""
+
+    class Shared:
+        def __init__(self, world):
+            import threading
+            self.world = world
+            self.barrier = threading.Barrier(world, timeout=120)
+            self.slots = [None] * world
+
+    def __init__(self, shared, rank):
+        import torch
+        self.shared, self.rank, self.world = shared, rank, shared.world
+        self.on, self.device, self.torch, self.dist, self.force = True, "cuda", torch, None, False
+        self.n_collectives = 0
+
+    def allgather(self, arr):
+        sh = self.shared
+        sh.slots[self.rank] = np.ascontiguousarray(arr).copy()
+        sh.barrier.wait()
+        out = np.stack(sh.slots)
+        sh.barrier.wait()
+        self.n_collectives += 1
+        return out
+
+    def allreduce(self, arr, op="sum"):
+        allv = self.allgather(arr)
+        return allv.sum(axis=0).astype(allv.dtype) if op == "sum" else allv.max(axis=0)
+
+
+def main_threads(nb, ploidy, tmp, out_path, world=2):
+    """`world` ranks as threads of THIS process, every engine on device 0, the native driver's collectives through the
+    loopback library: run with BOSSX_RCCL_LIB set (test_parity_gpu.py builds it and starts this as a subprocess)."""
+    import pickle
+    import threading
+    assert os.environ.get("BOSSX_RCCL_LIB"), "BOSSX_RCCL_LIB must name the loopback library"
+    sys.path[:0] = [REPO, os.path.join(REPO, "tests")]
+    os.chdir(tmp)
+    shared = ThreadComm.Shared(world)
+    ret, errs = {}, []
+
+    def go(rank):
+        try:
+            ret[rank], runs = run_rank(rank, nb, ploidy, device=0, comm=ThreadComm(shared, rank))
+            shared.barrier.wait()
+            runs.engine.close()
+        except BaseException as e:      # noqa: BLE001 - reported by the parent
+            import traceback
+            errs.append((rank, traceback.format_exc()))
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=go, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    with open(out_path, "wb") as fh:
+        pickle.dump(dict(ret=ret, errs=errs), fh)
+    return 1 if errs else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main_threads(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]))

@@ -13,6 +13,7 @@ from scenarios import (GOLDEN, SCENARIOS, E2E_BATCHES, E2E_REJECT, batch_digest,
                        e2e_contig_strings, e2e_reference, unpack_strat)
 
 pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _product(ploidy, nb, in_tmp):
@@ -1276,6 +1277,41 @@ def test_device_front_end_error_classes_equal_the_reference():
         eng.close()
     assert not bad, bad
 
+
+
+def _loopback_rccl():
+    """tests/rccl_loopback/librccl_loopback.so (built by __graft_entry__.build(); here if it is missing)."""
+    import subprocess
+    d = os.path.join(REPO, "tests", "rccl_loopback")
+    so = os.path.join(d, "librccl_loopback.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(d, "rccl_loopback.cpp")):
+        subprocess.run(["make", "-C", d], check=True)
+    return so
+
+
+@pytest.mark.parametrize("nb,ploidy", [(1, 2), (2, 1)])
+def test_native_driver_two_ranks_on_one_device_vs_oracle(nb, ploidy, tmp_path):
+    """The native multi-GPU driver with world = 2 on a ONE-GPU box: two engines on device 0, each owning its share of
+    the contigs, driven by two threads of one process; every collective of the update — the "some strategy is on"
+    flag, halo rows + normaliser, the exact histogram limbs (bossx_dist_update) and the batch summaries of the sharded
+    reads (bossx_dist_allgather) — goes through the library's communicator, which BOSSX_RCCL_LIB points at the
+    loopback double of librccl (tests/rccl_loopback).  Thresholds, statistics and every contig's mask on both
+    ranks equal the single-process oracle's, update by update."""
+    import pickle
+    import subprocess
+    import sys
+    import dist_scenario
+    so = _loopback_rccl()
+    out = tmp_path / "ranks.pkl"
+    env = dict(os.environ, BOSSX_RCCL_LIB=so, PYTHONPATH=os.pathsep.join([REPO, os.path.join(REPO, "tests")]))
+    env.pop("BOSSX_TORCH_COLLECTIVES", None)
+    p = subprocess.run([sys.executable, os.path.join(REPO, "tests", "dist_scenario.py"), str(nb), str(ploidy), str(tmp_path), str(out)],
+                       capture_output=True, text=True, timeout=900, env=env)
+    got = pickle.load(open(out, "rb")) if out.exists() else dict(ret={}, errs=[("-", "no result file")])
+    assert p.returncode == 0 and not got["errs"], (p.stderr[-3000:], got["errs"])
+    dist_scenario.check(got["ret"], dist_scenario.oracle_expected(nb, ploidy), 2, full_stats=False)
+    # per update: the summaries' all-gather + two all-reduces (three until some strategy is on), all inside the library
+    assert all(got["ret"][r][-1]["collectives"] >= 3 * 3 for r in range(2))
 
 
 @pytest.mark.gpu
