@@ -912,7 +912,8 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         // NEGATIVE ends count from the contig's end — inside the contig the reference goes on there, anything
         // else leaves a slice shorter than the mapping (IndexError)
         bool range_bad = false;
-        if (local && !bad_t && pl.tlo < 0) {
+        if (local && !bad_t && pl.thi - pl.tlo > int64_t(INT32_MAX)) range_bad = true;      // (longer than any contig: checked here, never laid out)
+        else if (local && !bad_t && pl.tlo < 0) {
             const int64_t clen = contigs[size_t(cidx)].length;
             if (pl.thi == pl.tlo) range_bad = false;                 // nothing to add
             else if (pl.thi < 0 && pl.tlo + clen >= 0) { pl.tlo += clen; pl.thi += clen; }
@@ -929,7 +930,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             if (code) { pre_fail(code, "read '" + r.qname + "': " + msg); break; }
             if (range_bad && !pre_range.code) {
                 pre_range.group = int64_t(gi); pre_range.code = BOSSX_E_RANGE;
-                pre_range.msg = "read '" + r.qname + "': mapping starts before the start of " + contigs[size_t(cidx)].name;
+                pre_range.msg = "read '" + r.qname + "': mapping lies outside " + contigs[size_t(cidx)].name;
             }
         }
         if (!walk_it) {
