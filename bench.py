@@ -576,6 +576,22 @@ def spawn_ranks(a):
     sys.stdout.flush()
 
 
+def host_cpu_state():
+    """CPU time of this process so far and the cgroup's throttling counters (cgroup v2; zeros where absent)."""
+    import time
+    st = {"cpu_s": time.process_time(), "nr_throttled": 0, "throttled_usec": 0, "quota": None}
+    try:
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            k, v = line.split()
+            if k in ("nr_throttled", "throttled_usec"):
+                st[k] = int(v)
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        st["quota"] = None if q == "max" else int(q) / int(p)
+    except (OSError, ValueError):
+        pass
+    return st
+
+
 def main():
     a = parse_args()
     if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and not a.prepare_only:
@@ -664,7 +680,9 @@ def main():
     eng.enable_timing(True)          # HIP events on the engine's own streams, collected after the region
     base = eng.kernel_stats()
     sel = batches[a.warmup:]
+    host_before = host_cpu_state()
     elapsed = timed(barrier, lambda: [R.step_e2e(b) for b in sel])
+    host_after = host_cpu_state()
     stats = eng.kernel_stats()
     kern = kernel_table(stats, base)
     # ---- secondary: the steady state of a REPLAY, where the caller already holds batch i+1 and hands it along
@@ -719,8 +737,8 @@ def main():
         # (the profiled run also holds the every-tile sweeps of the full_sweep loop: when the timed region
         # swept only the tiles that receive bases, its traffic is that of the ingesting launches alone)
         incremental = kern[roof_k]["bytes"] < 0.99 * kern_full[roof_k]["bytes"]
-        traffic, traffic_src, traffic_commit, traffic_ksrc = pmc_traffic(workload, "site_sweep_kernel",
-                                                           only="site_sweep_kernel<true" if incremental else None)
+        traffic, traffic_src, traffic_commit, traffic_ksrc = pmc_traffic(workload, "site_sweep",
+                                                           only="_kernel<true" if incremental else None)
         commit = current_commit()
         longest_bins = max(c.length // 100 + 1 for c in runs.contigs_filt.values())
         out = {
@@ -779,6 +797,12 @@ def main():
                                       "of the fallback kernel, not of an update"},
             "host": {"stage_batch_ms_mean": 1e3 * float(np.mean(t_stage)),
                      "batch_generation_s": t_gen,
+                     # the host side of the timed region: CPUs this container may use (CFS quota), CPU-seconds per wall-second
+                     # the process spent inside it, and how long the scheduler held its threads back there (cgroup cpu.stat)
+                     "cpu_quota_cores": host_before["quota"],
+                     "cpus_busy_in_timed_region": (host_after["cpu_s"] - host_before["cpu_s"]) / max(elapsed, 1e-9),
+                     "throttled_ms_in_timed_region": (host_after["throttled_usec"] - host_before["throttled_usec"]) / 1e3,
+                     "throttled_periods_in_timed_region": host_after["nr_throttled"] - host_before["nr_throttled"],
                      "note": "stage_batch = native PAF/CIGAR parse + upload of one batch (inside ms_per_step)"},
             "move_sum_on_fp64_matrix_core": eng.matrix_chain,
             "benefit_chain_form": dict(eng.chain_stats(), note="chunk-parallel, exact (candidate tables on the matrix core -> stitched start "

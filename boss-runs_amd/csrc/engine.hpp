@@ -192,6 +192,7 @@ struct ParseInput {
 void pool_run(int n_tasks, const std::function<void(int)> &fn);
 
 size_t ops_capacity_for(size_t paf_len);
+int cpu_budget();                // hardware threads, affinity mask and cgroup CPU quota, whichever is smallest
 int parse_threads();             // BOSSX_PARSE_THREADS, default min(8, hardware threads)
 
 // Parses the PAF text, picks the best mapping per read and expands CIGARs into emit runs.

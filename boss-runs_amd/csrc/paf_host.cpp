@@ -12,6 +12,8 @@
 #include "engine.hpp"
 #include "bossx_py.h"
 
+#include <sched.h>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -597,8 +599,7 @@ class WorkPool {
     // bounds the pool as well as the line parse (tasks are pulled dynamically: fewer workers still
     // finish the job, the caller takes part).
     static int worker_cap() {
-        const unsigned hc = std::thread::hardware_concurrency();
-        int cap = std::min<int>(hc > 1 ? int(hc) - 1 : 0, 2 * parse_threads() - 1);
+        int cap = std::min<int>(cpu_budget() - 1, 2 * parse_threads() - 1);
         if (getenv("BOSSX_PARSE_THREADS")) cap = std::min(cap, parse_threads() - 1);
         if (const char *e = getenv("BOSSX_POOL_THREADS")) cap = std::min(cap, std::max(atoi(e), 1) - 1);
         return std::max(cap, 0);
@@ -653,10 +654,34 @@ struct JobGuard {
 
 size_t ops_capacity_for(size_t paf_len) { return paf_len / 2 + paf_len / 16 + 64; }
 
+// CPUs this process may actually use: the hardware threads, the affinity mask, and the container's CFS quota
+// (cgroup v2 cpu.max, v1 cpu.cfs_quota_us) — a pool sized for 256 hardware threads inside a 16-CPU quota is
+// throttled by the scheduler for the rest of every 100-ms period it overdraws.
+int cpu_budget() {
+    static const int budget = [] {
+        unsigned hc = std::thread::hardware_concurrency();
+        int n = int(hc ? hc : 1u);
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int k = CPU_COUNT(&set); if (k > 0) n = std::min(n, k); }
+        long long quota = -1, period = -1;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64] = {0};
+            if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+            fclose(f);
+        } else {
+            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
+            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = -1; fclose(g); }
+        }
+        if (quota > 0 && period > 0) n = std::min<long long>(n, std::max<long long>(1, quota / period));
+        return std::max(n, 1);
+    }();
+    return budget;
+}
+
 int parse_threads() {
     if (const char *e = getenv("BOSSX_PARSE_THREADS")) { const int v = atoi(e); if (v >= 1) return std::min(v, 64); }
-    const unsigned hc = std::thread::hardware_concurrency();
-    return int(std::max(1u, std::min(hc ? hc : 1u, 16u)));
+    // (two of the budget are left to the calling thread's own work and the runtime's threads)
+    return std::max(1, std::min(cpu_budget() - 2, 16));
 }
 
 int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs,

@@ -12,10 +12,10 @@ bench)
   timeout 300 python bench.py --workload ecoli --no-others --no-large > gpurun_out/bench/ecoli.json 2> gpurun_out/bench/ecoli.err
   timeout 300 python bench.py --workload barcoded --no-others --no-large > gpurun_out/bench/barcoded.json 2> gpurun_out/bench/barcoded.err
   timeout 300 python bench.py --workload grch38 --steps 8 --warmup 3 > gpurun_out/bench/grch38.json 2> gpurun_out/bench/grch38.err
-  timeout 120 python3 scripts/probe_chain.py > gpurun_out/bench/chain_probe.txt 2>&1
-  timeout 60 ./scripts/mfma_chain_floor.bin > gpurun_out/bench/mfma_chain_floor.txt
-  timeout 60 ./scripts/mfma_chain_groups.bin > gpurun_out/bench/mfma_chain_groups.txt
-  timeout 60 ./scripts/mfma_chain_neighbours.bin > gpurun_out/bench/mfma_chain_neighbours.txt
+
+
+
+
   for f in default ecoli barcoded grch38; do python3 -c "
 import json,sys
 d=json.load(open('gpurun_out/bench/$f.json'))

@@ -8,7 +8,7 @@ bench._GEN[w] = bench.make_reference(w, 0)
 nb = bench.WORKLOADS[w][3]
 batches = bench.generate_batches([(w, 100 + i, 4000, nb) for i in range(14)])
 os.chdir(tempfile.mkdtemp())
-runs, nb = bench.make_runs(w, bench._GEN[w], 0, 1, 0, False)
+runs, nb = bench.make_runs(w, bench._GEN[w], 0, 1, 0, os.environ.get("ENT", "1") == "1")
 eng = runs.engine
 T = {}
 for it, b in enumerate(batches):
