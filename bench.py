@@ -681,8 +681,10 @@ def main():
     base = eng.kernel_stats()
     sel = batches[a.warmup:]
     host_before = host_cpu_state()
+    cs0 = eng.chain_stats()
     elapsed = timed(barrier, lambda: [R.step_e2e(b) for b in sel])
     host_after = host_cpu_state()
+    cs1 = eng.chain_stats()
     stats = eng.kernel_stats()
     kern = kernel_table(stats, base)
     # ---- secondary: the steady state of a REPLAY, where the caller already holds batch i+1 and hands it along
@@ -690,6 +692,7 @@ def main():
     n_pipe = min(len(sel), 10)
     R.prime(sel[0])
     elapsed_pipe = timed(barrier, lambda: R.run_e2e(sel[:n_pipe], tail=extra))
+    cs2 = eng.chain_stats()
     # the CPU port runs ONE update here, from the state the engine holds now — a regime with scored,
     # unscored and capped sites side by side.  (The deeply saturated regime a long run ends in — every site
     # capped, thresholds of 1e-304 — is compared separately: scripts/ecoli_diff.py at 90 / 120 / 150 updates,
@@ -704,7 +707,9 @@ def main():
     # ---- the same updates with the inputs already resident in HBM (parse + upload outside) --------
     summ, t_stage = R.stage(sel)
     base2 = eng.kernel_stats()
+    cs3 = eng.chain_stats()
     elapsed_res = timed(barrier, lambda: [R.step_resident(i, b, s) for i, (b, s) in enumerate(zip(sel, summ))])
+    cs4 = eng.chain_stats()
     kern_res = kernel_table(eng.kernel_stats(), base2)
     # ---- and once more with every tile swept at every update (BOSSX_INCREMENTAL=0): the streaming form
     # of the sweep kernel on this workload, for the roofline of the kernel as opposed to the update
@@ -805,7 +810,11 @@ def main():
                      "throttled_periods_in_timed_region": host_after["nr_throttled"] - host_before["nr_throttled"],
                      "note": "stage_batch = native PAF/CIGAR parse + upload of one batch (inside ms_per_step)"},
             "move_sum_on_fp64_matrix_core": eng.matrix_chain,
-            "benefit_chain_form": dict(eng.chain_stats(), note="chunk-parallel, exact (candidate tables on the matrix core -> stitched start "
+            "benefit_chain_form": dict(eng.chain_stats(),
+                                       per_loop={"timed_lone_updates": {k: cs1[k] - cs0[k] for k in cs0},
+                                                 "pipelined": {k: cs2[k] - cs1[k] for k in cs1},
+                                                 "resident": {k: cs4[k] - cs3[k] for k in cs3}},
+                                       note="chunk-parallel, exact (candidate tables on the matrix core -> stitched start "
                                        "values -> every 4096-bin segment recomputed from its exact start and checked against its "
                                        "successor's; the serial kernel is enqueued behind, gated on a failed check); counters since "
                                        "finalize, over every loop of this script"),
