@@ -156,7 +156,8 @@ struct bossx_engine {
     double pending_emit = 0, pending_ops = 0;
     bool touched_dirty = false;     // the `touched` byte array holds flags the next sweep must read
     bool full_sweep_needed = true;  // bin sums / bucket sums are not current everywhere (start, import, preload): sweep every tile
-    bool dz_fresh = false;          // the last sweep may have zeroed sites by dropout for the first time (see launch_sweep)
+    bool dz_fresh = false;          // the last sweep may have zeroed sites by dropout for the first time, anywhere (see launch_sweep)
+    std::vector<uint8_t> dz_fresh_k;   // ... or in these contigs only: their threshold moved in the last sweep
     std::unordered_map<const void *, size_t> lds_granted;   // dynamic LDS each chain kernel has been cleared for ON THIS DEVICE
     std::vector<int32_t> last_thr;  // dropout threshold each contig was last swept with
     uint32_t *d_tile_ref = nullptr;
@@ -1417,20 +1418,26 @@ int launch_sweep(bossx_engine *h) {
     // The reference looks every site that dropout zeroed up again at the NEXT update (`scores == 0.0`,
     // sequences.py:433-441) and writes its entropy then.  New zeros only appear in a sweep whose
     // threshold moved (or after an import / preload): coverage only grows, so under an unchanged
-    // threshold no site falls to or below it.  The update after such a sweep therefore sweeps every
-    // tile once more when the entropy array is kept — an untouched tile would otherwise hold the
-    // entropy (and the SCORED bit) of its freshly zeroed sites back until it next receives a base.
-    const bool dz_resweep = h->dz_fresh && h->d_entropy && !getenv("BOSSX_NO_DZ_RESWEEP");
+    // threshold no site falls to or below it — and thresholds are per contig.  The update after such a sweep
+    // therefore sweeps once more, when the entropy array is kept, every tile of the contigs whose threshold
+    // had moved (everything after an import / preload) — an untouched tile would otherwise hold the entropy
+    // (and the SCORED bit) of its freshly zeroed sites back until it next receives a base.  (Round 3 swept
+    // the whole reference again for ONE contig's threshold: at GRCh38, 27 contigs crossing int(mean / 8) at
+    // different updates, a 10-ms sweep of 3.1 Gb behind every one of them.)
+    const bool dz_on = h->d_entropy && !getenv("BOSSX_NO_DZ_RESWEEP");
+    const bool dz_resweep = h->dz_fresh && dz_on;
+    if (h->dz_fresh_k.size() != thr.size()) h->dz_fresh_k.assign(thr.size(), 0);
     // A contig whose own threshold moved is swept whole; the others keep their untouched tiles (27 contigs
     // cross int(mean / 8) at 27 different updates: a 150-kb scaffold must not cost a sweep of 3.1 Gb).
     const bool full = h->full_sweep_needed || h->touched_dirty || split || !want_inc || dz_resweep;
     std::vector<size_t> resweep;                 // local contigs swept whole although the update is incremental
     if (!full)
         for (size_t k = 0; k < thr.size(); ++k)
-            if (thr[k] != h->last_thr[k] && !h->contigs[size_t(h->filt[k])].remote) resweep.push_back(k);
+            if ((thr[k] != h->last_thr[k] || (dz_on && h->dz_fresh_k[k])) && !h->contigs[size_t(h->filt[k])].remote) resweep.push_back(k);
     bool any_thr = false;
     for (int32_t t : thr) any_thr = any_thr || t >= 0;
-    h->dz_fresh = any_thr && (h->full_sweep_needed || h->touched_dirty || thr_changed);
+    h->dz_fresh = any_thr && (h->full_sweep_needed || h->touched_dirty);
+    for (size_t k = 0; k < thr.size(); ++k) h->dz_fresh_k[k] = (thr[k] >= 0 && thr[k] != h->last_thr[k]) ? 1 : 0;
     // The chain of this update may run NEXT TO the sweep (second stream, tiles handed over as they
     // are published).  Measured on MI355X it no longer pays by default: the concurrent chain variant
     // is ~8 % slower than the serial one (agent-scope loads, flag polling), a publishing sweep is
