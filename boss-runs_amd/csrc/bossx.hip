@@ -1550,11 +1550,15 @@ int launch_sweep(bossx_engine *h) {
         unsigned long long pr[24];
         HIPCHK(hipMemcpy(pr, P.probe, sizeof(pr), hipMemcpyDeviceToHost));
         HIPCHK(hipMemset(P.probe, 0, sizeof(pr)));
+        // (site_sweep1_kernel: seven words — tiles | top..ingested | ..gate passed | ..scored | barrier | phase B | behind it;
+        //  the barcoded template: six — items | top..gathered | ..scored | barrier | phase B | tail)
         for (int o = 0; o <= 8; o += 8)
-            if (pr[o])
-                fprintf(stderr, "[sweep probe] %s: %llu items (wave 0 of each block), cycles per item: top..codes gathered %.0f | ..scored (phase A, next tile's loads issued) %.0f | barrier %.0f | phase B %.0f | tail %.0f | total %.0f\n",
-                        o ? "ingest" : "plain", pr[o], double(pr[o + 1]) / pr[o], double(pr[o + 2]) / pr[o], double(pr[o + 3]) / pr[o], double(pr[o + 4]) / pr[o],
-                        double(pr[o + 5]) / pr[o], double(pr[o + 1] + pr[o + 2] + pr[o + 3] + pr[o + 4] + pr[o + 5]) / pr[o]);
+            if (pr[o]) {
+                double tot = 0;
+                fprintf(stderr, "[sweep probe] %s: %llu tiles (wave 0 of each block), cycles per tile:", o ? "ingest" : "plain", pr[o]);
+                for (int i = 1; i < 7; ++i) { fprintf(stderr, " %.0f", double(pr[o + i]) / double(pr[o])); tot += double(pr[o + i]) / double(pr[o]); }
+                fprintf(stderr, " | total %.0f\n", tot);
+            }
     }
     if (h->pending_slot >= 0) {
         bossx_engine::Staged &st = h->slots[size_t(h->pending_slot)];
