@@ -86,6 +86,7 @@ struct bossx_engine {
     int32_t spec_pause = 0;            // updates left on the serial chain: too many chunks had to be added the plain way last time
     int64_t spec_plain_total = 0, spec_paused_updates = 0, spec_launches = 0;
     int64_t *d_chunk_off = nullptr; int64_t spec_total = 0, spec_max_segs = 0;
+    int32_t spec_seg_chunks = kSpecSegChunks;   // chunks per segment block of the chain's final pass (finalize)
     double *d_spec_tab = nullptr, *d_spec_starts = nullptr;
     unsigned long long *d_spec_stats = nullptr;
     int32_t nb = 1;
@@ -645,7 +646,29 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
             max_bins = std::max(max_bins, bins);
         }
         h->spec_total = off.back();
-        h->spec_max_segs = (max_bins + kSpecSeg - 1) / kSpecSeg;
+        // Segment length of the final pass: a segment block costs ~4 us + 6.8 us per chunk and has a CU to itself (its step
+        // arrays take 99 KB of LDS), so what a launch costs is ROUNDS of CUs x the block time — 546 blocks of four chunks at
+        // chr20+21 are three rounds (93 us), 242 blocks of nine chunks one (65 us).  The cheapest length up to 32 chunks:
+        {
+            int cus = 256;
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, h->cfg.device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+            double best = 0.0;
+            for (int32_t cch = kSpecSegChunks; cch <= 32; ++cch) {
+                int64_t blocks = 0;
+                for (size_t k = 0; k < h->filt.size(); ++k) {
+                    const ContigInfo &c = h->contigs[size_t(h->filt[k])];
+                    if (c.remote) continue;
+                    blocks += ((c.T + 1 + kSpecL - 1) / kSpecL + cch - 1) / cch;
+                }
+                blocks *= int64_t(nb) * 2;
+                const double cost = std::ceil(double(blocks) / double(cus)) * (4.0 + 6.8 * double(cch));
+                if (cch == kSpecSegChunks || cost < best) { best = cost; h->spec_seg_chunks = cch; }
+            }
+            if (const char *e = getenv("BOSSX_SEG_CHUNKS")) h->spec_seg_chunks = std::max(1, atoi(e));
+        }
+        const int64_t seg_bins = int64_t(h->spec_seg_chunks) * kSpecL;
+        h->spec_max_segs = (max_bins + seg_bins - 1) / seg_bins;
         // Does it pay?  Measured on MI355X (profiles/r03_*): the serial kernel walks 3.9 ns per bin of the longest contig, one
         // block per (contig, barcode, strand) and a CU each; the chunk-parallel form costs 5.2 ns per (window, strand, chunk)
         // table, 0.27 us per chunk of the longest contig for the stitch and 22 us per round of 256 segments.  Many short
@@ -656,14 +679,14 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
             for (size_t k = 0; k < h->filt.size(); ++k) {
                 const ContigInfo &c = h->contigs[size_t(h->filt[k])];
                 if (c.remote) continue;
-                segs += (c.T + 1 + kSpecSeg - 1) / kSpecSeg; chunks += (c.T + 1 + kSpecL - 1) / kSpecL;
+                segs += (c.T + 1 + seg_bins - 1) / seg_bins; chunks += (c.T + 1 + kSpecL - 1) / kSpecL;
                 longest = std::max<int64_t>(longest, c.T + 1); ++n_local;
             }
             const double blocks = double(n_local) * nb * 2;
             h->spec_est_serial_us = 3.9e-3 * double(longest) * std::ceil(blocks / 256.0);
             // (round 4: four windows per matrix operation in the candidates, ~0.08 us per chunk in the stitch)
             h->spec_est_us = 1.6e-3 * double(chunks) * nb * 2 * BOSSX_NWIN + 0.08 * double((longest + kSpecL - 1) / kSpecL) +
-                             22.0 * std::ceil(double(segs) * nb * 2 / 256.0) + 30.0;
+                             (4.0 + 6.8 * double(h->spec_seg_chunks)) * std::ceil(double(segs) * nb * 2 / 256.0) + 30.0;
             h->spec_plain_share = chunks > 0 ? double((longest + kSpecL - 1) / kSpecL) / (double(chunks) * nb * 2 * BOSSX_NWIN) : 0.0;
             const char *e = getenv("BOSSX_CHAIN_SPEC");
             if (!(e && atoi(e) == 2) && h->spec_est_us > 0.7 * h->spec_est_serial_us) h->chain_spec = false;
@@ -1747,14 +1770,14 @@ void launch_chain(bossx_engine *h, const ChainParams &P0, size_t lds, hipStream_
     else if (!live0 && h->chain_spec && h->matrix_chain && h->chain_ch == 256 && h->spec_total > 0) {
         // chunk-parallel: candidate tables -> stitched start values -> every segment at once (kernels.hip.inc)
         SpecParams Q;
-        P.spec_chunk_off = h->d_chunk_off; P.spec_total = h->spec_total; P.spec_starts = h->d_spec_starts;
+        P.spec_chunk_off = h->d_chunk_off; P.spec_total = h->spec_total; P.spec_starts = h->d_spec_starts; P.seg_chunks = h->spec_seg_chunks;
         Q.C = P; Q.chunk_off = h->d_chunk_off; Q.total_chunks = h->spec_total; Q.tab = h->d_spec_tab; Q.starts = h->d_spec_starts;
         Q.stats = getenv("BOSSX_SPEC_STATS") ? h->d_spec_stats : nullptr;
         Q.strict = getenv("BOSSX_SPEC_STRICT") ? atoi(getenv("BOSSX_SPEC_STRICT")) : 0;
         hipLaunchKernelGGL(chain_candidates_kernel, dim3(uint32_t(h->spec_total), (BOSSX_NWIN + kCandWin - 1) / kCandWin, uint32_t(h->nb * 2)), dim3(64), 0, stream, Q);
         hipLaunchKernelGGL(chain_stitch_kernel, dim3(uint32_t(h->filt.size() * size_t(h->nb) * 2 * BOSSX_NWIN)), dim3(64), 0, stream, Q);
-        if (getenv("BOSSX_SPEC_SELFTEST") && h->spec_total > kSpecSegChunks)      // (the first contig needs a second segment)
-            hipLaunchKernelGGL(chain_spoil_kernel, dim3(1), dim3(1), 0, stream, h->d_spec_starts, int64_t(kSpecSegChunks));
+        if (getenv("BOSSX_SPEC_SELFTEST") && h->spec_total > h->spec_seg_chunks)      // (the first contig needs a second segment)
+            hipLaunchKernelGGL(chain_spoil_kernel, dim3(1), dim3(1), 0, stream, h->d_spec_starts, int64_t(h->spec_seg_chunks));
         grant_lds(h, reinterpret_cast<const void *>(benefit_chain_kernel<true, false, 256, true>), lds);
         hipLaunchKernelGGL((benefit_chain_kernel<true, false, 256, true>), dim3(uint32_t(h->spec_max_segs), uint32_t(h->filt.size() * size_t(h->nb) * 2)),
                            dim3(kChainThreads), lds, stream, P);
