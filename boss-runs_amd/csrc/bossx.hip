@@ -89,6 +89,7 @@ struct bossx_engine {
     int32_t spec_seg_chunks = kSpecSegChunks;   // chunks per segment block of the chain's final pass (finalize)
     double *d_spec_tab = nullptr, *d_spec_starts = nullptr;
     unsigned long long *d_spec_stats = nullptr;
+    unsigned long long *d_spec_hash = nullptr;     // [rows] input hash of every table row (0: never built)
     int32_t nb = 1;
 
     // native multi-GPU driver (bossx_dist_init): RCCL communicator of this engine's device
@@ -471,15 +472,16 @@ void bossx_destroy(bossx_engine *h) {
     if (h->d_tile_order) hipFree(h->d_tile_order);
     if (h->d_carry_ring) hipFree(h->d_carry_ring);
     if (h->d_spec_stats && getenv("BOSSX_SPEC_STATS")) {
-        unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpy(st, h->d_spec_stats, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess)
-            fprintf(stderr, "[bossx] chunk-parallel chain: %llu (window, chunk) tables, %llu plain, %llu identity, %.1f candidates each; %llu chunks added plainly by the stitch; %lld updates on the serial chain meanwhile; %d mismatches (plain because: climbs more than 4 binades %llu, at most %llu; start not a normal positive number %llu)\n",
-                    st[0], st[1], st[2], st[0] > st[1] + st[2] ? double(st[3]) / double(st[0] - st[1] - st[2]) : 0.0, st[4], (long long)h->spec_paused_updates, h->spec_mismatches, st[5], st[7], st[6]);
+            fprintf(stderr, "[bossx] chunk-parallel chain: %llu (window, chunk) tables built + %llu left standing (inputs unchanged), %llu plain, %llu identity, %.1f candidates each; %llu chunks added plainly by the stitch; %lld updates on the serial chain meanwhile; %d mismatches (plain because: climbs more than 4 binades %llu, at most %llu; start not a normal positive number %llu)\n",
+                    st[0], st[8], st[1], st[2], st[0] > st[1] + st[2] ? double(st[3]) / double(st[0] - st[1] - st[2]) : 0.0, st[4], (long long)h->spec_paused_updates, h->spec_mismatches, st[5], st[7], st[6]);
     }
     if (h->d_chunk_off) hipFree(h->d_chunk_off);
     if (h->d_spec_tab) hipFree(h->d_spec_tab);
     if (h->d_spec_starts) hipFree(h->d_spec_starts);
     if (h->d_spec_stats) hipFree(h->d_spec_stats);
+    if (h->d_spec_hash) hipFree(h->d_spec_hash);
     if (h->d_tile_contig) hipFree(h->d_tile_contig);
     void *ptrs[] = {h->d_state, h->d_touched, h->d_strat, h->d_bucket_on, h->d_entropy, h->d_ds,
                     h->d_benefit, h->d_lut_score, h->d_lut_ent, h->d_fhat, h->d_bucket_sums, h->d_drop_count,
@@ -698,7 +700,7 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
             hipMalloc(reinterpret_cast<void **>(&h->d_spec_starts), rows * sizeof(double) + 64) != hipSuccess) {
             (void)hipGetLastError();
             h->chain_spec = false;          // (the serial chain needs no scratch)
-        } else if ((rc = dev_alloc(h, &h->d_spec_stats, 8, true))) return rc;
+        } else if ((rc = dev_alloc(h, &h->d_spec_stats, 12, true)) || (rc = dev_alloc(h, &h->d_spec_hash, rows + 8, true))) return rc;
         }
     }
     if (h->chain_flow_ce != 2) h->chain_gc = false;
@@ -1773,6 +1775,7 @@ void launch_chain(bossx_engine *h, const ChainParams &P0, size_t lds, hipStream_
         P.spec_chunk_off = h->d_chunk_off; P.spec_total = h->spec_total; P.spec_starts = h->d_spec_starts; P.seg_chunks = h->spec_seg_chunks;
         Q.C = P; Q.chunk_off = h->d_chunk_off; Q.total_chunks = h->spec_total; Q.tab = h->d_spec_tab; Q.starts = h->d_spec_starts;
         Q.stats = getenv("BOSSX_SPEC_STATS") ? h->d_spec_stats : nullptr;
+        Q.hash = getenv("BOSSX_SPEC_NO_SKIP") ? nullptr : h->d_spec_hash;
         Q.strict = getenv("BOSSX_SPEC_STRICT") ? atoi(getenv("BOSSX_SPEC_STRICT")) : 0;
         hipLaunchKernelGGL(chain_candidates_kernel, dim3(uint32_t(h->spec_total), (BOSSX_NWIN + kCandWin - 1) / kCandWin, uint32_t(h->nb * 2)), dim3(64), 0, stream, Q);
         hipLaunchKernelGGL(chain_stitch_kernel, dim3(uint32_t(h->filt.size() * size_t(h->nb) * 2 * BOSSX_NWIN)), dim3(64), 0, stream, Q);
