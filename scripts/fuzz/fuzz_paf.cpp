@@ -7,7 +7,7 @@
 // are too long or too short for the read, garbage and NUL bytes, empty reads, reads cut short, other
 // letters in reads, duplicate read names, barcodes out of range — and calls the parser with 1 or 3 threads.
 // Pass = no sanitizer report, and the return code is one the reference's behaviour maps to:
-//   0 ok | -3 ValueError | -4 KeyError | -5 IndexError | -8 TypeError | -9 AssertionError
+//   0 ok | -3 ValueError | -4 KeyError | -5 IndexError | -8 TypeError | -9 AssertionError | -10 OverflowError
 // (paf.py:18-75, 631-672; sequences.py:678-794; reference.py:138).  BOSSX_E_INVALID (-1) is what the
 // entry point returns when its own consistency checks of the emit runs / tile segments / device-walk plans
 // fail: a bug, reported with the input.
@@ -183,7 +183,7 @@ int main(int argc, char **argv) {
                     return 2;
                 }
         }
-        const bool known = rc == BOSSX_OK || rc == BOSSX_E_PARSE || rc == BOSSX_E_KEY || rc == BOSSX_E_RANGE || rc == BOSSX_E_TYPE || rc == BOSSX_E_ASSERT;
+        const bool known = rc == BOSSX_OK || rc == BOSSX_E_PARSE || rc == BOSSX_E_KEY || rc == BOSSX_E_RANGE || rc == BOSSX_E_TYPE || rc == BOSSX_E_ASSERT || rc == BOSSX_E_OVERFLOW;
         if (!known) {
             fprintf(stderr, "iteration %ld (seed %llu): return code %d: %s\n---- PAF (%zu bytes) ----\n", it, (unsigned long long)seed, rc, err, b.paf.size());
             fwrite(b.paf.data(), 1, b.paf.size(), stderr);
@@ -193,7 +193,7 @@ int main(int argc, char **argv) {
         }
         ++counts[-rc];
     }
-    printf("%ld batches: ok %ld, ValueError %ld, KeyError %ld, IndexError %ld, TypeError %ld, AssertionError %ld\n", iters, counts[0], counts[3], counts[4],
-           counts[5], counts[8], counts[9]);
+    printf("%ld batches: ok %ld, ValueError %ld, KeyError %ld, IndexError %ld, TypeError %ld, AssertionError %ld, OverflowError %ld\n", iters, counts[0], counts[3], counts[4],
+           counts[5], counts[8], counts[9], counts[10]);
     return 0;
 }
