@@ -52,6 +52,7 @@ struct alignas(16) EmitOp {
 };
 constexpr uint32_t kOpRev = 1u << 16;
 constexpr uint32_t kOpDel = 1u << 17;
+constexpr uint32_t kOpBcast = 1u << 18;   // every base of the run is read[qpos]: a one-base slice of the read laid under a longer CIGAR (numpy broadcasts it, sequences.py:790)
 
 struct ContigInfo {
     std::string name;
@@ -117,6 +118,7 @@ struct alignas(16) MapPlan {
 static_assert(sizeof(MapPlan) == 64, "MapPlan is uploaded as is");
 constexpr uint32_t kPlanRev = 1u << 8;
 constexpr uint32_t kPlanCheckBases = 1u << 9;
+constexpr uint32_t kPlanBroadcast = 1u << 10;      // the PAF columns select ONE base of the read: it stands under every query-consuming run
 
 // Outcome of the device walk per mapping (read back by the host before anything is ingested).
 enum : uint32_t {

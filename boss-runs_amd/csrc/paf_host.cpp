@@ -390,8 +390,8 @@ struct WalkOut {
 //   [t_ok false: tstart / tend stayed strings]        TypeError       min / max, :730-731
 //   reference bases emitted != |tend - tstart|        AssertionError  :732
 // The one authority on the CLASS of a CIGAR failure: the host walk and the device walk detect, this
-// classifies.  A read slice of exactly one base is broadcast by numpy over however many bases the CIGAR
-// consumes — the reference goes on with nonsense; this path refuses it (ValueError).
+// classifies.  (A read slice of exactly one base is broadcast by numpy over however many bases the CIGAR
+// consumes: the reference goes on with that, and so does this path.)
 int check_cigar_text(const char *cg, size_t n, int64_t q_len, int64_t span, bool q_ok, bool t_ok, std::string &msg) {
     size_t n_tok = 0;
     bool overflow = false, huge = false;
@@ -415,9 +415,10 @@ int check_cigar_text(const char *cg, size_t n, int64_t q_len, int64_t span, bool
     if (overflow) { msg = "CIGAR run of 2^32 bases or more"; return BOSSX_E_OVERFLOW; }
     if (huge) { msg = "CIGAR run of 10^9 bases or more"; return BOSSX_E_PARSE; }
     if (!q_ok) { msg = "query coordinate is not an integer"; return BOSSX_E_TYPE; }
-    if (consumed != static_cast<unsigned __int128>(q_len)) {
+    // (a slice of exactly ONE base is broadcast by numpy over however many bases the CIGAR consumes: no error there, and
+    // the walks read that one base under every run — kPlanBroadcast)
+    if (consumed != static_cast<unsigned __int128>(q_len) && q_len != 1) {
         msg = "CIGAR consumes " + std::to_string(uint64_t(consumed)) + " query bases, the PAF columns select " + std::to_string(q_len);
-        if (q_len == 1) msg += " (numpy would broadcast the one base: refused)";
         return BOSSX_E_PARSE;
     }
     if (!t_ok) { msg = "coordinate is not an integer"; return BOSSX_E_TYPE; }
@@ -458,7 +459,8 @@ void walk_plans(const ParseInput &in, const std::vector<ContigInfo> &contigs, co
         const int64_t tlo = pl.tlo, thi = pl.thi;
         // query walk: '+' reads seq[q_first + i]; '-' reads comp(seq[q_first - i]) (sequences.py:707-716)
         int64_t q = pl.q_first;
-        const int64_t qstep = r.rev ? -1 : 1;
+        const bool bcast = pl.q_len == 1;               // numpy broadcasts a one-base slice over every query-consuming run
+        const int64_t qstep = bcast ? 0 : (r.rev ? -1 : 1);
         const int64_t q_need = pl.q_len;
         // quick look at the whole aligned stretch of the read; only a read that holds something
         // other than A/C/G/T there gets the per-run check below (insertions may hold anything)
@@ -472,7 +474,7 @@ void walk_plans(const ParseInput &in, const std::vector<ContigInfo> &contigs, co
         int64_t consumed = 0, ref_pos = tlo;
         uint64_t cur_emit = pl.emit0;
         EmitOp *const first = w;
-        const uint32_t meta_base = (uint32_t(pl.bc) << 8) | (r.rev ? kOpRev : 0u);
+        const uint32_t meta_base = (uint32_t(pl.bc) << 8) | (r.rev ? kOpRev : 0u) | (bcast ? kOpBcast : 0u);
         const char *cp = r.cg, *ce = r.cg + r.cg_len;
         // the reference tokenises with re.findall(r"(\d+)([MIDNSHP=XB])") (sequences.py:672,767): whatever
         // is not digits directly followed by one of these letters is skipped, silently
@@ -495,9 +497,9 @@ void walk_plans(const ParseInput &in, const std::vector<ContigInfo> &contigs, co
             }
             const bool del = (op == 'D');          // emits code 4, consumes nothing (sequences.py:782,793)
             if (!del) {
-                if (consumed + len > q_need) { failed = true; break; }       // more than the slice holds: a shape mismatch in cig_rep[notdel] = int_seq[start:end]
+                if (!bcast && consumed + len > q_need) { failed = true; break; }       // more than the slice holds: a shape mismatch in cig_rep[notdel] = int_seq[start:end]
                 const int64_t q_last = q + qstep * (len - 1);
-                if (check_bases && !all_acgt(in.seqs + seq_b + (r.rev ? q_last : q), size_t(len)))
+                if (check_bases && !all_acgt(in.seqs + seq_b + (r.rev ? q_last : q), size_t(bcast ? 1 : len)))
                     range_fail("read '" + r.qname + "': base other than A/C/G/T inside an aligned segment");
             }
             if (ref_pos + len > c.length)
@@ -512,7 +514,7 @@ void walk_plans(const ParseInput &in, const std::vector<ContigInfo> &contigs, co
             ref_pos += len;
             if (!del) { consumed += len; q += qstep * len; }
         }
-        if (failed || n_tok == 0 || consumed != q_need || ref_pos - tlo != thi - tlo) return fail();
+        if (failed || n_tok == 0 || (consumed != q_need && !bcast) || ref_pos - tlo != thi - tlo) return fail();
         wo.emitted_per_contig[size_t(pl.cidx)] += uint64_t(thi - tlo);
         // split the read's emitted stretch at sweep-tile boundaries (padded site space)
         if (w > first) {
@@ -1016,7 +1018,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             const int64_t room = c.length - tlo;
             mp.room = uint32_t(room < 0 ? 0 : (room > int64_t(UINT32_MAX) ? int64_t(UINT32_MAX) : room));
             mp.ops_cap = uint32_t(r.cg_len / 2 + 1);
-            mp.flags = uint32_t(pl.bc & 0xff) | (r.rev ? kPlanRev : 0u);      // (kPlanCheckBases: below, once the reads have been looked at)
+            mp.flags = uint32_t(pl.bc & 0xff) | (r.rev ? kPlanRev : 0u) | (q_need == 1 ? kPlanBroadcast : 0u);      // (kPlanCheckBases: below, once the reads have been looked at)
             // groups: every sweep tile the stretch [site0, site0 + span) touches, for this barcode.
             // A stretch that runs past its contig (an IndexError reported by the device walk) is
             // clipped here so that no key outside the table is marked.
@@ -1349,7 +1351,7 @@ extern "C" int bossx_host_parse(const char *const *contig_names, const int64_t *
             uint8_t code = 4;
             if (!(o.meta & kOpDel)) {
                 const bool rev = (o.meta & kOpRev) != 0;
-                const char ch = blob[size_t(rev ? o.qpos - j : o.qpos + j)];
+                const char ch = blob[size_t((o.meta & kOpBcast) ? o.qpos : (rev ? o.qpos - j : o.qpos + j))];
                 code = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 255;
                 if (rev && code != 255) code = uint8_t(3 - code);
             }

@@ -310,6 +310,16 @@ def fuzz_error_cases(n=FUZZ_N, seed=FUZZ_SEED):
             elif len(g) > 5:
                 g[5] = ["e1", "e2", "nope"][int(rng.integers(0, 3))]
             lines.insert(i + int(rng.integers(0, 2)), "\t".join(g))
+        elif kind == 11:    # the query columns select ONE base of the read (numpy broadcasts it over the whole CIGAR) or none
+            if len(f) > 3:
+                try:
+                    ql = max(int(f[1]), 2)
+                    v = int(rng.integers(0, ql - 1))
+                    f[2] = str(v)
+                    f[3] = str(v + int(rng.integers(0, 2)))
+                    lines[i] = "\t".join(f)
+                except ValueError:
+                    pass
         else:               # coordinates shifted consistently (a mapping that runs past the contig end / before its start)
             if len(f) > 8:
                 try:
@@ -327,6 +337,6 @@ def fuzz_error_cases(n=FUZZ_N, seed=FUZZ_SEED):
                              extras=bool(rng.integers(0, 4) == 0))
         lines, seqs = b["paf"].split("\n"), b["seqs"]
         for _ in range(int(rng.integers(0, 4))):
-            lines, seqs = mutate(lines, seqs, int(rng.integers(0, 11)))
+            lines, seqs = mutate(lines, seqs, int(rng.integers(0, 12)))
         cases.append(("f%04d" % c, "\n".join(lines), seqs))
     return contigs, cases
