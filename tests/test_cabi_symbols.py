@@ -44,3 +44,22 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "oracle/" not in src or f.endswith(".md"), f
+
+
+def test_rccl_loopback_double_exports_what_the_driver_binds():
+    """tests/rccl_loopback/librccl_loopback.so (BOSSX_RCCL_LIB; test infrastructure) must carry every entry point
+    RcclApi::load looks up in librccl (boss-runs_amd/csrc/bossx.hip), and nothing under the product may name it."""
+    import ctypes
+    import subprocess
+    d = os.path.join(REPO, "tests", "rccl_loopback")
+    subprocess.run(["make", "-C", d], check=True, capture_output=True)
+    lib = ctypes.CDLL(os.path.join(d, "librccl_loopback.so"))
+    src = open(os.path.join(REPO, "boss-runs_amd", "csrc", "bossx.hip")).read()
+    bound = set(re.findall(r'sym\("(nccl\w+)"\)', src))
+    assert bound >= {"ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclAllReduce", "ncclAllGather", "ncclGetErrorString"}
+    for name in bound:
+        assert hasattr(lib, name), name
+    for root, _, files in os.walk(os.path.join(REPO, "boss-runs_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".inc")):
+                assert "rccl_loopback" not in open(os.path.join(root, f)).read() or f == "bossx.hip", f
