@@ -264,7 +264,7 @@ class BossRuns(Boss):
         try:
             eng.select_batch(a["slot"])
             a["summ"] = eng.stage_batch(a["paf_text"], a["new_reads"], barcodes=a["barcodes"], min_len=a["min_len"])
-        except (ValueError, KeyError, IndexError, TypeError, AssertionError) as e:     # the reference's rejects
+        except (ValueError, KeyError, IndexError, TypeError, AssertionError, OverflowError) as e:     # the reference's rejects
             a["error"] = e
         finally:
             eng.select_batch(self._cur_slot)
