@@ -8,6 +8,7 @@ restated), drives `BossRuns` exactly as `process_batch_runs` does minus the mapp
 reference's outputs as small `.npz` fixtures next to this script.
 
     cd /tmp && python3 /root/repo/tests/golden/make_golden.py
+    cd /tmp && GOLDEN_ONLY=errors_fuzz python3 /root/repo/tests/golden/make_golden.py     # one fixture only: errors | errors_fuzz | sat
 
 Fixtures whose values pass through `bottleneck.move_sum` carry `movesum_unpinned=1`
 (the shim restates Bottleneck 1.3.x; the real library is not installed).
