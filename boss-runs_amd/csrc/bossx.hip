@@ -1944,6 +1944,8 @@ int launch_hist(bossx_engine *h, const bossx_fhat_desc *fh, int gate, bool clear
     if (P.d2 < 0) P.d2 = 0;   // trimmed instead of padded: indices unchanged
     if (P.d1 < 0) P.d1 = 0;
     P.run = target >= (int64_t(1) << 18) ? 16 : 2;
+    P.staged = (P.run == 16 && double(target) * h->nb * 16.0 > 128e6) ? 1 : 0;      // (both strands' benefits against half the 256-MB Infinity Cache)
+    if (const char *e = getenv("BOSSX_HIST_STAGED")) P.staged = atoi(e) != 0 && P.run == 16;
     const int64_t span = int64_t(256) * P.run;
     const int64_t blocks = std::min<int64_t>((target + span - 1) / span, 2048);
     time_begin(h, BOSSX_K_HIST);
