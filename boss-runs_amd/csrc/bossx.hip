@@ -1949,7 +1949,8 @@ int launch_hist(bossx_engine *h, const bossx_fhat_desc *fh, int gate, bool clear
     const int64_t span = int64_t(256) * P.run;
     const int64_t blocks = std::min<int64_t>((target + span - 1) / span, 2048);
     time_begin(h, BOSSX_K_HIST);
-    hipLaunchKernelGGL(threshold_hist_kernel, dim3(uint32_t(std::max<int64_t>(blocks, 1)), uint32_t(h->nb * 2)), dim3(256), 0, h->stream, P);
+    hipLaunchKernelGGL(threshold_hist_kernel, dim3(uint32_t(std::max<int64_t>(blocks, 1)), uint32_t(h->nb * 2)), dim3(256),
+                       P.staged ? size_t(256 * 16 + 256) * sizeof(double) : size_t(0), h->stream, P);
     time_end(h, BOSSX_K_HIST, double(target) * h->nb * 2 * 8.0);
     HIPCHK(hipGetLastError());
     return BOSSX_OK;
