@@ -1777,7 +1777,7 @@ void launch_chain(bossx_engine *h, const ChainParams &P0, size_t lds, hipStream_
         Q.stats = getenv("BOSSX_SPEC_STATS") ? h->d_spec_stats : nullptr;
         Q.hash = getenv("BOSSX_SPEC_NO_SKIP") ? nullptr : h->d_spec_hash;
         Q.strict = getenv("BOSSX_SPEC_STRICT") ? atoi(getenv("BOSSX_SPEC_STRICT")) : 0;
-        hipLaunchKernelGGL(chain_candidates_kernel, dim3(uint32_t(h->spec_total * ((BOSSX_NWIN + kCandWin - 1) / kCandWin)), 1, uint32_t(h->nb * 2)), dim3(64), 0, stream, Q);
+        hipLaunchKernelGGL(chain_candidates_kernel, dim3(uint32_t(h->spec_total), (BOSSX_NWIN + kCandWin - 1) / kCandWin, uint32_t(h->nb * 2)), dim3(64), 0, stream, Q);
         hipLaunchKernelGGL(chain_stitch_kernel, dim3(uint32_t(h->filt.size() * size_t(h->nb) * 2 * BOSSX_NWIN)), dim3(64), 0, stream, Q);
         if (getenv("BOSSX_SPEC_SELFTEST") && h->spec_total > h->spec_seg_chunks)      // (the first contig needs a second segment)
             hipLaunchKernelGGL(chain_spoil_kernel, dim3(1), dim3(1), 0, stream, h->d_spec_starts, int64_t(h->spec_seg_chunks));
