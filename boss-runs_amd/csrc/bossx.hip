@@ -2828,6 +2828,17 @@ int bossx_import(bossx_engine *h, int32_t contig, int32_t which, const void *src
                                  size_t(L) * 8, hipMemcpyHostToDevice));
             break;
         }
+        case 3: {
+            // the downsampled scores (Contig.scores_ds, reference.py:225-231) as the input of bossx_benefit: a parity hook for the
+            // move_sum chain alone (tests/golden/g_movesum.npz).  The next sweep overwrites them.
+            const int64_t nbin = L / kWindow + 1;
+            if (src_bytes != size_t(nb * nbin) * 8) return fail(h, BOSSX_E_INVALID, "import size mismatch");
+            HIPCHK(hipStreamSynchronize(h->stream));
+            for (int64_t b = 0; b < nb; ++b)
+                HIPCHK(hipMemcpy(h->d_ds + b * h->B + c.bin_off, static_cast<const double *>(src) + b * nbin, size_t(nbin) * 8,
+                                 hipMemcpyHostToDevice));
+            break;
+        }
         case 5: {
             if (src_bytes != size_t(nb * L)) return fail(h, BOSSX_E_INVALID, "import size mismatch");
             HIPCHK(hipStreamSynchronize(h->stream));

@@ -626,6 +626,8 @@ class Engine:
             raw = np.ascontiguousarray(np.asarray(arr, dtype=np.uint16).transpose(2, 1, 0))
         elif which == "entropy":
             raw = np.ascontiguousarray(np.asarray(arr, dtype=np.float64).T)
+        elif which == "scores_ds":
+            raw = np.ascontiguousarray(np.asarray(arr, dtype=np.float64).T)
         elif which == "state":
             raw = np.ascontiguousarray(np.asarray(arr, dtype=np.uint8).T)
         elif which == "touched":

@@ -403,7 +403,7 @@ int32_t bossx_matrix_chain(const bossx_engine *h);
  *   7 bucket switches uint8[nb][L//20000+1] (export only)
  *   8 benefit tail float64[nb][2][min(L//100+1, n_filt)] (export only; multi-GPU halo rows)
  *   9 strat      uint8 [L//100][2][nb] (Contig.strat)
- * bossx_import accepts 0, 2, 5, 6, 7 (layout [nb][n_buckets]) and 9.                                                            */
+ * bossx_import accepts 0, 2, 3 (input of bossx_benefit until the next sweep), 5, 6, 7 (layout [nb][n_buckets]) and 9.                                                          */
 int bossx_export(bossx_engine *h, int32_t contig, int32_t which, void *dst, size_t dst_bytes);
 int bossx_import(bossx_engine *h, int32_t contig, int32_t which, const void *src, size_t src_bytes);
 

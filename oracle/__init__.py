@@ -16,8 +16,11 @@ Pinning status:
     (tests/base/test_runs_sequences.py:113-126, tests/base/test_readlengthdist.py:21-32,
     tests/base/test_reference.py:10-36) and against golden vectors produced by importing
     the reference in the build container (tests/golden/make_golden.py);
-  * PARITY UNPINNED for `move_sum`: Bottleneck (~=1.3.7, reference pyproject.toml:19) is a
-    third-party C dependency that is absent from /root/reference and from this image.
-    `oracle/movesum.c` restates its published running-sum algorithm; no reference test
-    holds a known answer at that boundary.
+  * `move_sum` is pinned to Bottleneck ITSELF: the library (~=1.3.7, reference pyproject.toml:19) is
+    absent from /root/reference and from the system Python, but /opt/conda/bin/python3.9 of the
+    build image ships the real compiled Bottleneck 1.3.2.  `tests/golden/make_movesum_golden.py`
+    runs it on every `scores_ds` column of the golden runs (at the windows those runs used, both
+    directions) and on random arrays over forty decades, and re-derives the golden fixtures'
+    `additional_benefit` with it (equal, 52 columns); `oracle/movesum.c` is held to
+    `tests/golden/g_movesum.npz` bit for bit (tests/test_oracle_golden.py).
 """

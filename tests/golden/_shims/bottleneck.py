@@ -1,11 +1,13 @@
-"""Import shim (fixture generation only): Bottleneck is not installed in this image.
+"""Import shim (fixture generation only): the system Python of this image has no Bottleneck.
 
-`move_sum` below restates the published algorithm of Bottleneck 1.3.x (`move_sum` in
+`move_sum` below restates the algorithm of Bottleneck 1.3.x (`move_sum` in
 bottleneck/src/move_template.c, pinned `bottleneck~=1.3.7` by the reference's
 pyproject.toml:19) for the only case the reference uses: 1-D float64 input without NaNs.
 A single running accumulator: the first `window` outputs add a[i]; afterwards
-`asum += a[i] - a[i-window]`. PARITY UNPINNED at this boundary: no reference test holds a
-known answer for it and the real library cannot be run here.
+`asum += a[i] - a[i-window]`.  PINNED: `tests/golden/g_movesum.npz` holds the outputs of the
+real compiled Bottleneck 1.3.2 (/opt/conda/bin/python3.9, `make_movesum_golden.py`) on every
+`scores_ds` column the reference passed through this shim in the golden runs, plus random arrays
+over forty decades; `tests/test_oracle_golden.py` holds this function to them bit for bit.
 """
 import numpy as np
 

@@ -10,8 +10,10 @@ reference's outputs as small `.npz` fixtures next to this script.
     cd /tmp && python3 /root/repo/tests/golden/make_golden.py
     cd /tmp && GOLDEN_ONLY=errors_fuzz python3 /root/repo/tests/golden/make_golden.py     # one fixture only: errors | errors_fuzz | sat
 
-Fixtures whose values pass through `bottleneck.move_sum` carry `movesum_unpinned=1`
-(the shim restates Bottleneck 1.3.x; the real library is not installed).
+Fixtures whose values pass through `bottleneck.move_sum` carry `movesum_via_shim=1`: the system Python
+has no Bottleneck, so the reference ran on `_shims/bottleneck.py`.  `make_movesum_golden.py` (run with
+/opt/conda/bin/python3.9, which ships the real Bottleneck 1.3.2) re-derives every `additional_benefit`
+column stored here with the real library and asserts it equal: the shim's results ARE Bottleneck's.
 Nothing from /root/reference is copied: fixtures hold inputs (or their seeds) and outputs.
 """
 import os
@@ -170,7 +172,7 @@ def run_scenario(out, tag, ploidy, nb):
         args.general.barcodes = ["barcode%02d" % (i + 1) for i in range(nb)]
     runs = boss.runs.core.BossRuns(args=args)
     runs.init()
-    d = dict(movesum_unpinned=np.array(1), ploidy=np.array(ploidy), nb=np.array(nb),
+    d = dict(movesum_via_shim=np.array(1), ploidy=np.array(ploidy), nb=np.array(nb),
              ref_digest=np.array(digest(*[c[1] for c in contigs])))
     for b in range(E2E_BATCHES):
         batch = e2e_batch(contigs, b, nb)
@@ -257,7 +259,7 @@ def run_saturated(out, ploidy=1, nb=1):
     args.optional.reject_refs = E2E_REJECT
     runs = boss.runs.core.BossRuns(args=args)
     runs.init()
-    d = dict(movesum_unpinned=np.array(1), ploidy=np.array(ploidy), nb=np.array(nb),
+    d = dict(movesum_via_shim=np.array(1), ploidy=np.array(ploidy), nb=np.array(nb),
              ref_digest=np.array(digest(*[c[1] for c in contigs])))
 
     def ingest(b):
@@ -284,6 +286,7 @@ def run_saturated(out, ploidy=1, nb=1):
         runs.scoring.find_strat_thread = orig
         assert captured, "strategies not switched on"
         d[tag + "_threshold"] = np.array(captured["threshold"])
+        d[tag + "_approx_ccl"] = np.array(runs.rl_dist.approx_ccl)
         d[tag + "_merged_strat"] = np.packbits(captured["merged_strat"].reshape(-1))
         d[tag + "_merged_shape"] = np.array(captured["merged_strat"].shape)
         d[tag + "_benefit_adj"] = captured["benefit_adj"]
@@ -366,7 +369,7 @@ def run_sim_scenario(out, tag, nb, accept_unmapped):
         def fill_cache(self, **kw):
             pass
     runs.sampler, runs.read_cache, runs.mu, runs.accept_unmapped = StubSampler(), StubCache(), 400, accept_unmapped
-    d = dict(movesum_unpinned=np.array(1), nb=np.array(nb), accept_unmapped=np.array(int(accept_unmapped)))
+    d = dict(movesum_via_shim=np.array(1), nb=np.array(nb), accept_unmapped=np.array(int(accept_unmapped)))
     for b in range(SIM_BATCHES):
         batch = sim_batch(contigs, b, nb)
         d["b%d_input_digest" % b] = np.array(digest(batch["paf"].encode(), batch["paf_trunc"].encode(),

@@ -267,3 +267,92 @@ def test_oracle_fuzz_error_classes_equal_the_reference():
     assert not bad, (len(bad), bad[:10])
     classes = {v.get("error", "ok") for v in gold.values()}
     assert classes >= {"ok", "ValueError", "IndexError", "KeyError", "AssertionError", "TypeError", "OverflowError"}
+
+
+# ---- move_sum pinned to Bottleneck itself (tests/golden/make_movesum_golden.py, real Bottleneck 1.3.2) --------------
+def _movesum_golden():
+    import hashlib
+    import json
+    g = np.load(os.path.join(GOLDEN, "g_movesum.npz"))
+    meta = json.loads(str(g["meta"]))
+
+    def sha(a):
+        return hashlib.sha256(np.ascontiguousarray(a, dtype="<f8").tobytes()).hexdigest()
+
+    def case_input(c):
+        if c["source"] == "inline":
+            return g["in_" + c["name"]]
+        fname, key, b = c["name"].split(":")
+        return np.ascontiguousarray(np.load(os.path.join(GOLDEN, fname))[key][:, int(b)])
+    return g, meta, sha, case_input
+
+
+def _shim_move_sum():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_bn_shim", os.path.join(GOLDEN, "_shims", "bottleneck.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.move_sum
+
+
+def test_move_sum_equals_bottleneck():
+    """oracle/movesum.c (and the import shim the golden runs went through) against the outputs of the REAL
+    Bottleneck 1.3.2 — reference call sites boss/runs/reference.py:233-234, 259-260: every `scores_ds` column the
+    reference handed to move_sum in the e2e / saturated golden runs at the windows those runs used, and random arrays
+    over forty decades with runs of `tiny` and zeros, forward (double reversal) and reverse, bit for bit."""
+    g, meta, sha, case_input = _movesum_golden()
+    assert meta["bottleneck"].startswith("1.3.") and meta["n_fixture_columns_equal_to_bottleneck"] >= 52
+    shim = _shim_move_sum()
+    n = 0
+    for ci, c in enumerate(meta["cases"]):
+        a = case_input(c)
+        assert a.shape[0] == c["n"]
+        for w in sorted(set(c["windows"])):
+            assert sha(move_sum(a, w)) == c["rev"][str(w)], (c["name"], w)
+            assert sha(move_sum(a[::-1], w)[::-1]) == c["fwd"][str(w)], (c["name"], w)
+            n += 2
+            if ci % 6 == 0 and w == c["windows"][3]:          # the (slow, pure-Python) shim on a sample of the arrays
+                assert sha(shim(a, w, min_count=1)) == c["rev"][str(w)], (c["name"], w)
+                assert sha(shim(a[::-1], w, min_count=1)[::-1]) == c["fwd"][str(w)], (c["name"], w)
+    assert n >= 1500
+    # full outputs: short arrays at every window 1..n (the min_count=1 head; w == n), and four long ones
+    for s, ns in enumerate(meta["short_n"]):
+        a = g["short%d_in" % s]
+        for w in range(1, ns + 1):
+            assert np.array_equal(move_sum(a, w), g["short%d_rev" % s][w - 1]), (s, w)
+            assert np.array_equal(move_sum(a[::-1], w)[::-1], g["short%d_fwd" % s][w - 1]), (s, w)
+            assert np.array_equal(shim(a, w, min_count=1), g["short%d_rev" % s][w - 1]), (s, w)
+    for k in g.files:
+        if k.startswith("rev_w") or k.startswith("fwd_w"):
+            d, w, name = k.split("_")
+            a = g["in_" + name]
+            got = move_sum(a, int(w[1:])) if d == "rev" else move_sum(a[::-1], int(w[1:]))[::-1]
+            assert np.array_equal(got, g[k]), k
+    # the window edges: Bottleneck raises ValueError for w < 1 and w > n, and so do the oracle and the shim
+    a = np.arange(10, dtype=np.float64)
+    for w, what in meta["edges_n10"].items():
+        for f in (lambda: move_sum(a, int(w)), lambda: shim(a, int(w), min_count=1)):
+            if what == "ok":
+                f()
+            else:
+                assert what == "ValueError"
+                with pytest.raises(ValueError):
+                    f()
+
+
+def test_calc_u_equals_bottleneck():
+    """Contig.calc_smu + calc_u (reference.py:215-269) of the oracle on the same arrays: `additional_benefit`
+    equals the one formed from Bottleneck's own sums."""
+    g, meta, sha, case_input = _movesum_golden()
+    for c in meta["cases"]:
+        a = case_input(c)
+        oc = OContig.__new__(OContig)
+        oc.nb, oc.length = 1, (a.shape[0] - 1) * 100
+        oc.scores_ds = a.reshape(-1, 1).copy()
+        oc.smu = np.zeros((a.shape[0], 2, 1))
+        oc.smu[:, 0, 0] = move_sum(oc.scores_ds[::-1, 0], c["windows"][0])[::-1]
+        oc.smu[:, 1, 0] = move_sum(oc.scores_ds[:, 0], c["windows"][0])
+        oc.calc_u(np.array(c["windows"][1:]) * 100)
+        assert sha(oc.additional_benefit[:, :, 0]) == c["benefit_sha"], c["name"]
+        if "benefit_" + c["name"] in g.files:
+            assert np.array_equal(oc.additional_benefit[:, :, 0], g["benefit_" + c["name"]])

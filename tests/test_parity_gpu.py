@@ -1537,3 +1537,63 @@ def test_chunk_parallel_chain_into_saturation_vs_oracle(form, in_tmp, monkeypatc
     assert np.median(cov) >= 30                                   # the genome did saturate ...
     assert tiny_bins > 1000                                       # ... with thousands of fully capped bins in the last update
     a.engine.close()
+
+
+@pytest.mark.parametrize("form", ["chunk_parallel", "serial"])
+def test_benefit_chain_equals_bottleneck(form, in_tmp, monkeypatch):
+    """The move_sum chain of the HIP path against Bottleneck ITSELF (tests/golden/g_movesum.npz, produced by
+    make_movesum_golden.py with the real compiled Bottleneck 1.3.2 — reference call sites
+    boss/runs/reference.py:233-234, 259-260): every `scores_ds` column the reference handed to move_sum in the
+    golden runs and random bin sums over forty decades (runs of `tiny`, of zeros, climbs of dozens of binades) are
+    imported as a contig's bin sums (bossx_import which = 3), `bossx_benefit` runs calc_smu + calc_u on them with
+    the windows of that case, and the exported `additional_benefit` must equal the one formed from Bottleneck's
+    sums bit for bit — in the chunk-parallel form (candidates -> stitch -> segments) and in the serial kernel."""
+    import hashlib
+    import json
+    from boss_runs_amd import synth
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.runs import BossRuns
+    monkeypatch.setenv("BOSSX_CHAIN_SPEC", "2" if form == "chunk_parallel" else "0")
+    g = np.load(os.path.join(GOLDEN, "g_movesum.npz"))
+    meta = json.loads(str(g["meta"]))
+    cases = meta["cases"]
+    sizes = sorted({c["n"] for c in cases})
+    lens = [(n - 1) * 100 + 37 for n in sizes]                 # a contig of n bins: L // 100 + 1 == n
+    names = ["ms%d" % n for n in sizes]
+    contigs = synth.make_reference(lens, seed=17, names=names)
+    args = BossConfig()
+    args.general.name = "bn_" + form
+    runs = BossRuns(args)
+    runs.init(contigs=[(n, synth.codes_to_str(c)) for n, c in contigs])
+    eng = runs.engine
+    mult = np.arange(0.05, 1, 0.1)[::-1]
+    fixtures = {}
+    for c in cases:
+        if c["source"] == "inline":
+            a = g["in_" + c["name"]]
+        else:
+            fname, key, b = c["name"].split(":")
+            if fname not in fixtures:
+                fixtures[fname] = np.load(os.path.join(GOLDEN, fname))
+            a = np.ascontiguousarray(fixtures[fname][key][:, int(b)])
+        ci = eng.names.index("ms%d" % c["n"])
+        eng.import_state(ci, "scores_ds", a.reshape(-1, 1))
+        assert np.array_equal(eng.export(ci, "scores_ds")[:, 0], a)
+        eng.benefit(np.array(c["windows"], dtype=np.int32), mult)
+        ab = eng.export(ci, "benefit")[:, :, 0]
+        assert hashlib.sha256(np.ascontiguousarray(ab, dtype="<f8").tobytes()).hexdigest() == c["benefit_sha"], c["name"]
+        if "benefit_" + c["name"] in g.files:
+            assert np.array_equal(ab, g["benefit_" + c["name"]]), c["name"]
+    st = eng.chain_stats()
+    if form == "chunk_parallel":
+        assert st["chunk_parallel_launches"] > 0, st
+    else:
+        assert st["chunk_parallel_launches"] == 0, st
+    # the window edges: Bottleneck raises ValueError for a window of 0 or beyond the array (a short contig against very
+    # long reads); the engine refuses the same calls
+    from boss_runs_amd._lib import BossxError
+    for bad in (0, max(sizes) + 1):
+        w = np.array([4] + [bad] * 10, dtype=np.int32)
+        with pytest.raises((ValueError, BossxError)):
+            eng.benefit(w, mult)
+    eng.close()
