@@ -369,6 +369,46 @@ int copy_site_field(bossx_engine *h, const ContigInfo &c, int32_t b, int field_o
     return BOSSX_OK;
 }
 
+// bossx_export / bossx_import of the fields whose device layout differs from the reference's (counter planes: reference-relative;
+// entropy: per-tile lane order): converted on the device through ONE bounded scratch buffer, a stretch of the contig per pass
+// (a whole-contig temporary was 2.5 GB per barcode for chr1 — a checkpoint next to a nearly full HBM could fail).
+int convert_field(bossx_engine *h, const ContigInfo &c, int32_t which, void *host, bool to_device) {
+    const int64_t L = c.length, nb = h->nb;
+    const int64_t rows = which == 0 ? nb * 5 : 1;                   // rows of the scratch per pass (entropy: one barcode at a time)
+    const int64_t elem = which == 0 ? 2 : 8;
+    const int64_t chunk = std::min<int64_t>(L, std::max<int64_t>(int64_t(1) << 20, (int64_t(16) << 20) / rows));
+    void *tmp = nullptr;
+    HIPCHK(hipMalloc(&tmp, size_t(rows * chunk * elem)));
+    hipError_t err = hipSuccess;
+    auto keep = [&](hipError_t e) { if (err == hipSuccess) err = e; };
+    for (int64_t pass_b = 0; pass_b < (which == 0 ? 1 : nb) && err == hipSuccess; ++pass_b)
+        for (int64_t s0 = 0; s0 < L && err == hipSuccess; s0 += chunk) {
+            const int64_t n = std::min(chunk, L - s0);
+            const dim3 grid(uint32_t(std::min<int64_t>((n + 255) / 256, 8192)));
+            auto copy_rows = [&](bool h2d) {
+                for (int64_t r = 0; r < rows; ++r) {
+                    uint8_t *hp = static_cast<uint8_t *>(host) + ((which == 0 ? r : pass_b) * L + s0) * elem;
+                    uint8_t *dp = static_cast<uint8_t *>(tmp) + r * n * elem;
+                    keep(h2d ? hipMemcpyAsync(dp, hp, size_t(n * elem), hipMemcpyHostToDevice, h->stream)
+                             : hipMemcpyAsync(hp, dp, size_t(n * elem), hipMemcpyDeviceToHost, h->stream));
+                }
+            };
+            if (to_device) copy_rows(true);
+            if (which == 0)
+                hipLaunchKernelGGL(planes_convert_kernel, grid, dim3(256), 0, h->stream, SiteState{h->d_state, h->nb}, h->nb, c.site_off, s0, n,
+                                   static_cast<uint16_t *>(tmp), to_device ? 1 : 0);
+            else
+                hipLaunchKernelGGL(entropy_convert_kernel, grid, dim3(256), 0, h->stream, h->d_entropy + pass_b * h->Gp, c.site_off, s0, n,
+                                   static_cast<double *>(tmp), to_device ? 1 : 0);
+            keep(hipGetLastError());
+            if (!to_device) copy_rows(false);
+            keep(hipStreamSynchronize(h->stream));      // the scratch is reused by the next pass; the host buffer is the caller's
+        }
+    (void)hipFree(tmp);
+    HIPCHK(err);
+    return BOSSX_OK;
+}
+
 int check_contig(bossx_engine *h, int32_t c, bool need_filt) {
     if (!h || c < 0 || c >= int32_t(h->contigs.size())) return fail(h, BOSSX_E_INVALID, "contig index out of range");
     if (need_filt && h->contigs[size_t(c)].rejected) return fail(h, BOSSX_E_INVALID, "contig is rejected");
@@ -2709,14 +2749,7 @@ int bossx_export(bossx_engine *h, int32_t contig, int32_t which, void *dst, size
         case 0: {
             if (!need(size_t(nb * 5 * L) * 2)) return fail(h, BOSSX_E_INVALID, "export buffer too small");
             // the counter planes are reference-relative on the device: un-rotated into the reference's A C G T deletion order
-            uint16_t *tmp = nullptr;
-            if ((rc = dev_alloc(h, &tmp, size_t(nb * 5 * L)))) return rc;
-            hipLaunchKernelGGL(planes_convert_kernel, dim3(uint32_t(std::min<int64_t>((L + 255) / 256, 8192))), dim3(256), 0, h->stream,
-                               SiteState{h->d_state, h->nb}, h->nb, c.site_off, L, tmp, 0);
-            hipError_t e1 = hipMemcpyAsync(dst, tmp, size_t(nb * 5 * L) * 2, hipMemcpyDeviceToHost, h->stream);
-            hipError_t e2 = hipStreamSynchronize(h->stream);
-            hipFree(tmp);
-            HIPCHK(e1); HIPCHK(e2);
+            if ((rc = convert_field(h, c, 0, dst, false))) return rc;
             break;
         }
         case 1: {
@@ -2735,9 +2768,7 @@ int bossx_export(bossx_engine *h, int32_t contig, int32_t which, void *dst, size
         case 2: {
             if (!h->d_entropy) return fail(h, BOSSX_E_INVALID, "entropy tracking is off");
             if (!need(size_t(nb * L) * 8)) return fail(h, BOSSX_E_INVALID, "export buffer too small");
-            for (int64_t b = 0; b < nb; ++b)
-                HIPCHK(hipMemcpyAsync(static_cast<double *>(dst) + b * L, h->d_entropy + b * h->Gp + c.site_off,
-                                      size_t(L) * 8, hipMemcpyDeviceToHost, h->stream));
+            if ((rc = convert_field(h, c, 2, dst, false))) return rc;
             break;
         }
         case 3: {
@@ -2799,17 +2830,8 @@ int bossx_import(bossx_engine *h, int32_t contig, int32_t which, const void *src
     switch (which) {
         case 0: {
             if (src_bytes != size_t(nb * 5 * L) * 2) return fail(h, BOSSX_E_INVALID, "import size mismatch");
-            {
-                // A C G T deletion planes -> the reference-relative planes of the site state (the state bytes hold the reference bases)
-                uint16_t *tmp = nullptr;
-                if ((rc = dev_alloc(h, &tmp, size_t(nb * 5 * L)))) return rc;
-                hipError_t e1 = hipMemcpyAsync(tmp, src, src_bytes, hipMemcpyHostToDevice, h->stream);
-                hipLaunchKernelGGL(planes_convert_kernel, dim3(uint32_t(std::min<int64_t>((L + 255) / 256, 8192))), dim3(256), 0, h->stream,
-                                   SiteState{h->d_state, h->nb}, h->nb, c.site_off, L, tmp, 1);
-                hipError_t e2 = hipStreamSynchronize(h->stream);
-                hipFree(tmp);
-                HIPCHK(e1); HIPCHK(e2);
-            }
+            // A C G T deletion planes -> the reference-relative planes of the site state (the state bytes hold the reference bases)
+            if ((rc = convert_field(h, c, 0, const_cast<void *>(src), true))) return rc;
             unsigned long long *d_tot = h->d_stats;
             HIPCHK(hipMemsetAsync(d_tot, 0, sizeof(unsigned long long), h->stream));
             hipLaunchKernelGGL(contig_total_kernel, dim3(1024), dim3(256), 0, h->stream, SiteState{h->d_state, h->nb}, h->nb,
@@ -2823,9 +2845,7 @@ int bossx_import(bossx_engine *h, int32_t contig, int32_t which, const void *src
         case 2: {
             if (!h->d_entropy) return fail(h, BOSSX_E_INVALID, "entropy tracking is off");
             if (src_bytes != size_t(nb * L) * 8) return fail(h, BOSSX_E_INVALID, "import size mismatch");
-            for (int64_t b = 0; b < nb; ++b)
-                HIPCHK(hipMemcpy(h->d_entropy + b * h->Gp + c.site_off, static_cast<const double *>(src) + b * L,
-                                 size_t(L) * 8, hipMemcpyHostToDevice));
+            if ((rc = convert_field(h, c, 2, const_cast<void *>(src), true))) return rc;
             break;
         }
         case 3: {
