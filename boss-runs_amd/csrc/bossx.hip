@@ -316,6 +316,11 @@ SweepParams sweep_params(bossx_engine *h) {
 // Rare path: a second batch arrives (or a slot is re-staged) before the sweep that would have
 // applied the pending one.  Apply the pending batch with the global-atomic scatter kernel; it
 // marks `touched`, which the next sweep then reads.
+// Derived entropy (kernels.hip.inc: ent_save_site) is the one-barcode engine's form; with several barcodes E is written at every lookup.
+EntSave ent_save_of(const bossx_engine *h) {
+    return (h->nb == 1 && h->d_entropy && h->lut_set) ? EntSave{h->d_entropy, h->d_lut_ent, h->d_touched} : EntSave{nullptr, nullptr, nullptr};
+}
+
 int flush_pending(bossx_engine *h) {
     if (h->pending_slot < 0) return BOSSX_OK;
     bossx_engine::Staged &st = h->slots[size_t(h->pending_slot)];
@@ -334,9 +339,13 @@ int flush_pending(bossx_engine *h) {
         st.emit_tiles_built = true;
     }
     time_begin(h, BOSSX_K_INGEST);
-    hipLaunchKernelGGL(ingest_scatter_kernel, dim3(n_tiles), dim3(256), 0, h->stream, st.d_ops, st.d_tiles,
+    const EntSave X = ent_save_of(h);
+    if (X.E)         // derived entropy: the scatter modifies patterns without looking the sites up — their entropies are saved first
+        hipLaunchKernelGGL(ingest_scatter_kernel<true>, dim3(n_tiles), dim3(256), 0, h->stream, st.d_ops, st.d_tiles,
+                           uint32_t(pb.n_ops), pb.total_emit, st.d_blob, SiteState{h->d_state, h->nb}, h->d_touched, h->d_err, X);
+    hipLaunchKernelGGL(ingest_scatter_kernel<false>, dim3(n_tiles), dim3(256), 0, h->stream, st.d_ops, st.d_tiles,
                        uint32_t(pb.n_ops), pb.total_emit, st.d_blob, SiteState{h->d_state, h->nb},
-                       h->d_touched, h->d_err);
+                       h->d_touched, h->d_err, X);
     time_end(h, BOSSX_K_INGEST, 6.0 * double(pb.total_emit) + 16.0 * double(pb.n_ops));
     HIPCHK(hipGetLastError());
     if (!st.ev_free) HIPCHK(hipEventCreateWithFlags(&st.ev_free, hipEventDisableTiming));
@@ -397,6 +406,9 @@ int convert_field(bossx_engine *h, const ContigInfo &c, int32_t which, void *hos
             if (which == 0)
                 hipLaunchKernelGGL(planes_convert_kernel, grid, dim3(256), 0, h->stream, SiteState{h->d_state, h->nb}, h->nb, c.site_off, s0, n,
                                    static_cast<uint16_t *>(tmp), to_device ? 1 : 0);
+            else if (!to_device && ent_save_of(h).E)      // one barcode: most entropies are derived from the counters (export_entropy_kernel)
+                hipLaunchKernelGGL(export_entropy_kernel, grid, dim3(256), 0, h->stream, SiteState{h->d_state, h->nb}, ent_save_of(h), c.site_off, s0, n,
+                                   static_cast<double *>(tmp));
             else
                 hipLaunchKernelGGL(entropy_convert_kernel, grid, dim3(256), 0, h->stream, h->d_entropy + pass_b * h->Gp, c.site_off, s0, n,
                                    static_cast<double *>(tmp), to_device ? 1 : 0);
@@ -2908,7 +2920,7 @@ int bossx_preload_coverage(bossx_engine *h, double depth, uint64_t seed) {
         if (c.remote) continue;
         const int64_t blocks = std::min<int64_t>((c.length + 255) / 256, 8192);
         hipLaunchKernelGGL(preload_kernel, dim3(uint32_t(blocks)), dim3(256), 0, h->stream, SiteState{h->d_state, h->nb},
-                           h->d_touched, h->nb, c.site_off, c.length, depth, seed);
+                           h->d_touched, h->nb, c.site_off, c.length, depth, seed, ent_save_of(h));
         unsigned long long *d_tot = h->d_stats;
         HIPCHK(hipMemsetAsync(d_tot, 0, sizeof(unsigned long long), h->stream));
         hipLaunchKernelGGL(contig_total_kernel, dim3(1024), dim3(256), 0, h->stream, SiteState{h->d_state, h->nb}, h->nb,
