@@ -1597,3 +1597,101 @@ def test_benefit_chain_equals_bottleneck(form, in_tmp, monkeypatch):
         with pytest.raises((ValueError, BossxError)):
             eng.benefit(w, mult)
     eng.close()
+
+
+def test_derived_entropy_crossings_vs_oracle(in_tmp):
+    """Derived entropy (one-barcode engine, kernels.hip.inc: ent_save_site): the engine writes no entropy at a lookup — a looked-up,
+    uncapped site's entropy is a function of its counters — and keeps the array only for capped / never-scored / pending sites.  What
+    that must get right, every step against the oracle's array (sequences.py:419-452):
+      1. sites that cross depth 30 after earlier lookups (their entropy freezes at the LAST pattern below the cap),
+      2. sites that cross on their first ever touch (a stack of 35 reads on fresh ground: the initial fill stays),
+      3. a second batch ingested before the sweep (fallback scatter: patterns modified without a lookup) with sites that cross in
+         the second pending batch after having been touched by the first,
+      4. export / import of the materialised array into a fresh engine, which then continues identically,
+      5. more stacks on already capped ground (nothing changes there)."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.runs import BossRuns
+    from oracle.pipeline import OracleRuns
+    from oracle.pafcigar import parse_paf, convert_records
+    contigs = synth.make_reference([150_000, 110_000], seed=77, names=["dA", "dB"])
+    strs = [(n, synth.codes_to_str(c)) for n, c in contigs]
+
+    def fresh(name):
+        args = BossConfig()
+        args.general.name = name
+        args.optional.ploidy = 2
+        args.optional.bucket_threshold = 0
+        r = BossRuns(args)
+        r.init(contigs=strs)
+        return r
+    runs = fresh("dent")
+    o = OracleRuns(strs, ploidy=2, nbarcodes=1, bucket_threshold=0)
+
+    def check(tag):
+        for n, oc in o.contigs.items():
+            pc = runs.contigs[n]
+            assert np.array_equal(pc.coverage, oc.coverage), (tag, n)
+            assert np.array_equal(pc.scores, oc.scores), (tag, n)
+            bad = np.flatnonzero(pc.entropy[:, 0] != oc.entropy[:, 0])
+            assert bad.size == 0, (tag, n, bad[:8], oc.coverage[bad[:3]].tolist())
+
+    def stack(name, spans_per_read, depth, prefix):
+        spans = [s for s in spans_per_read for _ in range(depth)]
+        return _exact_reads(contigs, name, spans, prefix)
+
+    def step(paf, seqs, tag):
+        rl = {k: len(v) for k, v in seqs.items()}
+        o.process_batch(paf, seqs, read_lengths=rl)
+        runs.rl_dist.update(rl)
+        runs.process_batch_paf(paf, seqs)
+        assert runs.threshold == o.threshold, tag
+        check(tag)
+
+    # 0-1: ordinary batches (lookups everywhere they land), then stacks: A on looked-up ground (crosses after lookups),
+    #      B on a stretch no read has touched yet (dropped from the ordinary batches: crosses on its first touch)
+    for b in range(2):
+        batch = _drop_mappings_into(synth.make_batch(contigs, 900, seed=7700 + b, mean_len=4000.0, nbarcodes=1), "dA", 100_000, 112_000)
+        step(batch["paf"], batch["seqs"], "plain%d" % b)
+    pa, sa = stack("dA", [(20_000, 26_000)], 20, "sA")
+    step(pa, sa, "stackA_20")                      # depth ~20 + what was there: some sites cross already
+    pa, sa = stack("dA", [(20_000, 26_000), (22_000, 31_000)], 9, "sA2")
+    step(pa, sa, "stackA_cross")
+    pb_, sb = stack("dA", [(101_000, 109_000)], 35, "sB")
+    step(pb_, sb, "stackB_first_touch")
+    assert (o.contigs["dA"].coverage[102_000:108_000].sum(axis=1) >= 30).all()
+    # 3: two batches before one sweep; the second makes sites of the first cross
+    p1, s1 = stack("dB", [(30_000, 38_000)], 18, "t1")
+    p2, s2 = stack("dB", [(33_000, 42_000)], 16, "t2")
+    incs = {n: [] for n in o.contigs}
+    for paf, seqs in ((p1, s1), (p2, s2)):
+        runs.engine.ingest_paf(paf, seqs)
+        for n, lst in convert_records(parse_paf(paf, min_len=200), seqs).items():
+            incs[n].extend(lst)
+    for n, c in o.contigs.items():
+        c.increment_coverage(incs[n])
+    runs.engine.sweep()
+    for n, c in o.contigs.items():
+        c.update_scores(o.cache)
+        c.modify_scores()
+    check("two_batches")
+    # 4: the materialised array through export / import into a fresh engine
+    runs2 = fresh("dent2")
+    for n in o.contigs:
+        c, c2 = runs.contigs[n], runs2.contigs[n]
+        runs2.engine.import_state(c2.index, "coverage", c.coverage)
+        runs2.engine.import_state(c2.index, "state", runs.engine.export(c.index, "state"))
+        runs2.engine.import_state(c2.index, "entropy", c.entropy)
+        assert np.array_equal(c2.entropy, o.contigs[n].entropy), n
+    # 5: both engines go on: stacks on capped ground and beside it
+    pc_, sc = stack("dA", [(24_000, 33_000), (105_000, 113_000)], 12, "sC")
+    rl = {k: len(v) for k, v in sc.items()}
+    o.process_batch(pc_, sc, read_lengths=rl)
+    for r in (runs, runs2):
+        r.rl_dist.update(rl)
+        r.process_batch_paf(pc_, sc)
+    check("after_import")
+    for n, oc in o.contigs.items():
+        assert np.array_equal(runs2.contigs[n].entropy, oc.entropy), n
+        assert np.array_equal(runs2.contigs[n].coverage, oc.coverage), n
+    runs.engine.close(); runs2.engine.close()
