@@ -409,6 +409,8 @@ def other_workload(name, device, batches, steps, warmup, track_entropy):
 
 
 GRCH38_EXTRA = [("MT", 16_569), ("scaf_150k", 150_000), ("scaf_250k", 250_000), ("scaf_400k", 400_000)]
+from boss_runs_amd.synth import GRCH38_LENS as _GRCH38_LENS      # noqa: E402  (numpy only)
+GRCH38_LENGTHS = list(_GRCH38_LENS) + [L for _, L in GRCH38_EXTRA]
 
 
 def grch38_contigs():
@@ -433,7 +435,7 @@ def run_grch38(a, rank, world, local_rank, steps=None, warmup=None):
     import torch.distributed as dist
     from boss_runs_amd import synth
     from boss_runs_amd.config import BossConfig
-    from boss_runs_amd.parallel import DistributedBossRuns, partition_contigs
+    from boss_runs_amd.parallel import DistributedBossRuns, partition_contigs, shard_balance
     from boss_runs_amd.runs import BossRuns
     steps = steps or a.steps
     warmup = warmup if warmup is not None else a.warmup
@@ -507,7 +509,11 @@ def run_grch38(a, rank, world, local_rank, steps=None, warmup=None):
                            "step = PAF text + reads in host memory -> masks in host memory" % (len(kept), G_total, a.reads),
                "scaling": "strong", "n_gpus": world, "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
                "steps": steps, "warmup": warmup, "ms_per_step": ms, "value_mbp_per_s": G_total / 1e6 / (elapsed / steps),
-               "shards": shards, "partition": "contiguous runs of contigs in FASTA order (linear partition by length)",
+               "shards": shards,
+               "partition": "whole contigs; longest-first packing or contiguous runs in FASTA order, whichever leaves the lighter heaviest rank (parallel.partition_contigs)",
+               "shard_balance": {"max_over_mean": shard_balance([L for _, _, L in kept], owner, world),
+                                 "linear": shard_balance([L for _, _, L in kept], partition_contigs([L for _, _, L in kept], world, "linear"), world),
+                                 "lpt": shard_balance([L for _, _, L in kept], partition_contigs([L for _, _, L in kept], world, "lpt"), world)},
                "site_sweep_rank0": {"avg_ms": kern["site_sweep"]["avg_ms"], "frac_of_hbm_peak": achieved / HBM_PEAK_GBS,
                                     "algorithmic_bytes": kern["site_sweep"]["bytes"]},
                "benefit_chain_ms_rank0": kern["benefit_chain"]["avg_ms"],

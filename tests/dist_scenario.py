@@ -10,6 +10,18 @@ import numpy as np
 from scenarios import REPO, E2E_REJECT, e2e_batch, e2e_contig_strings, e2e_reference
 
 
+# BOSSX_DIST_SCENARIO=four: four contigs whose longest-first packing onto two ranks is NOT contiguous (owners 0 1 0 1): the row-drift
+# halo of every contig must travel whoever owns its neighbours.  Default: the end-to-end reference (two kept contigs).
+def _scenario():
+    from boss_runs_amd import synth
+    if os.environ.get("BOSSX_DIST_SCENARIO") == "four":
+        contigs = synth.make_reference([300_000, 120_000, 110_000, 290_000], seed=5, names=["f0", "f1", "f2", "f3"])
+        return contigs, [(n, synth.codes_to_str(c)) for n, c in contigs], "", \
+            (lambda b, nb: synth.make_batch(contigs, 900, seed=500 + b, mean_len=3000.0, nbarcodes=nb))
+    contigs = e2e_reference()
+    return contigs, e2e_contig_strings(contigs), E2E_REJECT, (lambda b, nb: e2e_batch(contigs, b, nb))
+
+
 def worker(rank, world, port, tmp, nb, ploidy, ret, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
@@ -40,20 +52,22 @@ def run_rank(rank, nb, ploidy, engine=None, device=None, comm=None):
     """One rank of the scenario: three sharded batches through DistributedBossRuns; what it ends each update with."""
     from boss_runs_amd.config import BossConfig
     from boss_runs_amd.parallel import DistributedBossRuns
-    contigs = e2e_reference()
+    contigs, strings, reject, make_batch = _scenario()
     args = BossConfig()
     args.general.name = "dist%d" % rank
     args.optional.ploidy = ploidy
-    args.optional.reject_refs = E2E_REJECT
+    args.optional.reject_refs = reject
+    if os.environ.get("BOSSX_DIST_SCENARIO") == "four":
+        args.optional.bucket_threshold = 0
     if device is not None:
         args.gpu.device = device
     if nb > 1:
         args.general.barcodes = ["barcode%02d" % (i + 1) for i in range(nb)]
     runs = DistributedBossRuns(args)
-    runs.init(contigs=e2e_contig_strings(contigs), engine=engine, sharded_reads=True, comm=comm)
+    runs.init(contigs=strings, engine=engine, sharded_reads=True, comm=comm)
     out = []
     for b in range(3):
-        batch = e2e_batch(contigs, b, nb)
+        batch = make_batch(b, nb)
         # shard the reads: a read goes to the rank owning the target of its first PAF line
         # (reads on the short / rejected contigs and unmapped reads go to rank 0)
         by_read = {}
@@ -79,11 +93,12 @@ def run_rank(rank, nb, ploidy, engine=None, device=None, comm=None):
 
 def oracle_expected(nb, ploidy):
     from oracle.pipeline import OracleRuns
-    contigs = e2e_reference()
-    o = OracleRuns(e2e_contig_strings(contigs), ploidy=ploidy, reject_refs={E2E_REJECT}, nbarcodes=nb)
+    contigs, strings, reject, make_batch = _scenario()
+    kw = dict(bucket_threshold=0) if os.environ.get("BOSSX_DIST_SCENARIO") == "four" else {}
+    o = OracleRuns(strings, ploidy=ploidy, reject_refs={reject} if reject else set(), nbarcodes=nb, **kw)
     expected = []
     for b in range(3):
-        batch = e2e_batch(contigs, b, nb)
+        batch = make_batch(b, nb)
         # multi-mapper second lines target another contig; the oracle sees the whole batch
         o.process_batch(batch["paf"], batch["seqs"], read_lengths=batch["read_lengths"],
                         barcodes=batch["barcodes"] if nb > 1 else None)

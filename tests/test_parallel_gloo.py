@@ -14,10 +14,24 @@ from boss_runs_amd.parallel import partition_contigs, fx_to_limbs, limbs_to_floa
 def test_partition_contigs():
     assert partition_contigs([5, 5], 4) == [0, 1]
     assert partition_contigs([1, 1, 1, 1], 2) == [0, 0, 1, 1]
-    o = partition_contigs([10, 1, 1, 1, 10], 3)
+    o = partition_contigs([10, 1, 1, 1, 10], 3, "linear")
     assert o == sorted(o) and len(set(o)) == 3
     assert partition_contigs([3, 2, 1], 1) == [0, 0, 0]
     assert partition_contigs([], 2) == []
+    # longest-first packing against the contiguous partition on the GRCh38 contig set of bench.py
+    from boss_runs_amd.parallel import shard_balance
+    import bench
+    lens = [L for L in bench.GRCH38_LENGTHS if L >= 100_000]
+    for world, lin_max, lpt_max in ((8, 1.19, 1.02), (4, 1.09, 1.01), (2, 1.005, 1.001)):
+        lin, lpt = partition_contigs(lens, world, "linear"), partition_contigs(lens, world, "lpt")
+        assert lin == sorted(lin) and set(lin) == set(range(world)) == set(lpt)
+        assert shard_balance(lens, lpt, world) <= lpt_max < shard_balance(lens, lin, world) + 0.1
+        assert shard_balance(lens, lin, world) >= lin_max
+        auto = partition_contigs(lens, world)
+        assert shard_balance(lens, auto, world) == min(shard_balance(lens, lin, world), shard_balance(lens, lpt, world))
+    # equal shards repeated per rank (the weak-scaling bench): the tie goes to the contiguous partition, each rank its own copy
+    assert partition_contigs([64, 46] * 4, 4) == [0, 0, 1, 1, 2, 2, 3, 3]
+    assert partition_contigs([64, 46] * 4, 4, "lpt") == [0, 0, 1, 1, 2, 2, 3, 3]
 
 
 def test_limb_roundtrip():
@@ -41,3 +55,23 @@ def test_two_ranks_equal_single_process_oracle(nb, ploidy, world, tmp_path):
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(dist_scenario.worker, args=(world, port, str(tmp_path), nb, ploidy, ret), nprocs=world, join=True)
     dist_scenario.check(ret, expected, world)
+
+
+@pytest.mark.parametrize("method", ["lpt", "linear"])
+def test_noncontiguous_partition_equals_single_process_oracle(method, tmp_path, monkeypatch):
+    """Four contigs (300 / 120 / 110 / 290 kb) on two ranks: longest-first packing gives owners 0 1 0 1 — every contig's
+    predecessor in the merged array lives on the OTHER rank, so each halo row of `_distribute_strategy` (core.py:125-155)
+    crosses ranks — and the contiguous partition 0 0 1 1.  Thresholds, statistics and masks equal the single-process oracle
+    either way."""
+    import dist_scenario
+    monkeypatch.setenv("BOSSX_DIST_SCENARIO", "four")
+    monkeypatch.setenv("BOSSX_PARTITION", method)
+    lens = [300_000, 120_000, 110_000, 290_000]
+    assert partition_contigs(lens, 2) == ([0, 1, 0, 1] if method == "lpt" else [0, 0, 1, 1])
+    expected = dist_scenario.oracle_expected(1, 2)
+    assert expected[-1]["threshold"] is not None
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(dist_scenario.worker, args=(2, port, str(tmp_path), 1, 2, ret), nprocs=2, join=True)
+    dist_scenario.check(ret, expected, 2)

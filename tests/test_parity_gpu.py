@@ -1289,20 +1289,24 @@ def _loopback_rccl():
     return so
 
 
-@pytest.mark.parametrize("nb,ploidy", [(1, 2), (2, 1)])
-def test_native_driver_two_ranks_on_one_device_vs_oracle(nb, ploidy, tmp_path):
+@pytest.mark.parametrize("nb,ploidy,scenario", [(1, 2, "e2e"), (2, 1, "e2e"), (1, 2, "four")])
+def test_native_driver_two_ranks_on_one_device_vs_oracle(nb, ploidy, scenario, tmp_path, monkeypatch):
     """The native multi-GPU driver with world = 2 on a ONE-GPU box: two engines on device 0, each owning its share of
     the contigs, driven by two threads of one process; every collective of the update — the "some strategy is on"
     flag, halo rows + normaliser, the exact histogram limbs (bossx_dist_update) and the batch summaries of the sharded
     reads (bossx_dist_allgather) — goes through the library's communicator, which BOSSX_RCCL_LIB points at the
     loopback double of librccl (tests/rccl_loopback).  Thresholds, statistics and every contig's mask on both
-    ranks equal the single-process oracle's, update by update."""
+    ranks equal the single-process oracle's, update by update.  `four`: four contigs packed longest-first onto the two
+    ranks (owners 0 1 0 1, dist_scenario._scenario): every halo row crosses ranks."""
     import pickle
     import subprocess
     import sys
     import dist_scenario
     so = _loopback_rccl()
     out = tmp_path / "ranks.pkl"
+    monkeypatch.setenv("BOSSX_DIST_SCENARIO", scenario)
+    if scenario == "four":
+        monkeypatch.setenv("BOSSX_PARTITION", "lpt")
     env = dict(os.environ, BOSSX_RCCL_LIB=so, PYTHONPATH=os.pathsep.join([REPO, os.path.join(REPO, "tests")]))
     env.pop("BOSSX_TORCH_COLLECTIVES", None)
     p = subprocess.run([sys.executable, os.path.join(REPO, "tests", "dist_scenario.py"), str(nb), str(ploidy), str(tmp_path), str(out)],
