@@ -147,6 +147,7 @@ struct bossx_engine {
         // sweep leave the first slot's scatter in flight while the second slot is remembered)
         bool busy = false;
         hipEvent_t ev_free = nullptr;
+        bool ev_free_recorded = false;   // ev_free stands behind the CURRENT content's last reader (an event left from an earlier batch proves nothing: ADVICE r4)
         int32_t *d_err = nullptr;        // the slot's own error word (a base other than A/C/G/T met while ITS codes were expanded)
         ParsedBatch pb;
         bool valid = false;
@@ -350,7 +351,7 @@ int flush_pending(bossx_engine *h) {
     HIPCHK(hipGetLastError());
     if (!st.ev_free) HIPCHK(hipEventCreateWithFlags(&st.ev_free, hipEventDisableTiming));
     HIPCHK(hipEventRecord(st.ev_free, h->stream));      // the scatter is the last reader of this slot's buffers
-    st.busy = true;
+    st.busy = true; st.ev_free_recorded = true;
     h->pending_slot = -1;
     h->touched_dirty = true;
     return BOSSX_OK;
@@ -1074,7 +1075,9 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
     HIPCHK(hipStreamSynchronize(h->stream_stage));
     {
         bossx_engine::Staged &cur = h->slots[size_t(h->slot)];
-        if (cur.busy) { if (cur.ev_free) HIPCHK(hipEventSynchronize(cur.ev_free)); else HIPCHK(hipStreamSynchronize(h->stream)); cur.busy = false; }
+        // (busy without a recorded event: the batch was handed to the main stream, bossx_ingest_staged, and its reader — the sweep or the
+        // fallback scatter — has not been enqueued yet: only the stream itself can be waited for)
+        if (cur.busy) { if (cur.ev_free && cur.ev_free_recorded) HIPCHK(hipEventSynchronize(cur.ev_free)); else HIPCHK(hipStreamSynchronize(h->stream)); cur.busy = false; }
     }
     const size_t blob_bytes = n_reads > 0 ? size_t(seq_off[n_reads]) : 0;
     if (blob_bytes >= (size_t(1) << 32)) return fail(h, BOSSX_E_RANGE, "read blob larger than 4 GiB");
@@ -1420,6 +1423,7 @@ int bossx_ingest_staged(bossx_engine *h) {
     if (st.ev_ready) HIPCHK(hipStreamWaitEvent(h->stream, st.ev_ready, 0));     // staged on stream_stage, consumed on the main stream
     if (st.d_err) hipLaunchKernelGGL(merge_err_kernel, dim3(1), dim3(1), 0, h->stream, st.d_err, h->d_err);
     h->slots[size_t(h->slot)].busy = true;        // (until the sweep that applies it — or a fallback scatter — is behind ev_free)
+    h->slots[size_t(h->slot)].ev_free_recorded = false;
     // the increments are applied by the next sweep, tile by tile (site_sweep_kernel prologue);
     // its prep launch marks the touched tiles
     h->pending_slot = h->slot;
@@ -1641,7 +1645,7 @@ int launch_sweep(bossx_engine *h) {
         bossx_engine::Staged &st = h->slots[size_t(h->pending_slot)];
         if (!st.ev_free) HIPCHK(hipEventCreateWithFlags(&st.ev_free, hipEventDisableTiming));
         HIPCHK(hipEventRecord(st.ev_free, h->stream));  // the sweep launches above are the last readers of this slot's buffers
-        st.busy = true;
+        st.busy = true; st.ev_free_recorded = true;
     }
     h->pending_slot = -1;
     h->touched_dirty = false;
@@ -2376,11 +2380,16 @@ int bossx_dist_allgather(bossx_engine *h, const void *send, void *recv_all, size
     if ((rc = grow_dev(h, &h->d_gather, &h->gather_cap, total, 256))) return rc;
     if ((rc = grow_pin(h, &h->h_gather_pin, &h->gather_pin_cap, total))) return rc;
     memcpy(h->h_gather_pin, send, bytes);
-    HIPCHK(hipMemcpyAsync(h->d_gather, h->h_gather_pin, bytes, hipMemcpyHostToDevice, h->stream));
-    NCCLCHK(rccl().AllGather(h->d_gather, h->d_gather + bytes, bytes, ncclInt8, h->comm, h->stream));
+    // On a side stream: the caller has just put this update's sweep on the engine's stream (update_begin) so that the exchange
+    // and the host's bookkeeping overlap with it; on that stream the host would wait for the whole sweep (10 ms at GRCh38).  The
+    // communicator is used by one stream at a time: every other collective of an update is issued after this call has returned, and
+    // every rank makes the calls in the same order.
+    hipStream_t gs = h->stream2 ? h->stream2 : h->stream;
+    HIPCHK(hipMemcpyAsync(h->d_gather, h->h_gather_pin, bytes, hipMemcpyHostToDevice, gs));
+    NCCLCHK(rccl().AllGather(h->d_gather, h->d_gather + bytes, bytes, ncclInt8, h->comm, gs));
     ++h->n_collectives;
-    HIPCHK(hipMemcpyAsync(h->h_gather_pin + bytes, h->d_gather + bytes, world * bytes, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_gather_pin + bytes, h->d_gather + bytes, world * bytes, hipMemcpyDeviceToHost, gs));
+    HIPCHK(hipStreamSynchronize(gs));
     memcpy(recv_all, h->h_gather_pin + bytes, world * bytes);
     return BOSSX_OK;
 }

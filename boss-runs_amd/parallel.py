@@ -462,6 +462,7 @@ class DistributedBossRuns(BossRuns):
         own kernels — MAX of the armed flag (until some strategy is on), MAX over halo rows + normaliser, SUM of
         the exact histogram limbs — one synchronisation at the end."""
         eng = self.engine
+        self.n_updates += 1
         self.begin_update()
         self._begun = False
         self._chain_early = False
@@ -477,33 +478,41 @@ class DistributedBossRuns(BossRuns):
                                  between=between)
         else:
             res = eng.update(thr_b, dist=True, between=between)
-        for cont in self.local_filt.values():
-            if res["contig_on"][cont.index]:
-                cont.switched_on[:] = True
-        self.armed = res["any_on"]
-        if not self.armed:
-            return
-        if not hasattr(self.rl_dist, "time_cost"):
-            raise AttributeError("'ReadlengthDist' object has no attribute 'time_cost'")
-        self.threshold = res["threshold"]
-        self.last_stats = dict(normaliser=res["normaliser"], ubar0=res["ubar0"],
-                               strat_size=res["strat_size"], n_bins=res["n_bins"])
-        for cont in self.local_filt.values():
-            cont.strat = eng.strat_view(cont.index)
-        if self.gather_masks and (self.comm.world > 1 or self.comm.force):
-            self._gather_masks()
-        if self.write_masks and self.comm.rank == 0:
-            self._write_contig_strategies(contig_strats=self.ref.get_strategy_dict())
+        # An exception raised by `between` (staging the next batch while this update ran) was held back by Engine.update so that this
+        # update's results could be collected: it is re-raised on EVERY way out of this method, once they have been applied.
+        # KeyboardInterrupt / SystemExit included — they travelled through the same hand-off.
+        held = res.get("between_error")
+        try:
+            for cont in self.local_filt.values():
+                if res["contig_on"][cont.index]:
+                    cont.switched_on[:] = True
+            self.armed = res["any_on"]
+            if not self.armed:
+                return
+            if not hasattr(self.rl_dist, "time_cost"):
+                raise AttributeError("'ReadlengthDist' object has no attribute 'time_cost'")
+            self.threshold = res["threshold"]
+            self.last_stats = dict(normaliser=res["normaliser"], ubar0=res["ubar0"],
+                                   strat_size=res["strat_size"], n_bins=res["n_bins"])
+            for cont in self.local_filt.values():
+                cont.strat = eng.strat_view(cont.index)
+            if self.gather_masks and (self.comm.world > 1 or self.comm.force):
+                self._gather_masks()
+            if self.write_masks and self.comm.rank == 0:
+                self._write_contig_strategies(contig_strats=self.ref.get_strategy_dict())
+        finally:
+            if held is not None:
+                raise held
 
-    n_updates = 0            # updates run since init (bench: collectives per update)
+    n_updates = 0            # updates run since init (bench: collectives per update), whichever entry point ran them
 
     def update_wrapper(self) -> None:
-        self.n_updates += 1
         return self._update_wrapper()
 
     def _update_wrapper(self) -> None:
         if getattr(self, "native", False):
             return self._update_native()
+        self.n_updates += 1
         if getattr(self, "instream", False):
             return self._update_instream()
         eng, comm = self.engine, self.comm

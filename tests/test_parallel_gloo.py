@@ -75,3 +75,37 @@ def test_noncontiguous_partition_equals_single_process_oracle(method, tmp_path, 
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(dist_scenario.worker, args=(2, port, str(tmp_path), 1, 2, ret), nprocs=2, join=True)
     dist_scenario.check(ret, expected, 2)
+
+
+def test_native_update_reraises_what_staging_ahead_raised():
+    """Engine.update holds an exception of `between()` (the next batch staged while the update runs) back so that the
+    update can be collected; `_update_native` must re-raise it on every way out — strategy not armed yet, read lengths missing,
+    normal completion — after applying the update's results, and count the update."""
+    from types import SimpleNamespace
+    from boss_runs_amd.parallel import DistributedBossRuns
+
+    class Boom(RuntimeError):
+        pass
+
+    def make(res, have_rl):
+        r = object.__new__(DistributedBossRuns)
+        r.args = SimpleNamespace(optional=SimpleNamespace(bucket_threshold=0))
+        r.engine = SimpleNamespace(update_begin=lambda thr: None, update=lambda *a, **k: dict(res), strat_view=lambda i: None)
+        r._begun, r._chain_early, r.armed, r.local_filt = False, False, False, {}
+        r.rl_dist = SimpleNamespace(time_cost=500, approx_ccl=np.arange(10) * 100 + 900) if have_rl else SimpleNamespace()
+        r.read_starts = SimpleNamespace(_engine=None, fhat_compact=lambda: (np.zeros((1, 2)), 1))
+        r.gather_masks, r.write_masks = False, False
+        r.comm = SimpleNamespace(world=1, force=False, rank=0)
+        return r
+    base = dict(contig_on=np.zeros(0, bool), any_on=False, threshold=1.0, normaliser=1.0, ubar0=0.0, strat_size=1, n_bins=1)
+    for res, have_rl in ((dict(base), True), (dict(base, any_on=True), False), (dict(base, any_on=True), True)):
+        r = make(dict(res, between_error=Boom("staging failed")), have_rl)
+        with pytest.raises(Boom):
+            r._update_native(between=lambda: None)
+        assert r.n_updates == 1 and r.armed == res["any_on"]
+    r = make(dict(base, any_on=True), True)                  # nothing held back: nothing raised, results applied
+    r._update_native()
+    assert r.threshold == 1.0 and r.n_updates == 1
+    r = make(dict(base, any_on=True, between_error=KeyboardInterrupt()), True)
+    with pytest.raises(KeyboardInterrupt):
+        r._update_native(between=lambda: None)
