@@ -88,6 +88,8 @@ struct bossx_engine {
     int64_t *d_chunk_off = nullptr; int64_t spec_total = 0, spec_max_segs = 0;
     int32_t spec_seg_chunks = kSpecSegChunks;   // chunks per segment block of the chain's final pass (finalize)
     double *d_spec_tab = nullptr, *d_spec_starts = nullptr;
+    double *d_spec_sup = nullptr; int64_t *d_sup_off = nullptr; int64_t spec_sup_total = 0;      // chain_compose_kernel: one super-row per group of spec_seg_chunks chunks
+    bool spec_no_compose = getenv("BOSSX_NO_COMPOSE") != nullptr;
     unsigned long long *d_spec_stats = nullptr;
     unsigned long long *d_spec_hash = nullptr;     // [rows] input hash of every table row (0: never built)
     int32_t nb = 1;
@@ -527,12 +529,16 @@ void bossx_destroy(bossx_engine *h) {
     if (h->d_spec_stats && getenv("BOSSX_SPEC_STATS")) {
         unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpy(st, h->d_spec_stats, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "[bossx] stitch: %llu groups stepped through their super-row, %llu composed but out of reach, %llu not composed\n", st[9], st[10], st[11]);
+        if (hipMemcpy(st, h->d_spec_stats, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess)
             fprintf(stderr, "[bossx] chunk-parallel chain: %llu (window, chunk) tables built + %llu left standing (inputs unchanged), %llu plain, %llu identity, %.1f candidates each; %llu chunks added plainly by the stitch; %lld updates on the serial chain meanwhile; %d mismatches (plain because: climbs more than 4 binades %llu, at most %llu; start not a normal positive number %llu)\n",
                     st[0], st[8], st[1], st[2], st[0] > st[1] + st[2] ? double(st[3]) / double(st[0] - st[1] - st[2]) : 0.0, st[4], (long long)h->spec_paused_updates, h->spec_mismatches, st[5], st[7], st[6]);
     }
     if (h->d_chunk_off) hipFree(h->d_chunk_off);
     if (h->d_spec_tab) hipFree(h->d_spec_tab);
     if (h->d_spec_starts) hipFree(h->d_spec_starts);
+    if (h->d_spec_sup) hipFree(h->d_spec_sup);
+    if (h->d_sup_off) hipFree(h->d_sup_off);
     if (h->d_spec_stats) hipFree(h->d_spec_stats);
     if (h->d_spec_hash) hipFree(h->d_spec_hash);
     if (h->d_tile_contig) hipFree(h->d_tile_contig);
@@ -754,6 +760,13 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
             (void)hipGetLastError();
             h->chain_spec = false;          // (the serial chain needs no scratch)
         } else if ((rc = dev_alloc(h, &h->d_spec_stats, 12, true)) || (rc = dev_alloc(h, &h->d_spec_hash, rows + 8, true))) return rc;
+        if (h->chain_spec && h->spec_seg_chunks <= kStitchBatch) {
+            std::vector<int64_t> soff(off.size(), 0);
+            for (size_t k = 0; k + 1 < off.size(); ++k) soff[k + 1] = soff[k] + (off[k + 1] - off[k] + h->spec_seg_chunks - 1) / h->spec_seg_chunks;
+            h->spec_sup_total = soff.back();
+            if ((rc = upload_vec(h, &h->d_sup_off, soff))) return rc;
+            if ((rc = dev_alloc(h, &h->d_spec_sup, size_t(nb) * 2 * BOSSX_NWIN * size_t(h->spec_sup_total) * kSupRow + 8, true))) return rc;
+        }
         }
     }
     if (h->chain_flow_ce != 2) h->chain_gc = false;
@@ -1834,6 +1847,10 @@ void launch_chain(bossx_engine *h, const ChainParams &P0, size_t lds, hipStream_
         Q.hash = getenv("BOSSX_SPEC_NO_SKIP") ? nullptr : h->d_spec_hash;
         Q.strict = getenv("BOSSX_SPEC_STRICT") ? atoi(getenv("BOSSX_SPEC_STRICT")) : 0;
         hipLaunchKernelGGL(chain_candidates_kernel, dim3(uint32_t(h->spec_total), (BOSSX_NWIN + kCandWin - 1) / kCandWin, uint32_t(h->nb * 2)), dim3(64), 0, stream, Q);
+        Q.sup = (h->d_spec_sup && !h->spec_no_compose) ? h->d_spec_sup : nullptr; Q.sup_off = h->d_sup_off; Q.sup_total = h->spec_sup_total; Q.group = h->spec_seg_chunks;
+        if (Q.sup)          // every group of seg_chunks rows composed into one super-row, all groups at once: the stitch walks groups
+            hipLaunchKernelGGL(chain_compose_kernel, dim3(uint32_t(h->spec_sup_total), BOSSX_NWIN, uint32_t(h->nb * 2)), dim3(64),
+                               size_t(h->spec_seg_chunks) * kSpecRow * sizeof(double), stream, Q);
         hipLaunchKernelGGL(chain_stitch_kernel, dim3(uint32_t(h->filt.size() * size_t(h->nb) * 2 * BOSSX_NWIN)), dim3(64), 0, stream, Q);
         if (getenv("BOSSX_SPEC_SELFTEST") && h->spec_total > h->spec_seg_chunks)      // (the first contig needs a second segment)
             hipLaunchKernelGGL(chain_spoil_kernel, dim3(1), dim3(1), 0, stream, h->d_spec_starts, int64_t(h->spec_seg_chunks));

@@ -23,7 +23,7 @@ for arm in "$@"; do
       echo "[$arm] tests: $(tail -1 $OUT/test_$tag.log)"
       grep -E "^(FAILED|ERROR)|Error|assert " $OUT/test_$tag.log | head -8
     fi
-    timeout 900 python bench.py --no-cpu-baseline --no-others --no-entropy-off-run --steps 12 --warmup 4 $BENCH_ARGS > $OUT/bench_$tag.json 2> $OUT/bench_$tag.err || { echo "[$arm] bench failed"; tail -5 $OUT/bench_$tag.err; exit 0; }
+    timeout 900 python bench.py --no-cpu-baseline --no-others --no-entropy-off-run --no-cold --no-late --steps 12 --warmup 4 $BENCH_ARGS > $OUT/bench_$tag.json 2> $OUT/bench_$tag.err || { echo "[$arm] bench failed"; tail -5 $OUT/bench_$tag.err; exit 0; }
     python3 - "$arm" "$OUT/bench_$tag.json" <<'PY'
 import json, sys
 arm, f = sys.argv[1], sys.argv[2]

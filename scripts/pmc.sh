@@ -8,7 +8,7 @@ OUT="$ROOT/gpurun_out/pmc"; mkdir -p "$OUT"
 K=$1; shift
 cd /tmp && export TMPDIR=/tmp
 export BOSSX_BATCH_CACHE=/tmp/bossx_batches BOSSX_NO_OVERLAP=1
-ARGS="--no-cpu-baseline --no-large --no-others --no-entropy-off-run --steps 8 --warmup 3 $BENCH_ARGS"
+ARGS="--no-cpu-baseline --no-large --no-others --no-entropy-off-run --no-cold --no-late --steps 8 --warmup 3 $BENCH_ARGS"
 [ -n "$LIST" ] && rocprofv3 -L > "$OUT/counters.txt" 2>&1
 python3 "$ROOT/bench.py" $ARGS --prepare-only > /dev/null 2>&1
 i=0

@@ -12,7 +12,7 @@ OUT="$ROOT/gpurun_out/prof_$W"
 mkdir -p "$OUT"
 COMMIT=$(cat "$ROOT/.bossx_commit" 2>/dev/null)
 cd /tmp && export TMPDIR=/tmp
-ARGS="--workload $W --no-cpu-baseline --no-large --no-others --no-entropy-off-run --steps 10 --warmup 3 $*"
+ARGS="--workload $W --no-cpu-baseline --no-large --no-others --no-entropy-off-run --no-cold --no-late --steps 10 --warmup 3 $*"
 # the batches are generated once, outside the profiler (forked workers + the profiler's preloaded tool
 # have deadlocked at exit); every pass below loads them from the cache
 export BOSSX_BATCH_CACHE=/tmp/bossx_batches_$W
