@@ -527,7 +527,9 @@ void bossx_destroy(bossx_engine *h) {
     if (h->d_tile_order) hipFree(h->d_tile_order);
     if (h->d_carry_ring) hipFree(h->d_carry_ring);
     if (h->d_spec_stats && getenv("BOSSX_SPEC_STATS")) {
-        unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st2[2] = {0, 0};
+        if (hipMemcpy(st2, h->d_spec_stats + 69, sizeof(st2), hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "[bossx] stitch: %llu cut rows walked piece by piece, %llu stretches evaluated on one rounding grid (each a round trip to the bin sums)\n", st2[1], st2[0]);
         if (hipMemcpy(st, h->d_spec_stats, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess)
             fprintf(stderr, "[bossx] stitch: %llu groups stepped through their super-row, %llu composed but out of reach, %llu not composed\n", st[9], st[10], st[11]);
         if (hipMemcpy(st, h->d_spec_stats, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess)
@@ -759,7 +761,7 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
             hipMalloc(reinterpret_cast<void **>(&h->d_spec_starts), rows * sizeof(double) + 64) != hipSuccess) {
             (void)hipGetLastError();
             h->chain_spec = false;          // (the serial chain needs no scratch)
-        } else if ((rc = dev_alloc(h, &h->d_spec_stats, 12, true)) || (rc = dev_alloc(h, &h->d_spec_hash, rows + 8, true))) return rc;
+        } else if ((rc = dev_alloc(h, &h->d_spec_stats, 96, true)) || (rc = dev_alloc(h, &h->d_spec_hash, rows + 8, true))) return rc;
         if (h->chain_spec && h->spec_seg_chunks <= kStitchBatch) {
             std::vector<int64_t> soff(off.size(), 0);
             for (size_t k = 0; k + 1 < off.size(); ++k) soff[k + 1] = soff[k] + (off[k + 1] - off[k] + h->spec_seg_chunks - 1) / h->spec_seg_chunks;
