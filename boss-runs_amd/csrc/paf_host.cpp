@@ -225,6 +225,17 @@ bool all_acgt(const char *p, size_t n) {
     }
     return bad == 0;
 }
+// ... or one of the digits the reference counts as well: every byte minus '0' is its column index (sequences.py:790), so '0'..'3'
+// are A C G T, '4' the deletion column, '7' becomes a deletion with the D operations (:803); anything else is out of range (IndexError)
+bool all_counted(const char *p, size_t n) {
+    unsigned bad = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned char c = static_cast<unsigned char>(p[i]);
+        const unsigned d = unsigned(c) - unsigned('0');
+        bad |= unsigned(!((c == 'A') | (c == 'C') | (c == 'G') | (c == 'T') | (d <= 4u) | (d == 7u)));
+    }
+    return bad == 0;
+}
 
 }  // namespace
 
@@ -499,7 +510,7 @@ void walk_plans(const ParseInput &in, const std::vector<ContigInfo> &contigs, co
             if (!del) {
                 if (!bcast && consumed + len > q_need) { failed = true; break; }       // more than the slice holds: a shape mismatch in cig_rep[notdel] = int_seq[start:end]
                 const int64_t q_last = q + qstep * (len - 1);
-                if (check_bases && !all_acgt(in.seqs + seq_b + (r.rev ? q_last : q), size_t(bcast ? 1 : len)))
+                if (check_bases && !all_counted(in.seqs + seq_b + (r.rev ? q_last : q), size_t(bcast ? 1 : len)))
                     range_fail("read '" + r.qname + "': base other than A/C/G/T inside an aligned segment");
             }
             if (ref_pos + len > c.length)
@@ -1354,6 +1365,7 @@ extern "C" int bossx_host_parse(const char *const *contig_names, const int64_t *
                 const char ch = blob[size_t((o.meta & kOpBcast) ? o.qpos : (rev ? o.qpos - j : o.qpos + j))];
                 code = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 255;
                 if (rev && code != 255) code = uint8_t(3 - code);
+                if (code == 255) { const unsigned d = unsigned(static_cast<unsigned char>(ch)) - unsigned('0'); if (d <= 4u) code = uint8_t(d); else if (d == 7u) code = 4; }      // (digits: their own column, either strand)
             }
             out_contig[e] = cidx;
             out_pos[e] = int64_t(site0 + j) - contigs[size_t(cidx)].site_off;

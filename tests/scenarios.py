@@ -339,4 +339,25 @@ def fuzz_error_cases(n=FUZZ_N, seed=FUZZ_SEED):
         for _ in range(int(rng.integers(0, 4))):
             lines, seqs = mutate(lines, seqs, int(rng.integers(0, 12)))
         cases.append(("f%04d" % c, "\n".join(lines), seqs))
+    # ---- round 5: DIGITS inside reads.  The reference turns A C G T into '0'..'3' and takes every byte of the read minus '0' as the column
+    # of np.add.at (sequences.py:666-667, 790): '0'..'3' in a read count as A C G T, '4' as a deletion, '7' becomes one with the D
+    # operations (:803), '5' '6' '8' '9' are out of range (IndexError) — on either strand (utils.py:93 complements letters only).
+    # Appended behind the cases above (their own generator: the first `n` cases stay what they were).
+    rng = np.random.default_rng(seed + 1)
+    for c in range(max(n // 8, 40) if n >= FUZZ_N else max(n // 8, 4)):
+        k_reads = int(rng.integers(1, 5))
+        b = synth.make_batch(contigs, k_reads, seed=int(rng.integers(0, 2 ** 31)), mean_len=600.0, min_len=250, max_len=1500,
+                             extras=bool(rng.integers(0, 4) == 0))
+        lines, seqs = b["paf"].split("\n"), dict(b["seqs"])
+        accepted_only = bool(rng.integers(0, 3))             # two cases in three hold only digits the reference goes on with
+        for name in list(seqs):
+            if rng.integers(0, 3) == 0:
+                continue
+            sq = list(seqs[name])
+            for _ in range(int(rng.integers(1, 5))):
+                sq[int(rng.integers(0, len(sq)))] = ("012347" if accepted_only else "0123456789")[int(rng.integers(0, 6 if accepted_only else 10))]
+            seqs[name] = "".join(sq)
+        for _ in range(int(rng.integers(0, 2))):
+            lines, seqs = mutate(lines, seqs, int(rng.integers(0, 12)))
+        cases.append(("d%04d" % c, "\n".join(lines), seqs))
     return contigs, cases
