@@ -46,6 +46,10 @@ struct bossx_engine {
     // (bossx_ingest_staged) makes `stream` wait for the slot's `ev_ready`.
     hipStream_t stream_stage = nullptr;
     hipEvent_t ev_begin = nullptr, ev_chain = nullptr, ev_sweep = nullptr, ev_fhat = nullptr;
+    // The read-start posterior depends on nothing but the batch's read starts: its launches (the counts' atomic adds, the terms, the
+    // scaling: ~30 us behind a gap) run on a stream of their own NEXT TO the sweep and the chain, and the histogram waits for one event
+    // (round 4 queued them behind the chain on the main stream, on the update's critical path).
+    hipStream_t stream_fhat = nullptr; hipEvent_t ev_fhat_side = nullptr;
     double *h_fhat_pin = nullptr;      // page-locked staging of the compact f-hat
     double *d_rs_counts = nullptr; int64_t rs_windows = 0;     // read-start counts resident in HBM (bossx_fhat_reset / _add)
     int64_t *d_rs_keys = nullptr; size_t rs_keys_cap = 0;
@@ -483,6 +487,8 @@ int bossx_create(const bossx_config *cfg, bossx_engine **out) {
         hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_sweep, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fhat, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->stream_fhat, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fhat_side, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&h->stream_up, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&h->stream_txt, hipStreamNonBlocking) != hipSuccess ||
@@ -517,6 +523,8 @@ void bossx_destroy(bossx_engine *h) {
     if (h->ev_chain) hipEventDestroy(h->ev_chain);
     if (h->ev_sweep) hipEventDestroy(h->ev_sweep);
     if (h->ev_fhat) hipEventDestroy(h->ev_fhat);
+    if (h->stream_fhat) { hipStreamSynchronize(h->stream_fhat); hipStreamDestroy(h->stream_fhat); }
+    if (h->ev_fhat_side) hipEventDestroy(h->ev_fhat_side);
     if (h->h_fhat_pin) hipHostFree(h->h_fhat_pin);
     if (h->d_rs_counts) hipFree(h->d_rs_counts);
     if (h->d_rs_keys) hipFree(h->d_rs_keys);
@@ -1996,12 +2004,21 @@ int build_fhat(bossx_engine *h, const FhatModel *up) {
     P.counts = h->d_rs_counts; P.fhat = h->d_fhat; P.sums = h->d_rs_sums;
     P.n = up->n_windows; P.rep = 20; P.d = up->target_rs - 20 * up->n_windows;
     P.alpha = up->alpha; P.den = up->den; P.expected = up->expected; P.on_target = up->on_target;
-    HIPCHK(hipMemsetAsync(h->d_rs_sums, 0, 6 * sizeof(unsigned long long), h->stream));
+    // on the side stream, behind the batch's own fhat_add; the main stream (where the histogram follows) waits for the result.  Not when
+    // the chain ran next to the sweep on stream2 (opt-in): that schedule orders itself through ev_fhat on the main stream.
+    const bool side = !h->chain_on_stream2 && h->stream_fhat != nullptr && !getenv("BOSSX_FHAT_MAIN_STREAM");
+    hipStream_t fs = side ? h->stream_fhat : h->stream;
+    if (!side && h->ev_rs_keys) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_rs_keys, 0));      // (this batch's counts were added on the side stream)
+    HIPCHK(hipMemsetAsync(h->d_rs_sums, 0, 6 * sizeof(unsigned long long), fs));
     // (few blocks: every wave ends with atomics on the same three accumulators — 2048 blocks spent 45 us queueing there)
     const uint32_t blocks = uint32_t(std::min<int64_t>((up->n_windows * 2 + 255) / 256, 128));
-    hipLaunchKernelGGL(fhat_terms_kernel, dim3(std::max(blocks, 1u)), dim3(256), 0, h->stream, P);
-    hipLaunchKernelGGL(fhat_scale_kernel, dim3(std::max(blocks, 1u)), dim3(256), 0, h->stream, P);
+    hipLaunchKernelGGL(fhat_terms_kernel, dim3(std::max(blocks, 1u)), dim3(256), 0, fs, P);
+    hipLaunchKernelGGL(fhat_scale_kernel, dim3(std::max(blocks, 1u)), dim3(256), 0, fs, P);
     HIPCHK(hipGetLastError());
+    if (side) {
+        HIPCHK(hipEventRecord(h->ev_fhat_side, fs));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_fhat_side, 0));
+    }
     HIPCHK(hipEventRecord(h->ev_fhat, h->stream));
     return BOSSX_OK;
 }
@@ -2057,6 +2074,7 @@ int bossx_fhat_reset(bossx_engine *h, const double *counts, int64_t n_windows) {
     if (!h || !h->finalized || n_windows < 0) return fail(h, BOSSX_E_INVALID, "bad fhat_reset call");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->stream_fhat) HIPCHK(hipStreamSynchronize(h->stream_fhat));
     int rc;
     if (n_windows != h->rs_windows || !h->d_rs_counts) {
         if (h->d_rs_counts) HIPCHK(hipFree(h->d_rs_counts));
@@ -2080,6 +2098,7 @@ int bossx_fhat_add(bossx_engine *h, const int64_t *keys, int32_t n_keys) {
     if (!h->ev_rs_keys) HIPCHK(hipEventCreateWithFlags(&h->ev_rs_keys, hipEventDisableTiming));
     if (size_t(n_keys) > h->rs_keys_cap) {
         HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->stream_fhat) HIPCHK(hipStreamSynchronize(h->stream_fhat));
         if (h->d_rs_keys) HIPCHK(hipFree(h->d_rs_keys));
         if (h->h_rs_keys_pin) HIPCHK(hipHostFree(h->h_rs_keys_pin));
         h->d_rs_keys = nullptr; h->h_rs_keys_pin = nullptr; h->rs_keys_cap = 0;
@@ -2092,11 +2111,12 @@ int bossx_fhat_add(bossx_engine *h, const int64_t *keys, int32_t n_keys) {
     // (the previous batch's copy has left it: the event is long signalled in practice)
     HIPCHK(hipEventSynchronize(h->ev_rs_keys));
     memcpy(h->h_rs_keys_pin, keys, size_t(n_keys) * sizeof(int64_t));
-    HIPCHK(hipMemcpyAsync(h->d_rs_keys, h->h_rs_keys_pin, size_t(n_keys) * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipEventRecord(h->ev_rs_keys, h->stream));
-    hipLaunchKernelGGL(fhat_add_kernel, dim3(uint32_t((n_keys + 255) / 256)), dim3(256), 0, h->stream,
+    hipStream_t fs = h->stream_fhat ? h->stream_fhat : h->stream;
+    HIPCHK(hipMemcpyAsync(h->d_rs_keys, h->h_rs_keys_pin, size_t(n_keys) * sizeof(int64_t), hipMemcpyHostToDevice, fs));
+    hipLaunchKernelGGL(fhat_add_kernel, dim3(uint32_t((n_keys + 255) / 256)), dim3(256), 0, fs,
                        h->d_rs_counts, h->d_rs_keys, n_keys, h->rs_windows * 2);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev_rs_keys, fs));      // the keys have left the staging buffer AND the counts hold them
     return BOSSX_OK;
 }
 
