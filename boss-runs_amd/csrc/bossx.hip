@@ -1860,7 +1860,7 @@ void launch_chain(bossx_engine *h, const ChainParams &P0, size_t lds, hipStream_
         Q.sup = (h->d_spec_sup && !h->spec_no_compose) ? h->d_spec_sup : nullptr; Q.sup_off = h->d_sup_off; Q.sup_total = h->spec_sup_total; Q.group = h->spec_seg_chunks;
         if (Q.sup)          // every group of seg_chunks rows composed into one super-row, all groups at once: the stitch walks groups
             hipLaunchKernelGGL(chain_compose_kernel, dim3(uint32_t(h->spec_sup_total), BOSSX_NWIN, uint32_t(h->nb * 2)), dim3(64),
-                               size_t(h->spec_seg_chunks) * kSpecRow * sizeof(double), stream, Q);
+                               size_t(h->spec_seg_chunks) * size_t(comp_row(h->spec_seg_chunks)) * sizeof(double), stream, Q);
         hipLaunchKernelGGL(chain_stitch_kernel, dim3(uint32_t(h->filt.size() * size_t(h->nb) * 2 * BOSSX_NWIN)), dim3(64), 0, stream, Q);
         if (getenv("BOSSX_SPEC_SELFTEST") && h->spec_total > h->spec_seg_chunks)      // (the first contig needs a second segment)
             hipLaunchKernelGGL(chain_spoil_kernel, dim3(1), dim3(1), 0, stream, h->d_spec_starts, int64_t(h->spec_seg_chunks));

@@ -1,7 +1,7 @@
 #!/bin/bash
-# GRCh38 on one GPU: chain counters + rocprofv3 kernel trace (gpurun -- bash scripts/r4_grch38_trace.sh)
+# GRCh38 on one GPU: chain counters + rocprofv3 kernel trace (gpurun -- bash scripts/grch38_trace.sh)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT="$ROOT/gpurun_out/r4/grch38"
+OUT="$ROOT/gpurun_out/grch38"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export BOSSX_BATCH_CACHE=/tmp/bossx_batches_grch38
