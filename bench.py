@@ -167,6 +167,7 @@ def pmc_traffic(workload, kernel_substr, only=None):
         return None, None, None, None
     d = json.load(open(files[-1]))
     tot, found = 0.0, False
+    _PMC_EXTRA.clear()
     for name, v in d.get("kernels", {}).items():
         if only is not None and only not in name:
             continue
@@ -175,7 +176,13 @@ def pmc_traffic(workload, kernel_substr, only=None):
             per_update = v.get("launches_per_update", 1.0)
             tot += (2.0 * v["FETCH_SIZE_avg_per_launch"] + v["WRITE_SIZE_avg_per_launch"]) * 1024.0 * per_update
             found = True
+            if v.get("avg_ns_timed_region"):      # the trace's launches of the lone-update loop on their own (summarise_prof.py)
+                _PMC_EXTRA["rocprof_avg_launch_ms_timed_region"] = v["avg_ns_timed_region"] / 1e6
+                _PMC_EXTRA["rocprof_avg_launch_ms_all_loops"] = v["avg_ns"] / 1e6
     return (tot if found else None), os.path.basename(files[-1]), d.get("commit"), d.get("kernel_sources")
+
+
+_PMC_EXTRA = {}
 
 
 def kernel_sources_hash():
@@ -844,6 +851,11 @@ def main():
                          "traffic_same_commit": bool(commit and traffic_commit and commit[:12] == str(traffic_commit)[:12]),
                          "traffic_same_kernel_sources": bool(traffic_ksrc and traffic_ksrc == kernel_sources_hash()),
                          "algorithmic_bytes": kern[roof_k]["bytes"], "avg_launch_ms": kern[roof_k]["avg_ms"],
+                         "rocprof": dict(_PMC_EXTRA, note="kernel-trace durations of the committed profile: the launches of its lone-update loop, and all 53 "
+                                         "launches of the script (later loops run on a state that has saturated further: slower launches)"),
+                         "pattern_ceiling": {"source": "profiles/r05_rw_pattern.txt (scripts/experiments/rw_pattern.hip: the launch's loads and stores without its arithmetic)",
+                                             "memory_system_tb_s_for_this_read_write_mix": [2.7, 3.3], "reads_only_tb_s": [6.1, 6.9],
+                                             "note": "a write costs twice a read and by the 64-byte granule it dirties; 0.40 of 8 TB/s is at or beyond what the machine gives the pattern (DESIGN 4.2)"},
                          "full_sweep": {"avg_launch_ms": kern_full[roof_k]["avg_ms"], "algorithmic_bytes": kern_full[roof_k]["bytes"],
                                         "achieved": kern_full[roof_k]["gbs"], "frac": (kern_full[roof_k]["gbs"] or 0.0) / HBM_PEAK_GBS,
                                         "note": "the same batches with every tile swept (BOSSX_INCREMENTAL=0), resident loop"},

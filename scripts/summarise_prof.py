@@ -29,6 +29,21 @@ if f:
     if n_upd:
         for v in res["kernels"].values():
             v["launches_per_update"] = v["calls"] / n_upd
+# The trace holds EVERY loop of bench.py (lone updates, pipelined, resident, every tile swept, the loop without events): a kernel's
+# average over all of them mixes regimes — the state saturates as the script goes on — so the launches of the TIMED region (the lone
+# loop: launches [warmup, warmup + steps) of a once-per-update kernel; profile_gpu.sh runs --warmup 3 --steps 10) are averaged on their own.
+f = find("trace", "*kernel_trace.csv")
+if f:
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+    per = {}
+    for r in rows:
+        per.setdefault(r["Kernel_Name"].split("(")[0], []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    W, K = 3, 10
+    for name, ds in per.items():
+        v = res["kernels"].get(name)
+        if v is not None and v.get("launches_per_update", 0) >= 0.9 and len(ds) >= W + K:
+            v["avg_ns_timed_region"] = sum(ds[W:W + K]) / K
+            v["timed_region_launches"] = "launches %d..%d of %d in start order (the lone-update loop)" % (W, W + K - 1, len(ds))
 for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     f = find(os.path.basename(d), "*counter_collection.csv")
     if not f:
@@ -58,7 +73,7 @@ for name, v in res["kernels"].items():
             if g(k) is not None:
                 v[k + "_frac_of_wave_cycles"] = g(k) / g("SQ_WAVE_CYCLES")
 json.dump(res, open(os.path.join(out, "%s_summary.json" % tag), "w"), indent=1)
-KEYS = ("calls", "avg_ns", "pct", "hbm_bytes_per_launch", "l2_hit_rate", "SQ_WAIT_ANY_frac_of_wave_cycles",
+KEYS = ("calls", "avg_ns", "avg_ns_timed_region", "pct", "hbm_bytes_per_launch", "l2_hit_rate", "SQ_WAIT_ANY_frac_of_wave_cycles",
         "SQ_ACTIVE_INST_VALU_frac_of_wave_cycles", "SQ_ACTIVE_INST_ANY_frac_of_wave_cycles")
 for k, v in sorted(res["kernels"].items(), key=lambda kv: -kv[1].get("total_ns", 0))[:8]:
     print(k[:48], {a: (round(v[a], 3) if isinstance(v[a], float) else v[a]) for a in KEYS if a in v})
