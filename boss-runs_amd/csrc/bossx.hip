@@ -536,6 +536,11 @@ void bossx_destroy(bossx_engine *h) {
     if (h->d_carry_ring) hipFree(h->d_carry_ring);
     if (h->d_spec_stats && getenv("BOSSX_SPEC_STATS")) {
         unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st2[2] = {0, 0};
+#ifdef BOSSX_STITCH_PROBE
+        unsigned long long pr[6] = {0, 0, 0, 0, 0, 0};
+        if (hipMemcpy(pr, h->d_spec_stats + 72, sizeof(pr), hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "[bossx] stitch probe (clock64 ticks, all launches): slowest wave ever %llu; sums over waves: cut rows %llu, other slow rows %llu, pieces %llu, whole waves %llu; most cut-row time on one wave (cumulative max) %llu\n", pr[0], pr[1], pr[2], pr[3], pr[4], pr[5]);
+#endif
         if (hipMemcpy(st2, h->d_spec_stats + 69, sizeof(st2), hipMemcpyDeviceToHost) == hipSuccess)
             fprintf(stderr, "[bossx] stitch: %llu cut rows walked piece by piece, %llu stretches evaluated on one rounding grid (each a round trip to the bin sums)\n", st2[1], st2[0]);
         if (hipMemcpy(st, h->d_spec_stats, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess)
