@@ -323,9 +323,9 @@ SweepParams sweep_params(bossx_engine *h) {
 // Rare path: a second batch arrives (or a slot is re-staged) before the sweep that would have
 // applied the pending one.  Apply the pending batch with the global-atomic scatter kernel; it
 // marks `touched`, which the next sweep then reads.
-// Derived entropy (kernels.hip.inc: ent_save_site) is the one-barcode engine's form; with several barcodes E is written at every lookup.
+// Derived entropy (kernels.hip.inc: ent_save_site): what the passes that modify patterns without looking them up, and the export, need.
 EntSave ent_save_of(const bossx_engine *h) {
-    return (h->nb == 1 && h->d_entropy && h->lut_set) ? EntSave{h->d_entropy, h->d_lut_ent, h->d_touched} : EntSave{nullptr, nullptr, nullptr};
+    return (h->d_entropy && h->lut_set) ? EntSave{h->d_entropy, h->d_lut_ent, h->d_touched, h->Gp} : EntSave{nullptr, nullptr, nullptr, 0};
 }
 
 int flush_pending(bossx_engine *h) {
@@ -413,8 +413,8 @@ int convert_field(bossx_engine *h, const ContigInfo &c, int32_t which, void *hos
             if (which == 0)
                 hipLaunchKernelGGL(planes_convert_kernel, grid, dim3(256), 0, h->stream, SiteState{h->d_state, h->nb}, h->nb, c.site_off, s0, n,
                                    static_cast<uint16_t *>(tmp), to_device ? 1 : 0);
-            else if (!to_device && ent_save_of(h).E)      // one barcode: most entropies are derived from the counters (export_entropy_kernel)
-                hipLaunchKernelGGL(export_entropy_kernel, grid, dim3(256), 0, h->stream, SiteState{h->d_state, h->nb}, ent_save_of(h), c.site_off, s0, n,
+            else if (!to_device && ent_save_of(h).E)      // most entropies are derived from the counters (export_entropy_kernel)
+                hipLaunchKernelGGL(export_entropy_kernel, grid, dim3(256), 0, h->stream, SiteState{h->d_state, h->nb}, ent_save_of(h), int32_t(pass_b), c.site_off, s0, n,
                                    static_cast<double *>(tmp));
             else
                 hipLaunchKernelGGL(entropy_convert_kernel, grid, dim3(256), 0, h->stream, h->d_entropy + pass_b * h->Gp, c.site_off, s0, n,
@@ -798,9 +798,9 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
         const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         const bool multi = h->nb > 1;
         const void *fn[2][2] = {{multi ? reinterpret_cast<const void *>(site_sweep_kernel<false, false, true>) : reinterpret_cast<const void *>(site_sweep1_kernel<false, true>),
-                                 multi ? reinterpret_cast<const void *>(site_sweep_kernel<false, true, true>) : reinterpret_cast<const void *>(site_sweep1_kernel<false, true>)},
+                                 multi ? reinterpret_cast<const void *>(site_sweep_kernel<false, false, true>) : reinterpret_cast<const void *>(site_sweep1_kernel<false, true>)},
                                 {multi ? reinterpret_cast<const void *>(site_sweep_kernel<true, false, true>) : reinterpret_cast<const void *>(site_sweep1_kernel<true, true>),
-                                 multi ? reinterpret_cast<const void *>(site_sweep_kernel<true, true, true>) : reinterpret_cast<const void *>(site_sweep1_kernel<true, true>)}};
+                                 multi ? reinterpret_cast<const void *>(site_sweep_kernel<true, false, true>) : reinterpret_cast<const void *>(site_sweep1_kernel<true, true>)}};
         if (const char *ce = getenv("BOSSX_SWEEP_CHUNK")) h->sweep_chunk = uint32_t(std::max(atoi(ce), 0));
         const char *e = getenv("BOSSX_SWEEP_BLOCKS_PER_CU");
         for (int a = 0; a < 2; ++a)
@@ -1485,8 +1485,8 @@ namespace {
         /* (the one-barcode kernel splits the items evenly over its resident blocks; the several-barcode one hands runs out) */ \
         const uint32_t blocks_ = (P).work_ctr ? (h->nb > 1 ? std::min((n_items_ + (P).chunk - 1u) / (P).chunk, res_) : std::min(n_items_, res_)) : n_items_; \
         if (h->nb > 1) {                                                                                  \
-            if (ent_) hipLaunchKernelGGL((site_sweep_kernel<ING, true, true>), dim3(blocks_), block, lds, stream, P); \
-            else hipLaunchKernelGGL((site_sweep_kernel<ING, false, true>), dim3(blocks_), block, lds, stream, P); \
+            /* (derived entropy: nothing entropy-specific is compiled into the scoring any more) */     \
+            hipLaunchKernelGGL((site_sweep_kernel<ING, false, true>), dim3(blocks_), block, lds, stream, P); \
         } else {                                                                                          \
             /* (one instantiation: the entropy stores are guarded by the array's presence at run time — the variant compiled */ \
             /* without them came out of the register allocator 25 registers fatter and spilling) */     \

@@ -1603,7 +1603,8 @@ def test_benefit_chain_equals_bottleneck(form, in_tmp, monkeypatch):
     eng.close()
 
 
-def test_derived_entropy_crossings_vs_oracle(in_tmp):
+@pytest.mark.parametrize("nb", [1, 2])
+def test_derived_entropy_crossings_vs_oracle(nb, in_tmp):
     """Derived entropy (one-barcode engine, kernels.hip.inc: ent_save_site): the engine writes no entropy at a lookup — a looked-up,
     uncapped site's entropy is a function of its counters — and keeps the array only for capped / never-scored / pending sites.  What
     that must get right, every step against the oracle's array (sequences.py:419-452):
@@ -1612,7 +1613,9 @@ def test_derived_entropy_crossings_vs_oracle(in_tmp):
       3. a second batch ingested before the sweep (fallback scatter: patterns modified without a lookup) with sites that cross in
          the second pending batch after having been touched by the first,
       4. export / import of the materialised array into a fresh engine, which then continues identically,
-      5. more stacks on already capped ground (nothing changes there)."""
+      5. more stacks on already capped ground (nothing changes there).
+    nb = 2: the several-barcode kernel (apply passes + row-wide change mask; every read of a stack in barcode 1, so barcode 0's
+    sites of those rows are looked up without having changed)."""
     from boss_runs_amd import synth
     from boss_runs_amd.config import BossConfig
     from boss_runs_amd.runs import BossRuns
@@ -1626,29 +1629,38 @@ def test_derived_entropy_crossings_vs_oracle(in_tmp):
         args.general.name = name
         args.optional.ploidy = 2
         args.optional.bucket_threshold = 0
+        if nb > 1:
+            args.general.barcodes = ["barcode%02d" % (i + 1) for i in range(nb)]
         r = BossRuns(args)
         r.init(contigs=strs)
         return r
-    runs = fresh("dent")
-    o = OracleRuns(strs, ploidy=2, nbarcodes=1, bucket_threshold=0)
+    runs = fresh("dent%d" % nb)
+    o = OracleRuns(strs, ploidy=2, nbarcodes=nb, bucket_threshold=0)
+    rngb = np.random.default_rng(4)
+
+    def bcs_of(seqs, fixed=None):
+        if nb == 1:
+            return None
+        return {k: (fixed if fixed is not None else int(rngb.integers(0, nb))) for k in seqs}
 
     def check(tag):
         for n, oc in o.contigs.items():
             pc = runs.contigs[n]
             assert np.array_equal(pc.coverage, oc.coverage), (tag, n)
             assert np.array_equal(pc.scores, oc.scores), (tag, n)
-            bad = np.flatnonzero(pc.entropy[:, 0] != oc.entropy[:, 0])
+            bad = np.flatnonzero((pc.entropy != oc.entropy).any(axis=1))
             assert bad.size == 0, (tag, n, bad[:8], oc.coverage[bad[:3]].tolist())
 
     def stack(name, spans_per_read, depth, prefix):
         spans = [s for s in spans_per_read for _ in range(depth)]
         return _exact_reads(contigs, name, spans, prefix)
 
-    def step(paf, seqs, tag):
+    def step(paf, seqs, tag, bc=None):
         rl = {k: len(v) for k, v in seqs.items()}
-        o.process_batch(paf, seqs, read_lengths=rl)
+        bcs = bcs_of(seqs, bc)
+        o.process_batch(paf, seqs, read_lengths=rl, barcodes=bcs)
         runs.rl_dist.update(rl)
-        runs.process_batch_paf(paf, seqs)
+        runs.process_batch_paf(paf, seqs, barcodes=bcs)
         assert runs.threshold == o.threshold, tag
         check(tag)
 
@@ -1657,20 +1669,27 @@ def test_derived_entropy_crossings_vs_oracle(in_tmp):
     for b in range(2):
         batch = _drop_mappings_into(synth.make_batch(contigs, 900, seed=7700 + b, mean_len=4000.0, nbarcodes=1), "dA", 100_000, 112_000)
         step(batch["paf"], batch["seqs"], "plain%d" % b)
+    last = nb - 1                                  # (the stacks go to ONE barcode: the others' sites of those rows are looked up unchanged)
     pa, sa = stack("dA", [(20_000, 26_000)], 20, "sA")
-    step(pa, sa, "stackA_20")                      # depth ~20 + what was there: some sites cross already
+    step(pa, sa, "stackA_20", bc=last)             # depth ~20 + what was there: some sites cross already
     pa, sa = stack("dA", [(20_000, 26_000), (22_000, 31_000)], 9, "sA2")
-    step(pa, sa, "stackA_cross")
+    step(pa, sa, "stackA_cross", bc=last)
     pb_, sb = stack("dA", [(101_000, 109_000)], 35, "sB")
-    step(pb_, sb, "stackB_first_touch")
-    assert (o.contigs["dA"].coverage[102_000:108_000].sum(axis=1) >= 30).all()
+    step(pb_, sb, "stackB_first_touch", bc=last)
+    assert (o.contigs["dA"].coverage[102_000:108_000, :, last].sum(axis=1) >= 30).all()
     # 3: two batches before one sweep; the second makes sites of the first cross
     p1, s1 = stack("dB", [(30_000, 38_000)], 18, "t1")
     p2, s2 = stack("dB", [(33_000, 42_000)], 16, "t2")
     incs = {n: [] for n in o.contigs}
     for paf, seqs in ((p1, s1), (p2, s2)):
-        runs.engine.ingest_paf(paf, seqs)
-        for n, lst in convert_records(parse_paf(paf, min_len=200), seqs).items():
+        bcs = bcs_of(seqs, last)
+        runs.engine.ingest_paf(paf, seqs, barcodes=bcs)
+        pd = parse_paf(paf, min_len=200)
+        if bcs is not None:
+            for recs in pd.values():
+                for r in recs:
+                    r.barcode = bcs[r.qname]
+        for n, lst in convert_records(pd, seqs).items():
             incs[n].extend(lst)
     for n, c in o.contigs.items():
         c.increment_coverage(incs[n])
@@ -1690,10 +1709,11 @@ def test_derived_entropy_crossings_vs_oracle(in_tmp):
     # 5: both engines go on: stacks on capped ground and beside it
     pc_, sc = stack("dA", [(24_000, 33_000), (105_000, 113_000)], 12, "sC")
     rl = {k: len(v) for k, v in sc.items()}
-    o.process_batch(pc_, sc, read_lengths=rl)
+    bcs = bcs_of(sc, last)
+    o.process_batch(pc_, sc, read_lengths=rl, barcodes=bcs)
     for r in (runs, runs2):
         r.rl_dist.update(rl)
-        r.process_batch_paf(pc_, sc)
+        r.process_batch_paf(pc_, sc, barcodes=bcs)
     check("after_import")
     for n, oc in o.contigs.items():
         assert np.array_equal(runs2.contigs[n].entropy, oc.entropy), n
