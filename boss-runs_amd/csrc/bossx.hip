@@ -120,6 +120,7 @@ struct bossx_engine {
     uint8_t *d_strat_bits = nullptr;   // packed masks (allocated on first use)
     double *d_entropy = nullptr, *d_ds = nullptr, *d_benefit = nullptr;
     double *d_lut_score = nullptr, *d_lut_ent = nullptr, *d_fhat = nullptr;
+    std::vector<char> raw_blob;       // byte-per-base copy of a batch's reads (BOSSX_HOST_WALK / BOSSX_CHECK_DEVICE_WALK only)
     unsigned long long *d_bucket_sums = nullptr, *d_stats = nullptr;
     uint32_t *d_drop_count = nullptr;
     int64_t fhat_cap = 0;
@@ -184,7 +185,6 @@ struct bossx_engine {
     uint32_t *d_walk = nullptr; size_t d_walk_cap = 0;        // n_runs | walk_err | ops_off | group_count | group_cursor | totals
     uint32_t *d_lane_scan = nullptr; size_t d_lane_scan_cap = 0;   // per mapping and lane: exclusive prefixes of the walk (pass 1 -> pass 2)
     std::vector<uint8_t> read_dirty;                          // per read: holds a byte other than A/C/G/T
-    bool blob_is_pinned = false;                              // the blob handed to stage_core lies in h_blob_pin
     // pinned scratch
     void *h_pin = nullptr; size_t pin_cap = 0;
     void *h_blob_pin = nullptr; size_t blob_pin_cap = 0;
@@ -944,36 +944,46 @@ void run_threads(int nt, F &&fn) {
     for (auto &th : pool) th.join();
 }
 
-// 32 bytes per step: a byte is one of A C G T iff a 16-entry table indexed by its low nibble
-// (A = 0x41, C = 0x43, T = 0x54, G = 0x47) gives the byte back; the other entries hold a byte
-// whose own low nibble differs from their index, so they can never match
-__attribute__((target("avx2"))) bool bytes_all_acgt_avx2(const char *p, size_t n) {
+// The read blob of the device holds four bits per base (engine.hpp: kNibBad): a read's bytes -> nibbles, low nibble first, from a
+// byte boundary on (an odd read's last high nibble is kNibBad: never addressed).  Returns true if some byte is not A / C / G / T.
+struct NibTable { uint8_t t[256]; constexpr NibTable() : t() { for (int i = 0; i < 256; ++i) t[i] = uint8_t(kNibBad); t['A'] = 0; t['C'] = 1; t['G'] = 2; t['T'] = 3;
+                                                                 t['0'] = 4; t['1'] = 5; t['2'] = 6; t['3'] = 7; t['4'] = 8; t['7'] = 9; } };
+constexpr NibTable kNib{};
+bool pack_read_scalar(const char *p, size_t n, uint8_t *dst) {
+    unsigned dirty = 0;
+    size_t i = 0;
+    for (; i + 2 <= n; i += 2) {
+        const unsigned a = kNib.t[static_cast<unsigned char>(p[i])], b = kNib.t[static_cast<unsigned char>(p[i + 1])];
+        dirty |= (a | b) >> 2;
+        dst[i >> 1] = uint8_t(a | (b << 4));
+    }
+    if (i < n) { const unsigned a = kNib.t[static_cast<unsigned char>(p[i])]; dirty |= a >> 2; dst[i >> 1] = uint8_t(a | (kNibBad << 4)); }
+    return dirty != 0;
+}
+// 32 bytes per step: a byte is one of A C G T iff a 16-entry table indexed by its low nibble (A = 0x41, C = 0x43, T = 0x54,
+// G = 0x47) gives the byte back (the other entries hold a byte whose own low nibble differs from their index: they never match);
+// a second table over the same index gives the code.  A block with any other byte (rare: digits, N) goes through the scalar table.
+__attribute__((target("avx2"))) bool pack_read_avx2(const char *p, size_t n, uint8_t *dst) {
     const __m256i lut = _mm256_setr_epi8(-1, 0x41, -1, 0x43, 0x54, -1, -1, 0x47, -1, -1, -1, -1, -1, -1, -1, 0,
                                          -1, 0x41, -1, 0x43, 0x54, -1, -1, 0x47, -1, -1, -1, -1, -1, -1, -1, 0);
-    const __m256i low = _mm256_set1_epi8(0x0f);
-    __m256i ok = _mm256_set1_epi8(char(0xff));
+    const __m256i code = _mm256_setr_epi8(0, 0, 0, 1, 3, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 3, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m256i low = _mm256_set1_epi8(0x0f), pair = _mm256_set1_epi16(0x1001);
+    bool dirty = false;
     size_t i = 0;
     for (; i + 32 <= n; i += 32) {
         const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(p + i));
-        ok = _mm256_and_si256(ok, _mm256_cmpeq_epi8(_mm256_shuffle_epi8(lut, _mm256_and_si256(v, low)), v));
+        const __m256i lo = _mm256_and_si256(v, low);
+        if (_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_shuffle_epi8(lut, lo), v)) != -1) { dirty |= pack_read_scalar(p + i, 32, dst + (i >> 1)); continue; }
+        const __m256i w = _mm256_maddubs_epi16(_mm256_shuffle_epi8(code, lo), pair);                      // even + 16 * odd, per pair of bytes
+        const __m256i pk = _mm256_permute4x64_epi64(_mm256_packus_epi16(w, w), 0x08);
+        _mm_storeu_si128(reinterpret_cast<__m128i *>(dst + (i >> 1)), _mm256_castsi256_si128(pk));
     }
-    bool good = _mm256_movemask_epi8(ok) == -1;
-    for (; i < n; ++i) {
-        const unsigned char c = static_cast<unsigned char>(p[i]);
-        good = good && ((c == 'A') | (c == 'C') | (c == 'G') | (c == 'T'));
-    }
-    return good;
+    if (i < n) dirty |= pack_read_scalar(p + i, n - i, dst + (i >> 1));
+    return dirty;
 }
-
-bool bytes_all_acgt(const char *p, size_t n) {
+bool pack_read(const char *p, size_t n, uint8_t *dst) {
     static const bool avx2 = __builtin_cpu_supports("avx2");
-    if (avx2) return bytes_all_acgt_avx2(p, n);
-    unsigned bad = 0;
-    for (size_t i = 0; i < n; ++i) {
-        const unsigned char c = static_cast<unsigned char>(p[i]);
-        bad |= unsigned(!((c == 'A') | (c == 'C') | (c == 'G') | (c == 'T')));
-    }
-    return bad == 0;
+    return avx2 ? pack_read_avx2(p, n, dst) : pack_read_scalar(p, n, dst);
 }
 
 template <typename T>
@@ -1092,8 +1102,10 @@ int check_device_walk(bossx_engine *h, bossx_engine::Staged &st, const ParseInpu
 // look for bytes other than A/C/G/T, the copy of the PAF text into page-locked memory and the line
 // parse are ONE parallel region; the uploads start as soon as it ends and overlap with the rest of
 // the host work.
+// `seq_off`: PADDED base offsets of the reads in the blob (every read on an even index: two bases per byte on the device);
+// `seq_len`: their lengths; `seq_ptrs`: where each read's bytes are now (the caller's strings: borrowed for the call).
 int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *names, const int64_t *name_off,
-               char *seqs, const int64_t *seq_off, const char *const *seq_ptrs, const int32_t *barcodes, int32_t n_reads,
+               const int64_t *seq_off, const int64_t *seq_len, const char *const *seq_ptrs, const int32_t *barcodes, int32_t n_reads,
                int32_t min_len, bossx_batch_summary *summary, int32_t *n_rec, int64_t *aligned_bases) {
     const bool timing = getenv("BOSSX_STAGE_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
@@ -1129,11 +1141,24 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
             hipStreamSynchronize(h->stream_stage);
         }
     } upload_guard{h};
-    // slack: the ingest prologue reads a 384-byte window that may start at the last base
-    if ((rc = grow_dev(h, &st.d_blob, &st.blob_cap, blob_bytes + 1024, 0))) return rc;
+    if ((rc = grow_dev(h, &st.d_blob, &st.blob_cap, blob_bytes / 2 + 1024, 0))) return rc;
+    // (the page-locked buffer is free: every upload out of it was waited for by the stage stream, synchronised above)
+    if (blob_bytes / 2 + 64 > h->blob_pin_cap) {
+        if (h->h_blob_pin) HIPCHK(hipHostFree(h->h_blob_pin));
+        h->h_blob_pin = nullptr; h->blob_pin_cap = 0;
+        const size_t cap = (blob_bytes / 2 + 64) * 5 / 4;
+        HIPCHK(hipHostMalloc(&h->h_blob_pin, cap, hipHostMallocDefault));
+        h->blob_pin_cap = cap;
+    }
+    uint8_t *const packed = static_cast<uint8_t *>(h->h_blob_pin);
     ParseInput in{paf ? paf : "", paf ? paf_len : 0, names, name_off, seq_off, barcodes, n_reads, min_len, h->nb};
-    in.seqs = seqs;
+    in.seq_len = seq_len;
     const bool host_walk = getenv("BOSSX_HOST_WALK") != nullptr;
+    // the host walk (and the comparison of the two walks) looks at the bases themselves: a byte-per-base copy at the same offsets
+    const bool raw_copy = host_walk || getenv("BOSSX_CHECK_DEVICE_WALK") != nullptr;
+    if (raw_copy) h->raw_blob.assign(blob_bytes + 64, 'A');
+    char *const seqs = raw_copy ? h->raw_blob.data() : nullptr;
+    in.seqs = seqs;
     if (!host_walk) {
         if ((rc = grow_pin(h, &h->h_paf_pin, &h->paf_pin_cap, in.paf_len + 64))) return rc;
         if ((rc = grow_dev(h, &h->d_paf, &h->d_paf_cap, in.paf_len + 64, 4096))) return rc;
@@ -1168,15 +1193,15 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
             const int32_t i0 = int32_t(bp - seq_off), i1 = int32_t(ep - seq_off);
             bool dirty = false;
             for (int32_t i = i0; i < i1; ++i) {
-                const size_t len = size_t(seq_off[i + 1] - seq_off[i]);
-                if (seq_ptrs) memcpy(seqs + seq_off[i], seq_ptrs[i], len);
-                const bool d = !bytes_all_acgt(seqs + seq_off[i], len);
+                const size_t len = size_t(seq_len[i]);
+                if (raw_copy) memcpy(seqs + seq_off[i], seq_ptrs[i], len);
+                const bool d = pack_read(seq_ptrs[i], len, packed + (seq_off[i] >> 1));      // (what is not A C G T is looked at again where it is aligned)
                 h->read_dirty[size_t(i)] = d ? 1 : 0;
                 dirty |= d;
             }
             if (dirty) any_dirty.store(1, std::memory_order_relaxed);
             if (i1 > i0 && seq_off[i1] > seq_off[i0] &&
-                hipMemcpyAsync(st.d_blob + seq_off[i0], seqs + seq_off[i0], size_t(seq_off[i1] - seq_off[i0]), hipMemcpyHostToDevice,
+                hipMemcpyAsync(st.d_blob + (seq_off[i0] >> 1), packed + (seq_off[i0] >> 1), size_t(seq_off[i1] - seq_off[i0]) >> 1, hipMemcpyHostToDevice,
                                h->stream_ups[g % n_up]) != hipSuccess)
                 up_fail.store(1);
         }
@@ -1190,7 +1215,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
         for (int i = 0; i < bossx_engine::kUpStreams && up_err == hipSuccess; ++i) up_err = hipStreamWaitEvent(h->stream_stage, h->ev_ups[i], 0);
         reads_awaited = true;
     };
-    const bool defer_reads = seq_ptrs != nullptr && !host_walk && !getenv("BOSSX_NO_DEFER_READS");
+    const bool defer_reads = !host_walk && !getenv("BOSSX_NO_DEFER_READS");
     in.after_pass1 = [&]() {      // everything staged on the upload streams precedes what follows on the main one
         if (up_fail.load()) { up_err = hipErrorUnknown; return; }
         up_err = hipEventRecord(h->ev_txt, h->stream_txt);
@@ -1377,8 +1402,16 @@ int bossx_stage_batch(bossx_engine *h, const char *paf, size_t paf_len, const ch
     if (!h || !h->finalized) return fail(h, BOSSX_E_INVALID, "stage_batch before finalize");
     if (n_reads < 0 || (n_reads > 0 && (!names || !name_off || !seqs || !seq_off))) return fail(h, BOSSX_E_INVALID, "bad batch arrays");
     HIPCHK(hipSetDevice(h->cfg.device));
-    // (the blob is the caller's: it is only read)
-    return stage_core(h, paf, paf_len, names, name_off, const_cast<char *>(seqs), seq_off, nullptr, barcodes, n_reads, min_len,
+    // (the blob is the caller's: it is only read — packed, like the strings of bossx_stage_batch_ptrs, into the engine's page-locked buffer)
+    std::vector<int64_t> poff(size_t(n_reads) + 1, 0), plen(size_t(n_reads), 0);
+    std::vector<const char *> ptrs(static_cast<size_t>(n_reads), nullptr);
+    for (int32_t i = 0; i < n_reads; ++i) {
+        plen[size_t(i)] = seq_off[i + 1] - seq_off[i];
+        if (plen[size_t(i)] < 0) return fail(h, BOSSX_E_INVALID, "seq_off must not decrease");
+        ptrs[size_t(i)] = seqs + seq_off[i];
+        poff[size_t(i) + 1] = poff[size_t(i)] + ((plen[size_t(i)] + 1) & ~int64_t(1));
+    }
+    return stage_core(h, paf, paf_len, names, name_off, poff.data(), plen.data(), ptrs.data(), barcodes, n_reads, min_len,
                       summary, n_rec, aligned_bases);
 }
 
@@ -1394,23 +1427,21 @@ int bossx_stage_batch_ptrs(bossx_engine *h, const char *paf, size_t paf_len, con
     std::vector<int64_t> name_off(size_t(n_reads) + 1, 0), seq_off(size_t(n_reads) + 1, 0);
     for (int32_t i = 0; i < n_reads; ++i) {
         name_off[size_t(i) + 1] = name_off[size_t(i)] + name_lens[i];
-        seq_off[size_t(i) + 1] = seq_off[size_t(i)] + seq_lens[i];
+        seq_off[size_t(i) + 1] = seq_off[size_t(i)] + ((seq_lens[i] + 1) & ~int64_t(1));      // (every read on an even base index: two bases per byte)
     }
     std::string names(size_t(name_off[size_t(n_reads)]), '\0');
     for (int32_t i = 0; i < n_reads; ++i) memcpy(&names[size_t(name_off[size_t(i)])], name_ptrs[i], size_t(name_lens[i]));
-    // the sequences are gathered into pinned memory inside stage_core's parallel region: one pass,
-    // and the H2D copy runs at full PCIe rate
-    const size_t blob_bytes = size_t(seq_off[size_t(n_reads)]);
-    HIPCHK(hipStreamSynchronize(h->stream_stage));     // the pinned buffer may still feed a copy (its uploads are ordered before the stage stream's last kernel)
-    if (blob_bytes + 64 > h->blob_pin_cap) {
-        if (h->h_blob_pin) HIPCHK(hipHostFree(h->h_blob_pin));
-        h->h_blob_pin = nullptr; h->blob_pin_cap = 0;
-        const size_t cap = (blob_bytes + 64) * 5 / 4;
-        HIPCHK(hipHostMalloc(&h->h_blob_pin, cap, hipHostMallocDefault));
-        h->blob_pin_cap = cap;
-    }
-    return stage_core(h, paf, paf_len, names.data(), name_off.data(), static_cast<char *>(h->h_blob_pin), seq_off.data(), seq_ptrs,
+    // the sequences are packed into pinned memory inside stage_core's parallel region: one pass, and half the bytes cross PCIe
+    return stage_core(h, paf, paf_len, names.data(), name_off.data(), seq_off.data(), seq_lens, seq_ptrs,
                       barcodes, n_reads, min_len, summary, n_rec, aligned_bases);
+}
+
+int bossx_pack_reads(const char *bases, int64_t n, uint8_t *dst, int32_t *dirty) {
+    if (n < 0 || (n > 0 && (!bases || !dst))) return BOSSX_E_INVALID;
+    // BOSSX_PACK_SCALAR: the table alone (what the vector path is held to)
+    const bool d = getenv("BOSSX_PACK_SCALAR") ? pack_read_scalar(bases, size_t(n), dst) : pack_read(bases, size_t(n), dst);
+    if (dirty) *dirty = d ? 1 : 0;
+    return BOSSX_OK;
 }
 
 int bossx_paf_summary(bossx_engine *h, const char *paf, size_t paf_len, const char *const *name_ptrs,

@@ -87,6 +87,11 @@ struct TilePiece {
 // Base codes of the emitted bases of a batch, one byte each, in emit order: 0..3 = A C G T on the
 // reference strand, 4 = deletion, kCodeSkip = nothing to count.  kCodePad bytes precede entry 0 so
 // that a thread may read the 8 bytes that START up to 7 bytes before a piece.
+// The read blob in HBM holds FOUR BITS per base (round 5: 12 MB instead of 24 over PCIe for a 4000-read batch — the upload was the
+// long pole of a lone update's staging): 0..3 = A C G T, 4..8 = the digits '0'..'4' and 9 = '7' (which the reference counts as
+// columns 0..4 and as a deletion, sequences.py:790, 803), kNibBad = any other byte (IndexError where it is aligned).  Blob indices
+// (MapPlan::seq_b / q0, EmitOp::qpos) are BASE indices: base i sits in byte i >> 1, low nibble first; every read starts on an even index.
+constexpr uint32_t kNibBad = 15;
 constexpr uint32_t kCodeSkip = 7;
 constexpr uint32_t kCodePad = 16;
 // The segments one barcode contributes to one sweep tile.  The groups of a tile are consecutive
@@ -176,6 +181,7 @@ struct ParseInput {
     int32_t n_threads = 0;       // 0: parse_threads()
     bool device_walk = false;    // fill ParsedBatch::plans / groups only; the CIGAR walk runs on the GPU
     const uint8_t *read_dirty = nullptr;   // per read: 1 if it holds a byte other than A/C/G/T (null: unknown, assume 1)
+    const int64_t *seq_len = nullptr;      // per read: its length where seq_off is PADDED (the device blob keeps every read on a byte boundary: two bases per byte); null: seq_off[r + 1] - seq_off[r]
     int64_t n_tiles = 0, paf_base = 0;     // device walk: tile count of the engine (group marking)
     // Work of the caller that is independent of the line parse (gathering the reads into the upload
     // buffer, copying the text) joins pass 1's parallel region as `extra_n` more tasks;

@@ -466,7 +466,7 @@ void walk_plans(const ParseInput &in, const std::vector<ContigInfo> &contigs, co
             if (!wo.range_err.code) { wo.range_err.group = int64_t(pi); wo.range_err.code = BOSSX_E_RANGE; wo.range_err.msg = std::move(msg); }
         };
         const ContigInfo &c = contigs[size_t(pl.cidx)];
-        const int64_t seq_b = in.seq_off[pl.read], seq_len = in.seq_off[pl.read + 1] - seq_b;
+        const int64_t seq_b = in.seq_off[pl.read], seq_len = in.seq_len ? in.seq_len[pl.read] : in.seq_off[pl.read + 1] - seq_b;
         const int64_t tlo = pl.tlo, thi = pl.thi;
         // query walk: '+' reads seq[q_first + i]; '-' reads comp(seq[q_first - i]) (sequences.py:707-716)
         int64_t q = pl.q_first;
@@ -941,7 +941,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         const bool local = cidx >= 0 && !contigs[size_t(cidx)].rejected && !contigs[size_t(cidx)].remote;
         const bool remote = cidx >= 0 && !contigs[size_t(cidx)].rejected && contigs[size_t(cidx)].remote;
         Plan pl{&r, int64_t(gi), read, local ? cidx : -1, 0, cur_emit, ops_at, 0, 0, 0, 0};
-        const int64_t seq_len = in.seq_off[read + 1] - in.seq_off[read];
+        const int64_t seq_len = in.seq_len ? in.seq_len[read] : in.seq_off[read + 1] - in.seq_off[read];
         if (!bad_q) read_slice(r, seq_len, pl.q_first, pl.q_len);
         pl.tlo = std::min(r.tstart, r.tend);
         pl.thi = std::max(r.tstart, r.tend);
@@ -1002,7 +1002,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             if (pl.cidx < 0) continue;
             const Rec &r = *pl.rec;
             const ContigInfo &c = contigs[size_t(pl.cidx)];
-            const int64_t seq_b = in.seq_off[pl.read], seq_len = in.seq_off[pl.read + 1] - seq_b;
+            const int64_t seq_b = in.seq_off[pl.read], seq_len = in.seq_len ? in.seq_len[pl.read] : in.seq_off[pl.read + 1] - seq_b;
             const int64_t tlo = pl.tlo, thi = pl.thi;
             const int64_t q = pl.q_first, q_need = pl.q_len;
             if (r.cg_len > size_t(UINT32_MAX) || thi - tlo > int64_t(UINT32_MAX)) {

@@ -236,6 +236,52 @@ def test_native_parser_vs_oracle_expansion(threads):
     assert np.array_equal(got["rev"], [int(r.rev) for r in recs])
 
 
+def test_read_packing_four_bits_per_base(monkeypatch):
+    """include/bossx.h (bossx_pack_reads): the reads cross PCIe as four bits per base.  The vector packer against the
+    scalar table and both against a numpy restatement of the code table, at every length 0..130 (tails, odd lengths), with
+    clean reads, digits (what sequences.py:766's np.fromstring reads as an index), lower case, N and arbitrary bytes."""
+    import ctypes as C
+    from boss_runs_amd import _lib
+    lib = _lib.load()
+    table = np.full(256, 15, np.uint8)
+    for ch, v in zip("ACGT012347", range(10)):
+        table[ord(ch)] = v
+    rng = np.random.default_rng(17)
+
+    def pack(raw):
+        dst = np.full((len(raw) + 1) // 2 + 8, 0xEE, np.uint8)
+        dirty = C.c_int32(-1)
+        assert lib.bossx_pack_reads(raw, len(raw), dst.ctypes.data, C.byref(dirty)) == 0
+        assert np.all(dst[(len(raw) + 1) // 2:] == 0xEE)          # nothing past the read's own bytes
+        return dst[:(len(raw) + 1) // 2].copy(), dirty.value
+
+    def want(raw):
+        c = table[np.frombuffer(raw, np.uint8)]
+        if c.size & 1:
+            c = np.append(c, np.uint8(15))
+        return (c[0::2] | (c[1::2] << 4)).astype(np.uint8), int(any(ch not in b"ACGT" for ch in raw))
+
+    for n in list(range(0, 131)) + [1000, 4097]:
+        clean = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), n))
+        kinds = [clean]
+        if n:
+            for alphabet in (b"ACGT0123456789", b"ACGTacgtN", bytes(range(1, 256))):
+                x = bytearray(clean)
+                for k in rng.integers(0, n, 1 + n // 37):
+                    x[k] = alphabet[int(rng.integers(0, len(alphabet)))]
+                kinds.append(bytes(x))
+            kinds.append(bytes(rng.integers(1, 256, n, dtype=np.uint8)))
+        for raw in kinds:
+            w, wd = want(raw)
+            for scalar in (False, True):
+                if scalar:
+                    monkeypatch.setenv("BOSSX_PACK_SCALAR", "1")
+                else:
+                    monkeypatch.delenv("BOSSX_PACK_SCALAR", raising=False)
+                got, d = pack(raw)
+                assert np.array_equal(got, w) and d == wd, (n, scalar)
+
+
 def test_dirty_reads_are_flagged_after_the_two_phase_job():
     """The host half of staging runs as a two-phase job (paf_host.cpp, WorkPool::start / JobGuard): the
     line parse + read index first, the caller's tasks — here, as in bossx_stage_batch_ptrs, slices of
