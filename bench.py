@@ -745,7 +745,14 @@ def main():
     sel = batches[a.warmup:]
     host_before = host_cpu_state()
     cs0 = eng.chain_stats()
-    elapsed = timed(barrier, lambda: [R.step_e2e(b) for b in sel])
+    step_s = []                      # wall time of every update of the timed region (diagnostic: a box's stalls show as outliers)
+
+    def lone_loop():
+        for b in sel:
+            t_b = time.perf_counter()
+            R.step_e2e(b)
+            step_s.append(time.perf_counter() - t_b)
+    elapsed = timed(barrier, lone_loop)
     host_after = host_cpu_state()
     cs1 = eng.chain_stats()
     stats = eng.kernel_stats()
@@ -878,6 +885,8 @@ def main():
                                       "longest contig would take at the dependent-op latency alone (5.1 cycles per bin) — the bound "
                                       "of the fallback kernel, not of an update"},
             "host": {"stage_batch_ms_mean": 1e3 * float(np.mean(t_stage)),
+                     "lone_update_ms_each": [round(1e3 * t, 3) for t in step_s],
+                     "lone_update_ms_median": 1e3 * float(np.median(step_s)),
                      "batch_generation_s": t_gen,
                      # the host side of the timed region: CPUs this container may use (CFS quota), CPU-seconds per wall-second
                      # the process spent inside it, and how long the scheduler held its threads back there (cgroup cpu.stat)
@@ -885,7 +894,9 @@ def main():
                      "cpus_busy_in_timed_region": (host_after["cpu_s"] - host_before["cpu_s"]) / max(elapsed, 1e-9),
                      "throttled_ms_in_timed_region": (host_after["throttled_usec"] - host_before["throttled_usec"]) / 1e3,
                      "throttled_periods_in_timed_region": host_after["nr_throttled"] - host_before["nr_throttled"],
-                     "note": "stage_batch = native PAF/CIGAR parse + upload of one batch (inside ms_per_step)"},
+                     "note": "stage_batch_ms_mean = native PAF/CIGAR parse + upload of one batch INTO A NEW SLOT (first-use allocations "
+                             "included: the resident loop's preparation, not the lone update's staging); lone_update_ms_each = "
+                             "the timed region's updates one by one (ms_per_step is their mean plus the closing synchronisation)"},
             "move_sum_on_fp64_matrix_core": eng.matrix_chain,
             "benefit_chain_form": dict(eng.chain_stats(),
                                        per_loop={"timed_lone_updates": {k: cs1[k] - cs0[k] for k in cs0},

@@ -95,6 +95,7 @@ struct bossx_engine {
     double *d_spec_sup = nullptr; int64_t *d_sup_off = nullptr; int64_t spec_sup_total = 0;      // chain_compose_kernel: one super-row per group of spec_seg_chunks chunks
     bool spec_no_compose = getenv("BOSSX_NO_COMPOSE") != nullptr;
     unsigned long long *d_spec_stats = nullptr;
+    unsigned long long *d_cand_probe = nullptr; size_t cand_probe_waves = 0;      // BOSSX_CAND_PROBE builds only
     unsigned long long *d_spec_hash = nullptr;     // [rows] input hash of every table row (0: never built)
     int32_t nb = 1;
 
@@ -534,6 +535,19 @@ void bossx_destroy(bossx_engine *h) {
     if (h->d_tile_done) hipFree(h->d_tile_done);
     if (h->d_tile_order) hipFree(h->d_tile_order);
     if (h->d_carry_ring) hipFree(h->d_carry_ring);
+#ifdef BOSSX_CAND_PROBE
+    if (h->d_cand_probe) {
+        std::vector<unsigned long long> cp(h->cand_probe_waves * 8, 0);
+        if (hipMemcpy(cp.data(), h->d_cand_probe, cp.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (size_t w = 0; w < h->cand_probe_waves; ++w) if (cp[w * 8 + 7]) for (int i = 0; i < 8; ++i) sum[i] += double(cp[w * 8 + size_t(i)]);
+            if (sum[7] > 0)
+                fprintf(stderr, "[bossx] candidates probe, last launch, per wave that reached the matrix-core loop (%.0f of %zu waves; ticks, %.2f per ns): loads + window sums %.0f, wait + differences + hash %.0f, scan + residue rule + edges %.0f, head / cut pieces %.0f, matrix core %.0f; whole wave %.0f = %.2f us\n",
+                        sum[7], h->cand_probe_waves, sum[5] / (sum[6] * 10.0), sum[0] / sum[7], sum[1] / sum[7], sum[2] / sum[7], sum[3] / sum[7], sum[4] / sum[7], sum[5] / sum[7], sum[6] / sum[7] * 0.01);
+        }
+        hipFree(h->d_cand_probe);
+    }
+#endif
     if (h->d_spec_stats && getenv("BOSSX_SPEC_STATS")) {
         unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st2[2] = {0, 0};
 #ifdef BOSSX_STITCH_PROBE
@@ -1890,8 +1904,16 @@ void launch_chain(bossx_engine *h, const ChainParams &P0, size_t lds, hipStream_
         P.spec_chunk_off = h->d_chunk_off; P.spec_total = h->spec_total; P.spec_starts = h->d_spec_starts; P.seg_chunks = h->spec_seg_chunks;
         Q.C = P; Q.chunk_off = h->d_chunk_off; Q.total_chunks = h->spec_total; Q.tab = h->d_spec_tab; Q.starts = h->d_spec_starts;
         Q.stats = getenv("BOSSX_SPEC_STATS") ? h->d_spec_stats : nullptr;
+        Q.probe = nullptr;
         Q.hash = getenv("BOSSX_SPEC_NO_SKIP") ? nullptr : h->d_spec_hash;
         Q.strict = getenv("BOSSX_SPEC_STRICT") ? atoi(getenv("BOSSX_SPEC_STRICT")) : 0;
+#ifdef BOSSX_CAND_PROBE
+        {
+            const size_t waves = size_t(h->spec_total) * size_t((BOSSX_NWIN + kCandWin - 1) / kCandWin) * size_t(h->nb * 2);
+            if (!h->d_cand_probe && hipMalloc(&h->d_cand_probe, waves * 64) == hipSuccess) h->cand_probe_waves = waves;
+            if (h->d_cand_probe && hipMemsetAsync(h->d_cand_probe, 0, waves * 64, stream) == hipSuccess) Q.probe = h->d_cand_probe;
+        }
+#endif
         hipLaunchKernelGGL(chain_candidates_kernel, dim3(uint32_t(h->spec_total), (BOSSX_NWIN + kCandWin - 1) / kCandWin, uint32_t(h->nb * 2)), dim3(64), 0, stream, Q);
         Q.sup = (h->d_spec_sup && !h->spec_no_compose) ? h->d_spec_sup : nullptr; Q.sup_off = h->d_sup_off; Q.sup_total = h->spec_sup_total; Q.group = h->spec_seg_chunks;
         if (Q.sup)          // every group of seg_chunks rows composed into one super-row, all groups at once: the stitch walks groups
