@@ -557,6 +557,16 @@ void bossx_destroy(bossx_engine *h) {
 #endif
         if (hipMemcpy(st2, h->d_spec_stats + 69, sizeof(st2), hipMemcpyDeviceToHost) == hipSuccess)
             fprintf(stderr, "[bossx] stitch: %llu cut rows walked piece by piece, %llu stretches evaluated on one rounding grid (each a round trip to the bin sums)\n", st2[1], st2[0]);
+        {
+            unsigned long long br[3] = {0, 0, 0};
+            if (hipMemcpy(br, h->d_spec_stats + 12, sizeof(br), hipMemcpyDeviceToHost) == hipSuccess)
+                fprintf(stderr, "[bossx] strided rows: %llu built; the stitch looked up %llu, %llu did not decide (evaluated from the exact value)\n", br[0], br[1], br[2]);
+#ifdef BOSSX_STRIDED_DEBUG
+            unsigned long long dbg[2] = {0, 0};
+            if (hipMemcpy(dbg, h->d_spec_stats + 15, sizeof(dbg), hipMemcpyDeviceToHost) == hipSuccess)
+                fprintf(stderr, "[bossx] strided debug: %llu strided super-row steps walked again chunk by chunk, %llu differ\n", dbg[0], dbg[1]);
+#endif
+        }
         if (hipMemcpy(st, h->d_spec_stats, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess)
             fprintf(stderr, "[bossx] stitch: %llu groups stepped through their super-row, %llu composed but out of reach, %llu not composed\n", st[9], st[10], st[11]);
         if (hipMemcpy(st, h->d_spec_stats, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess)
