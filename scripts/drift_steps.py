@@ -2,7 +2,7 @@
 per-kernel time of every update (sweep / benefit chain / histogram / masks), plus the chain's counters every ten updates.
    gpurun -- python3 scripts/drift_steps.py [workload] [steps]"""
 import os, sys, tempfile, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bench
 w = sys.argv[1] if len(sys.argv) > 1 else "chr20_21"
@@ -24,10 +24,10 @@ for i, b in enumerate(batches[5:]):
     R.step_e2e(b)
     dt = 1e3 * (time.perf_counter() - t0)
     ks = eng.kernel_stats()
-    rows.append((dt, ks["site_sweep"]["ms_last"], ks["benefit_chain"]["ms_last"], ks["threshold_hist"]["ms_last"], ks["strategy_mask"]["ms_last"]))
+    rows.append((dt, ks["site_sweep"]["ms_last"], ks["benefit_chain"]["ms_last"], ks["threshold_hist"]["ms_last"], ks["strategy_mask"]["ms_last"], ks["site_sweep"]["bytes_last"] / 1e6))
     if i % 10 == 9:
-        print("update %3d: wall %.2f ms | sweep %.3f chain %.3f hist %.3f mask %.3f | %s" % ((i + 1,) + rows[-1] + (eng.chain_stats(),)))
+        print("update %3d: wall %.2f ms | sweep %.3f chain %.3f hist %.3f mask %.3f (sweep: %.0f MB) | %s" % ((i + 1,) + rows[-1] + (eng.chain_stats(),)))
 r = np.array(rows)
 for lo in range(0, steps, 10):
     m = np.median(r[lo:lo + 10], axis=0)
-    print("updates %2d-%2d median: wall %.3f | sweep %.3f chain %.3f hist %.3f mask %.3f | rest %.3f" % ((lo + 1, lo + 10) + tuple(m) + (m[0] - m[1:].sum(),)))
+    print("updates %2d-%2d median: wall %.3f | sweep %.3f chain %.3f hist %.3f mask %.3f | rest %.3f | sweep %.0f MB = %.2f TB/s" % ((lo + 1, lo + 10) + tuple(m[:5]) + (m[0] - m[1:5].sum(), m[5], m[5] / m[1] / 1e3)))

@@ -1,7 +1,7 @@
 """Per-step wall time of lone updates, several loops in a row (is the first timed loop of bench.py representative?).
    gpurun -- python3 scripts/lone_steps.py [workload]"""
 import os, sys, tempfile, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bench
 if os.environ.get("WITH_TORCH"):
