@@ -738,9 +738,11 @@ def main():
     # ---- the timed region: K end-to-end decision updates on fresh batches, ONE AFTER THE OTHER (SURVEY §8d's t_update:
     # PAF text + read strings in host memory -> masks in host memory; nothing of batch i+1 is touched before update i has
     # returned — a live run's next batch does not exist yet, and in simulation it is the outcome of this update's masks)
+    # (the engine's HIP events are switched on BEFORE the warm-up: the first record of an event on a stream costs milliseconds —
+    # 8-16 ms seen on the first timed update when they were switched on behind it — and belongs to no update)
+    eng.enable_timing(True)          # HIP events on the engine's own streams, collected after the region
     for b in batches[:a.warmup]:
         R.step_e2e(b)
-    eng.enable_timing(True)          # HIP events on the engine's own streams, collected after the region
     base = eng.kernel_stats()
     sel = batches[a.warmup:]
     host_before = host_cpu_state()

@@ -19,7 +19,10 @@ for b in batches[:5]:
 eng.enable_timing(True)
 eng.synchronize()
 rows = []
+stats_from = int(os.environ.get("DRIFT_STATS_FROM", "-1"))      # the chain's own counters (BOSSX_SPEC_STATS, printed at exit) from this update on only
 for i, b in enumerate(batches[5:]):
+    if i == stats_from:
+        os.environ["BOSSX_SPEC_STATS"] = "1"
     t0 = time.perf_counter()
     R.step_e2e(b)
     dt = 1e3 * (time.perf_counter() - t0)
