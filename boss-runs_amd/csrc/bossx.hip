@@ -1015,7 +1015,7 @@ int grow_dev(bossx_engine *h, T **p, size_t *cap, size_t need, size_t slack) {
     if (need <= *cap) return BOSSX_OK;
     if (*p) HIPCHK(hipFree(*p));
     *p = nullptr; *cap = 0;
-    const size_t c = need * 9 / 8 + slack;
+    const size_t c = need * 5 / 4 + slack;      // (a quarter of headroom: a batch a little larger than every one before must not cost a hipFree — a device-wide wait — and a hipMalloc inside an update)
     int rc = dev_alloc(h, p, c);
     if (rc) return rc;
     *cap = c;
