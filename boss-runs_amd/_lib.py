@@ -123,6 +123,7 @@ PROTOTYPES = {
     "bossx_dist_collectives": (C.c_int64, [C.c_void_p]),
     "bossx_dist_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "bossx_chain_stats": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bossx_chain_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "bossx_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "bossx_host_free": (C.c_int, [C.c_void_p]),
     "bossx_set_overlap": (C.c_int, [C.c_void_p, C.c_int32]),

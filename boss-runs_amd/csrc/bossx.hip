@@ -2507,6 +2507,19 @@ int bossx_chain_stats(const bossx_engine *h, int64_t out[4]) {
     return BOSSX_OK;
 }
 
+int bossx_chain_counters(bossx_engine *h, int64_t out[8]) {
+    if (!h || !out) return BOSSX_E_INVALID;
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    if (!h->d_spec_stats) return BOSSX_OK;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    unsigned long long st[16];
+    HIPCHK(hipMemcpy(st, h->d_spec_stats, sizeof(st), hipMemcpyDeviceToHost));
+    out[0] = int64_t(st[0]); out[1] = int64_t(st[8]); out[2] = int64_t(st[1]); out[3] = int64_t(st[12]); out[4] = int64_t(st[13]); out[5] = int64_t(st[14]);
+    out[6] = int64_t(st[9]); out[7] = int64_t(st[10] + st[11]);
+    return BOSSX_OK;
+}
+
 int bossx_dist_chain(bossx_engine *h, const int32_t *windows, const double *mult) {
     if (!h || !h->finalized || !h->comm || !windows || !mult) return fail(h, BOSSX_E_INVALID, "bad dist_chain call (bossx_dist_init first)");
     HIPCHK(hipSetDevice(h->cfg.device));

@@ -441,6 +441,14 @@ class Engine:
         return dict(chunk_parallel_launches=int(out[0]), serial_launches_while_paused=int(out[1]),
                     chunks_added_plainly=int(out[2]), failed_checks=int(out[3]))
 
+    def chain_counters(self):
+        """Device-side counters of the chunk-parallel chain (include/bossx.h: bossx_chain_counters; BOSSX_SPEC_STATS must be set)."""
+        out = (C.c_int64 * 8)()
+        self._ck(self.lib.bossx_chain_counters(self.h, out))
+        keys = ("rows_built", "rows_left_standing", "rows_without_table", "strided_rows_built", "strided_rows_looked_up",
+                "strided_rows_undecided", "groups_stepped", "groups_walked")
+        return dict(zip(keys, (int(v) for v in out)))
+
     def update(self, bucket_threshold, windows=None, mult=None, tc=0.0, fhat_c=None, target_rs=0,
                want_stats=False, bits=False, fhat_model=None, dist=False, between=None):
         """bossx_update (`dist`: bossx_dist_update): one fused decision update.  Without `fhat_c` only the sweep and the

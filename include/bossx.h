@@ -349,6 +349,13 @@ int bossx_dist_allgather(bossx_engine *h, const void *send, void *recv_all, size
  *   out[2] chunks the stitch added the plain way               needed plain adds in the launch before: 8 launches pause)
  *   out[3] launches whose check failed (the serial kernel, enqueued behind and gated on the flag, then ran; 3: off) */
 int bossx_chain_stats(const bossx_engine *h, int64_t out[4]);
+/* The chunk-parallel chain's device-side counters (collected only while the environment holds BOSSX_SPEC_STATS: the kernels then
+ * count with atomics), since finalize: out[0] table rows built, [1] rows left standing (inputs unchanged), [2] rows without a table,
+ * [3] strided rows built (a chunk whose sum climbs more than four binades: 64 of its residues, csrc/kernels.hip.inc kStridedK),
+ * [4] strided rows the stitch looked up chunk by chunk, [5] ... of which the two enclosing candidates ended on different values
+ * (the chunk is then evaluated from the exact value), [6] groups stepped through their composed super-row, [7] groups walked chunk
+ * by chunk.  Diagnostics and tests; results never depend on them.                                                              */
+int bossx_chain_counters(bossx_engine *h, int64_t out[8]);
 /* Page-locked host memory for the caller's output buffers — the mask buffer of bossx_update above
  * all: a device-to-host copy into it is a direct DMA, into pageable memory it is staged (2.2 MB of
  * masks at 110 Mb: 0.1 ms less per update; registering pageable memory after the fact measured

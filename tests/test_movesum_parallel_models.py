@@ -104,6 +104,58 @@ def test_candidate_tables_predict_chunk_ends_exactly(w):
     assert wrong1 > chunks1 // 8, (chunks1, wrong1)
 
 
+def _predict_strided(a, w, L):
+    """Strided rows (csrc/kernels.hip.inc: kStridedK) in numpy: a chunk whose sum climbs more than four binades keeps 64 of its
+    4 * 2^rise residues, 2^(rise - 4) ulps apart; the exact start, reduced modulo 4 * 2^rise ulps, lies between two of them and
+    takes their common end — exact because the recurrence is monotone in its start.  Returns (#strided chunks, #decided, #wrong)."""
+    a = np.asarray(a, dtype=np.float64)
+    n = a.shape[0]
+    d = a.copy(); d[w:] = a[w:] - a[:-w]
+    true = move_sum_serial(a, w)
+    cs = np.concatenate([[0.0], np.cumsum(a)])
+    strided = decided = wrong = 0
+    for lo in range(L, n, L):
+        hi = min(n, lo + L)
+        start = true[lo - 1]
+        A = cs[lo] - cs[max(lo - w, 0)]
+        seg = cs[lo + 1:hi + 1] - cs[np.maximum(np.arange(lo + 1, hi + 1) - w, 0)]
+        top = max(float(np.max(np.abs(seg))), abs(A)) * (1 + 2.0 ** -20)
+        if not (A > 0 and np.isfinite(A)) or np.frexp(A)[1] != np.frexp(start)[1]:
+            continue
+        rise = int(np.frexp(top)[1] - np.frexp(A)[1])
+        if rise <= 4 or rise > 28:
+            continue
+        strided += 1
+        u = np.spacing(A)
+        Kfull, stride = 4 << rise, 1 << (rise - 4)
+        base = np.floor(A / (u * Kfull)) * (u * Kfull)
+        ends = base + np.arange(64) * (stride * u)
+        for j in range(lo, hi):
+            ends = ends + d[j]
+        assert np.all(np.diff(ends) >= 0)                         # monotone in the start, whatever the magnitudes
+        t = int(round((start - base) / u))
+        tm = t % Kfull
+        r, rem = tm // stride, tm % stride
+        if rem == 0 or (r < 63 and ends[r] == ends[r + 1]):
+            decided += 1
+            wrong += int(ends[r] + (t - tm) * u != true[hi - 1])
+    return strided, decided, wrong
+
+
+@pytest.mark.parametrize("w", [11, 39, 127])
+def test_strided_rows_decide_exactly_or_not_at_all(w):
+    """Bins of deep sites with one in ten holding a shallow one (a run from ~12x coverage on): nearly every chunk climbs 10-25 binades.
+    A decided strided row must give the sequential recurrence's value bit for bit; most rows must be decided (the 64 ends take a
+    handful of values: an exact start falls between two different ones a few times in a hundred)."""
+    rng = np.random.default_rng(77 + w)
+    n = 30 * 1024
+    a = rng.uniform(0.5e-9, 2e-9, n) * 10.0 ** np.cumsum(rng.normal(0, 0.01, n)).clip(-2, 2)
+    sp = rng.random(n) < 0.1
+    a[sp] = 10.0 ** rng.uniform(-5, -2, int(sp.sum()))
+    strided, decided, wrong = _predict_strided(a, w, 1024)
+    assert strided >= 10 and wrong == 0 and decided >= 0.75 * strided, (strided, decided, wrong)
+
+
 def _saturated_bins(rng, n):
     """Bin sums of a genome part of which is capped: ordinary bins (a gamma around 0.6) with long stretches of 100 x tiny
     (fully capped), stretches with deep sites only (1e-44 .. 1e-36), and a few bins with a handful of uncapped sites."""

@@ -1603,6 +1603,56 @@ def test_benefit_chain_equals_bottleneck(form, in_tmp, monkeypatch):
     eng.close()
 
 
+def test_strided_rows_spiky_bins_vs_oracle(in_tmp, monkeypatch):
+    """Strided rows (csrc/kernels.hip.inc: kStridedK).  Bin sums as a run holds them from ~12x coverage on — bins of deep sites (1e-9) with
+    one bin in ten holding a shallow site (1e-2 .. 1e-5): every window sum climbs 10-25 binades when such a bin enters and falls back when
+    it leaves — are imported into a contig of twenty chunks; the chunk-parallel chain must reproduce the oracle's sequential move_sum
+    (oracle/movesum.c; reference.py:215-269) bit for bit, WITHOUT a failed segment check, and do so through strided rows: built by the
+    candidates kernel, composed into the groups' super-rows, and — where the stitch looks one up chunk by chunk — mostly decided.  Three
+    arrays: spikes over a flat floor, over a floor that itself wanders over six decades, and spikes that come in runs."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.runs import BossRuns
+    from oracle.movesum import move_sum
+    monkeypatch.setenv("BOSSX_CHAIN_SPEC", "2")
+    monkeypatch.setenv("BOSSX_SPEC_STATS", "1")
+    n = 20 * 1024 + 300
+    contigs = synth.make_reference([(n - 1) * 100 + 37], seed=23, names=["spiky"])
+    args = BossConfig()
+    args.general.name = "strided"
+    runs = BossRuns(args)
+    runs.init(contigs=[(nm, synth.codes_to_str(c)) for nm, c in contigs])
+    eng = runs.engine
+    windows = np.array([4, 11, 27, 39, 49, 58, 68, 77, 89, 103, 127], dtype=np.int32)      # mu // 100 and the default approx_ccl // 100
+    mult = np.arange(0.05, 1, 0.1)[::-1]
+    for kind in range(3):
+        rng = np.random.default_rng(500 + kind)
+        a = rng.uniform(0.5e-9, 2e-9, n)
+        if kind == 1:
+            a *= 10.0 ** np.cumsum(rng.normal(0, 0.02, n)).clip(-3, 3)
+        spikes = rng.random(n) < 0.1
+        if kind == 2:
+            spikes = np.convolve(rng.random(n) < 0.03, np.ones(4), "same") > 0
+        a[spikes] = 10.0 ** rng.uniform(-5, -2, int(spikes.sum()))
+        a = np.ascontiguousarray(a)
+        eng.import_state(0, "scores_ds", a.reshape(-1, 1))
+        eng.benefit(windows, mult)
+        got = eng.export(0, "benefit")[:, :, 0]
+        smu = np.stack([move_sum(a[::-1], 4)[::-1], move_sum(a, 4)], axis=1)
+        tmp = np.zeros((n, 2))
+        for i in range(10):
+            tmp[:, 0] += move_sum(a[::-1], int(windows[1 + i]))[::-1] * mult[i]
+            tmp[:, 1] += move_sum(a, int(windows[1 + i])) * mult[i]
+        want = tmp - smu
+        want[want < 0] = 0
+        assert np.array_equal(got, want), kind
+    st, cn = eng.chain_stats(), eng.chain_counters()
+    assert st["chunk_parallel_launches"] == 3 and st["failed_checks"] == 0, st
+    assert cn["strided_rows_built"] > 100 and cn["groups_stepped"] > 0, cn
+    assert cn["strided_rows_undecided"] <= cn["strided_rows_looked_up"], cn
+    eng.close()
+
+
 @pytest.mark.parametrize("nb", [1, 2])
 def test_derived_entropy_crossings_vs_oracle(nb, in_tmp):
     """Derived entropy (one-barcode engine, kernels.hip.inc: ent_save_site): the engine writes no entropy at a lookup — a looked-up,
