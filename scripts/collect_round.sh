@@ -15,6 +15,7 @@ if [ "$what" = copy ]; then
   cp gpurun_out/tier/gpu_tier_summary.txt profiles/${R}_gpu_tier.txt 2>/dev/null
   cp gpurun_out/extras/rw_pattern.txt profiles/${R}_rw_pattern.txt 2>/dev/null
   cp gpurun_out/extras/regimes.txt profiles/${R}_regimes.txt 2>/dev/null
+  cp gpurun_out/extras/drift.txt profiles/${R}_drift.txt 2>/dev/null
   cp gpurun_out/grch38/trace/grch38_kernel_stats.csv profiles/${R}_grch38_1gpu_kernel_stats.csv 2>/dev/null
   ls -la profiles/${R}_*
   exit 0
@@ -45,5 +46,6 @@ if [ "$what" = extras ] || [ "$what" = all ]; then
   [ -x scripts/rw_pattern.bin ] && scripts/rw_pattern.bin > gpurun_out/extras/rw_pattern.txt 2>&1
   ( for d in 8 28; do bash scripts/regime_trace.sh $d; done; bash scripts/trace_timeline.sh | tail -28 ) > gpurun_out/extras/regimes.txt 2>&1
   bash scripts/grch38_trace.sh > gpurun_out/extras/grch38_trace.txt 2>&1
+  ( python3 scripts/drift_steps.py chr20_21 60 2>&1 | tail -12; bash scripts/drift_trace.sh 2>&1 | tail -24 ) > gpurun_out/extras/drift.txt 2>&1      # lone updates as coverage accumulates
   tail -3 gpurun_out/extras/rw_pattern.txt
 fi
