@@ -389,7 +389,8 @@ class Runner:
 
 def timed(fn_barrier, steps_fn):
     import gc
-    gc.collect()
+    # (no gc.collect() here: what it frees goes back to the allocator, trimmed heaps back to the OS, and the first update after it pays
+    # the page faults of its ~20 MB of parse buffers again — 9 ms seen on the first timed update; the collection is done before the warm-up)
     gc.disable()                 # no collector pause inside the timed region
     fn_barrier()
     t0 = time.perf_counter()
@@ -741,8 +742,12 @@ def main():
     # (the engine's HIP events are switched on BEFORE the warm-up: the first record of an event on a stream costs milliseconds —
     # 8-16 ms seen on the first timed update when they were switched on behind it — and belongs to no update)
     eng.enable_timing(True)          # HIP events on the engine's own streams, collected after the region
+    import gc
+    gc.collect()
+    barrier()                        # (torch's first synchronize initialises its context: before the warm-up, not between it and the timed region)
     for b in batches[:a.warmup]:
         R.step_e2e(b)
+    barrier()
     base = eng.kernel_stats()
     sel = batches[a.warmup:]
     host_before = host_cpu_state()

@@ -1013,6 +1013,7 @@ bool pack_read(const char *p, size_t n, uint8_t *dst) {
 template <typename T>
 int grow_dev(bossx_engine *h, T **p, size_t *cap, size_t need, size_t slack) {
     if (need <= *cap) return BOSSX_OK;
+    if (getenv("BOSSX_STAGE_TIMING")) fprintf(stderr, "[bossx] grow_dev: %zu -> %zu elements of %zu bytes\n", *cap, need, sizeof(T));
     if (*p) HIPCHK(hipFree(*p));
     *p = nullptr; *cap = 0;
     const size_t c = need * 5 / 4 + slack;      // (a quarter of headroom: a batch a little larger than every one before must not cost a hipFree — a device-wide wait — and a hipMalloc inside an update)
@@ -1025,6 +1026,7 @@ int grow_dev(bossx_engine *h, T **p, size_t *cap, size_t need, size_t slack) {
 template <typename T>
 int grow_pin(bossx_engine *h, T **p, size_t *cap, size_t need) {
     if (need <= *cap) return BOSSX_OK;
+    if (getenv("BOSSX_STAGE_TIMING")) fprintf(stderr, "[bossx] grow_pin: %zu -> %zu elements of %zu bytes\n", *cap, need, sizeof(T));
     if (*p) HIPCHK(hipHostFree(*p));
     *p = nullptr; *cap = 0;
     const size_t c = need * 5 / 4 + 4096;
@@ -1273,7 +1275,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
             if (!n_plans) return;
             auto go = [&]() -> int {
                 int rc2;
-                while (txt_done.load(std::memory_order_acquire) < n_c) _mm_pause();     // the text slices have been handed to the DMA engine
+                for (int sp = 0; txt_done.load(std::memory_order_acquire) < n_c; ++sp) { if (sp < 2000) _mm_pause(); else std::this_thread::yield(); }     // the text slices have been handed to the DMA engine (spin, then yield: see WorkPool::start)
                 if (up_fail.load()) return fail(h, BOSSX_E_HIP, "upload of the PAF text failed");
                 HIPCHK(hipEventRecord(h->ev_txt, h->stream_txt));
                 HIPCHK(hipStreamWaitEvent(h->stream_stage, h->ev_txt, 0));

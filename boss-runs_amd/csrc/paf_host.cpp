@@ -590,7 +590,9 @@ class WorkPool {
         gen_a_.fetch_add(1, std::memory_order_release);
         cv_.notify_all();
         work(*job, /*first_only=*/job->n_first < n);
-        while (job->pending_first.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
+        // (spin briefly, then yield: the task waited for may sit on a worker that is runnable but has no CPU — other processes share the
+        // host — and a caller that keeps spinning on its own CPU waits a scheduler time slice for it: 7-9 ms stalls of a 1.6-ms update)
+        for (int s = 0; job->pending_first.load(std::memory_order_acquire) > 0; ++s) { if (s < 2000) __builtin_ia32_pause(); else std::this_thread::yield(); }
         return job;
     }
     static void wait_all(Job &job) {
@@ -758,7 +760,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
     };
     // (the index is built by a worker NEXT TO the grouping below, which needs it only for a record
     // whose read is neither the previous record's nor the next one of the batch)
-    auto wait_index = [&]() { while (!index_ready.load(std::memory_order_acquire)) __builtin_ia32_pause(); };
+    auto wait_index = [&]() { for (int s = 0; !index_ready.load(std::memory_order_acquire); ++s) { if (s < 2000) __builtin_ia32_pause(); else std::this_thread::yield(); } };
 
     // ---- pass 1 (threads over line ranges): lines -> filtered records, in line order; then the
     // best record per query name, groups in first-appearance order --------------------------
