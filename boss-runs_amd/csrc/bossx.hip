@@ -1208,8 +1208,14 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
         if (dev_set != dev) { if (hipSetDevice(dev) != hipSuccess) up_fail.store(1); dev_set = dev; }
         if (t < n_c) {
             const size_t lo = in.paf_len * size_t(t) / size_t(n_c), hi = in.paf_len * size_t(t + 1) / size_t(n_c);
+            const auto c0_ = std::chrono::steady_clock::now();
             memcpy(h->h_paf_pin + lo, in.paf + lo, hi - lo);
+            const auto c1_ = std::chrono::steady_clock::now();
             if (hi > lo && hipMemcpyAsync(h->d_paf + lo, h->h_paf_pin + lo, hi - lo, hipMemcpyHostToDevice, h->stream_txt) != hipSuccess) up_fail.store(1);
+            if (timing) {
+                const double a_ = std::chrono::duration<double, std::milli>(c1_ - c0_).count(), b_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c1_).count();
+                if (a_ + b_ > 2.0) fprintf(stderr, "[bossx] text slice %d: memcpy %.2f ms, hipMemcpyAsync %.2f ms\n", t, a_, b_);
+            }
             txt_done.fetch_add(1, std::memory_order_release);
         } else {                  // reads [b, e) of a byte-balanced slice: gather (if still scattered) and look at the bases
             const int g = t - n_c;
@@ -1275,10 +1281,18 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
             if (!n_plans) return;
             auto go = [&]() -> int {
                 int rc2;
+                const auto g0_ = std::chrono::steady_clock::now();
+                auto lap = [&](const char *what) {      // (BOSSX_STAGE_TIMING: which step of a slow walk launch took the time)
+                    if (!timing) return;
+                    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g0_).count();
+                    if (ms > 2.0) fprintf(stderr, "[bossx] walk launch: %.2f ms in, behind %s\n", ms, what);
+                };
                 for (int sp = 0; txt_done.load(std::memory_order_acquire) < n_c; ++sp) { if (sp < 2000) _mm_pause(); else std::this_thread::yield(); }     // the text slices have been handed to the DMA engine (spin, then yield: see WorkPool::start)
+                lap("the wait for the text slices");
                 if (up_fail.load()) return fail(h, BOSSX_E_HIP, "upload of the PAF text failed");
                 HIPCHK(hipEventRecord(h->ev_txt, h->stream_txt));
                 HIPCHK(hipStreamWaitEvent(h->stream_stage, h->ev_txt, 0));
+                lap("event record + stream wait");
                 if ((rc2 = grow_dev(h, &st.d_ops, &st.ops_cap, pbe.ops_cap, 1024))) return rc2;
                 if ((rc2 = grow_dev(h, &st.d_segs, &st.segs_cap, pbe.segs_cap, 64))) return rc2;
                 if ((rc2 = grow_dev(h, &st.d_tilerefs, &st.tilerefs_cap, size_t(n_groups), 64))) return rc2;
@@ -1289,11 +1303,13 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                 if ((rc2 = grow_dev(h, &h->d_walk, &h->d_walk_cap, n_walk, 64))) return rc2;
                 plan_bytes = size_t(n_plans) * sizeof(MapPlan); group_bytes = size_t(n_groups) * sizeof(TileRef);
                 if ((rc2 = grow_pin(h, &h->h_plan_pin, &h->plan_pin_cap, plan_bytes + group_bytes + size_t(n_plans) * 4 + 64))) return rc2;
+                lap("the buffer checks");
                 memcpy(h->h_plan_pin, pbe.plans.data(), plan_bytes);
                 memcpy(h->h_plan_pin + plan_bytes, pbe.tiles.data(), group_bytes);
                 HIPCHK(hipMemcpyAsync(h->d_plans, h->h_plan_pin, plan_bytes, hipMemcpyHostToDevice, h->stream_stage));
                 HIPCHK(hipMemcpyAsync(st.d_tilerefs, h->h_plan_pin + plan_bytes, group_bytes, hipMemcpyHostToDevice, h->stream_stage));
                 HIPCHK(hipMemsetAsync(h->d_walk, 0, n_walk * sizeof(uint32_t), h->stream_stage));
+                lap("the plan copies + memset");
                 W.plans = h->d_plans; W.n_plans = n_plans; W.paf = h->d_paf; W.blob = st.d_blob;
                 W.n_runs = h->d_walk; W.walk_err = W.n_runs + n_plans; W.ops_off = W.walk_err + n_plans;
                 W.group_count = W.ops_off + n_plans + 1; W.group_cursor = W.group_count + n_groups;
@@ -1307,6 +1323,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                 HIPCHK(hipGetLastError());
                 back = reinterpret_cast<uint32_t *>(h->h_plan_pin + plan_bytes + group_bytes);
                 HIPCHK(hipMemcpyAsync(back, W.totals, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream_stage));
+                lap("the three launches + the copy back");
                 return BOSSX_OK;
             };
             early_rc = go();
