@@ -1306,10 +1306,13 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                 lap("the buffer checks");
                 memcpy(h->h_plan_pin, pbe.plans.data(), plan_bytes);
                 memcpy(h->h_plan_pin + plan_bytes, pbe.tiles.data(), group_bytes);
+                lap("the copies into the page-locked plan buffer");
                 HIPCHK(hipMemcpyAsync(h->d_plans, h->h_plan_pin, plan_bytes, hipMemcpyHostToDevice, h->stream_stage));
+                lap("the plans' hipMemcpyAsync");
                 HIPCHK(hipMemcpyAsync(st.d_tilerefs, h->h_plan_pin + plan_bytes, group_bytes, hipMemcpyHostToDevice, h->stream_stage));
+                lap("the groups' hipMemcpyAsync");
                 HIPCHK(hipMemsetAsync(h->d_walk, 0, n_walk * sizeof(uint32_t), h->stream_stage));
-                lap("the plan copies + memset");
+                lap("the hipMemsetAsync");
                 W.plans = h->d_plans; W.n_plans = n_plans; W.paf = h->d_paf; W.blob = st.d_blob;
                 W.n_runs = h->d_walk; W.walk_err = W.n_runs + n_plans; W.ops_off = W.walk_err + n_plans;
                 W.group_count = W.ops_off + n_plans + 1; W.group_cursor = W.group_count + n_groups;

@@ -33,3 +33,22 @@ ts = []
 for i in range(25):
     t0 = time.perf_counter(); R.step_e2e(batches[i]); ts.append(1e3 * (time.perf_counter() - t0))
 print("updates behind a synchronize + kernel_stats:", " ".join("%.1f" % t for t in ts))
+
+if os.environ.get("WITH_TORCH"):
+    for rep in range(3):
+        torch.cuda.synchronize(); eng.synchronize()
+        ts = []
+        eng.select_batch(5)
+        for i in range(3):
+            t0 = time.perf_counter(); eng.stage_batch(batches[i]["paf"], batches[i]["seqs"]); ts.append(1e3 * (time.perf_counter() - t0))
+        eng.select_batch(0)
+        for i in range(4):
+            t0 = time.perf_counter(); R.step_e2e(batches[i]); ts.append(1e3 * (time.perf_counter() - t0))
+        print("behind torch.cuda.synchronize(): three stage-only calls, then four updates:", " ".join("%.1f" % t for t in ts))
+    for rep in range(3):
+        torch.cuda.synchronize(); eng.synchronize()
+        time.sleep(0.05)
+        ts = []
+        for i in range(4):
+            t0 = time.perf_counter(); R.step_e2e(batches[i]); ts.append(1e3 * (time.perf_counter() - t0))
+        print("behind torch.cuda.synchronize() + 50 ms: four updates:", " ".join("%.1f" % t for t in ts))
