@@ -22,6 +22,7 @@ batches already parsed and resident in HBM are reported beside it as `kernels_on
 import argparse
 import json
 import os
+os.environ.setdefault("GPU_FORCE_BLIT_COPY_SIZE", "1024")      # copies below 1 MB as shader kernels: see boss-runs_amd/_lib.py load(), DESIGN §6 (before anything initialises HIP)
 import sys
 import tempfile
 import time

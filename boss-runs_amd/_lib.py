@@ -162,6 +162,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # The staging's ~24 uploads per batch (0.7-1.5 MB each) go out as shader copies instead of through the copy engine: a
+    # copy-engine submission now and then does not return for 7-9 ms — a 1.7-ms update then takes 9.  The HIP
+    # runtime reads the setting when it initialises: it has an effect only if nothing in the process has touched HIP yet
+    # (import this package before torch touches the GPU, or export the variable), and an explicit setting wins.
+    os.environ.setdefault("GPU_FORCE_BLIT_COPY_SIZE", "1024")
     if not os.path.exists(LIB_PATH) and os.path.exists("/opt/rocm/bin/hipcc") and not os.environ.get("BOSSX_NO_AUTOBUILD"):
         # a clean checkout: build the HIP extension in-tree (same as __graft_entry__.build())
         import subprocess
