@@ -1954,9 +1954,16 @@ void launch_chain(bossx_engine *h, const ChainParams &P0, size_t lds, hipStream_
         hipLaunchKernelGGL(chain_stitch_kernel, dim3(uint32_t(h->filt.size() * size_t(h->nb) * 2 * BOSSX_NWIN)), dim3(64), 0, stream, Q);
         if (getenv("BOSSX_SPEC_SELFTEST") && h->spec_total > h->spec_seg_chunks)      // (the first contig needs a second segment)
             hipLaunchKernelGGL(chain_spoil_kernel, dim3(1), dim3(1), 0, stream, h->d_spec_starts, int64_t(h->spec_seg_chunks));
-        grant_lds(h, reinterpret_cast<const void *>(benefit_chain_kernel<true, false, 256, true>), lds);
-        hipLaunchKernelGGL((benefit_chain_kernel<true, false, 256, true>), dim3(uint32_t(h->spec_max_segs), uint32_t(h->filt.size() * size_t(h->nb) * 2)),
-                           dim3(kChainThreads), lds, stream, P);
+        // the segments: the barrier-free pipeline where its LDS fits (round 5: 20-34 cycles per four bins against the barrier kernel's
+        // 47-58), the barrier kernel otherwise (BOSSX_SEG_BARRIER=1 / BOSSX_CHAIN_BARRIER=1: always)
+        const dim3 seg_grid(uint32_t(h->spec_max_segs), uint32_t(h->filt.size() * size_t(h->nb) * 2));
+        if (h->chain_flow && h->chain_flow_fits && !getenv("BOSSX_SEG_BARRIER")) {
+            grant_lds(h, reinterpret_cast<const void *>(benefit_chain_flow_kernel<false, 256, 4, 2, false, true>), lds);
+            hipLaunchKernelGGL((benefit_chain_flow_kernel<false, 256, 4, 2, false, true>), seg_grid, dim3(kChainThreads), lds, stream, P);
+        } else {
+            grant_lds(h, reinterpret_cast<const void *>(benefit_chain_kernel<true, false, 256, true>), lds);
+            hipLaunchKernelGGL((benefit_chain_kernel<true, false, 256, true>), seg_grid, dim3(kChainThreads), lds, stream, P);
+        }
         h->last_chain_spec = true;
         ++h->spec_launches;
         // ... and behind them the serial chain, which does nothing unless a segment failed its check
