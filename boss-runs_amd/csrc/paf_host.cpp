@@ -200,7 +200,7 @@ std::string normalise_name(std::string_view s) {
 }
 
 struct Group {
-    Rec best;
+    Rec *best;               // the record chosen so far: stays where its line task put it (moving 4000 records with their strings was a third of the grouping)
     int64_t key_q, key_dp;
     int32_t read = -1;       // index of the read in the batch (-1: the name is not in the batch)
     int32_t n_recs = 1;      // kept records of this read
@@ -866,9 +866,9 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
                     }
                     const int key_err = r.key_err;
                     if (*slot < 0) {
-                        groups.push_back(Group{std::move(r), r.mapq, r.as, read, 1, key_err});
+                        groups.push_back(Group{&r, r.mapq, r.as, read, 1, key_err});
                         if (read >= 0) *slot = int32_t(groups.size() - 1);
-                        else group_of_unknown.emplace(std::string_view(groups.back().best.qname), int32_t(groups.size() - 1));
+                        else group_of_unknown.emplace(std::string_view(r.qname), int32_t(groups.size() - 1));     // (the key views the FIRST record's name: it stays in place)
                     } else {
                         Group &g = groups[size_t(*slot)];
                         ++g.n_recs;
@@ -876,9 +876,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
                         // argsort by (mapq, AS), last element wins; stable for ties (paf.py:716-721)
                         if (r.mapq > g.key_q || (r.mapq == g.key_q && r.as >= g.key_dp)) {
                             g.key_q = r.mapq; g.key_dp = r.as;
-                            std::string keep = std::move(g.best.qname);     // the map's key views this buffer
-                            g.best = std::move(r);
-                            g.best.qname = std::move(keep);
+                            g.best = &r;
                         }
                     }
                 }
@@ -904,7 +902,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
     size_t ops_at = 0;
     int32_t n_rec = 0;
     for (size_t gi = 0; gi < groups.size(); ++gi) {
-        const Rec &r = groups[gi].best;
+        const Rec &r = *groups[gi].best;
         auto pre_fail = [&](int code, std::string msg) { pre_err.group = int64_t(gi); pre_err.code = code; pre_err.msg = std::move(msg); };
         if (groups[gi].n_recs > 1 && groups[gi].key_err) {
             pre_fail(groups[gi].key_err, "read '" + r.qname + "': mapping quality / AS of one of its mappings is not an int64");   // choose_best_mapper, paf.py:716-718
