@@ -97,6 +97,10 @@ struct bossx_engine {
     unsigned long long *d_spec_stats = nullptr;
     unsigned long long *d_cand_probe = nullptr; size_t cand_probe_waves = 0;      // BOSSX_CAND_PROBE builds only
     unsigned long long *d_spec_hash = nullptr;     // [rows] input hash of every table row (0: never built)
+    unsigned long long *d_row_meta = nullptr;      // [rows] the stamp + window every table row is good for (chain_candidates_kernel's quick way out)
+    uint32_t *d_tile_stamp = nullptr;              // [n_tiles] stamp of the sweep launch that last wrote the tile's bin sums
+    uint32_t stamp_counter = 0;                    // stamps handed out to sweep launches so far
+    double sweep_tile_share = 1.0;                 // share of the tiles the last update's sweep rewrote
     int32_t nb = 1;
 
     // native multi-GPU driver (bossx_dist_init): RCCL communicator of this engine's device
@@ -313,6 +317,7 @@ SweepParams sweep_params(bossx_engine *h) {
     P.Gp = h->Gp; P.B = h->B; P.NBK = h->NBK; P.nb = h->nb;
     P.score0 = h->score0; P.tiny = std::numeric_limits<double>::min();
     P.tile_done = h->d_tile_done; P.epoch = h->epoch;
+    P.tile_stamp = h->d_tile_stamp; P.stamp = ++h->stamp_counter;      // (every set of sweep parameters its own stamp: monotonic is all that matters)
     P.publish = h->sweep_published ? 1 : 0;
     P.dense = 0; P.ingest_only = 0; P.ingest_first = 0; P.tile_base = 0;
     P.order = h->d_tile_order;
@@ -580,6 +585,8 @@ void bossx_destroy(bossx_engine *h) {
     if (h->d_sup_off) hipFree(h->d_sup_off);
     if (h->d_spec_stats) hipFree(h->d_spec_stats);
     if (h->d_spec_hash) hipFree(h->d_spec_hash);
+    if (h->d_row_meta) hipFree(h->d_row_meta);
+    if (h->d_tile_stamp) hipFree(h->d_tile_stamp);
     if (h->d_tile_contig) hipFree(h->d_tile_contig);
     void *ptrs[] = {h->d_state, h->d_touched, h->d_strat, h->d_bucket_on, h->d_entropy, h->d_ds,
                     h->d_benefit, h->d_lut_score, h->d_lut_ent, h->d_fhat, h->d_bucket_sums, h->d_drop_count,
@@ -798,7 +805,8 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
             hipMalloc(reinterpret_cast<void **>(&h->d_spec_starts), rows * sizeof(double) + 64) != hipSuccess) {
             (void)hipGetLastError();
             h->chain_spec = false;          // (the serial chain needs no scratch)
-        } else if ((rc = dev_alloc(h, &h->d_spec_stats, 96, true)) || (rc = dev_alloc(h, &h->d_spec_hash, rows + 8, true))) return rc;
+        } else if ((rc = dev_alloc(h, &h->d_spec_stats, 96, true)) || (rc = dev_alloc(h, &h->d_spec_hash, rows + 8, true)) ||
+                   (rc = dev_alloc(h, &h->d_row_meta, rows + 8, true)) || (rc = dev_alloc(h, &h->d_tile_stamp, size_t(h->n_tiles) + 8, true))) return rc;
         if (h->chain_spec && h->spec_seg_chunks <= kStitchBatch) {
             std::vector<int64_t> soff(off.size(), 0);
             for (size_t k = 0; k + 1 < off.size(); ++k) soff[k + 1] = soff[k] + (off[k + 1] - off[k] + h->spec_seg_chunks - 1) / h->spec_seg_chunks;
@@ -1678,6 +1686,14 @@ int launch_sweep(bossx_engine *h) {
     if (h->epoch == 0xffffffffu) h->epoch = 1;   // never the 'pending' value
     h->sweep_published = publish;                // tiles are published only if a chain will run next to this sweep
     SweepParams P = sweep_params(h);
+    // how much of the reference this update's sweep rewrites (tiles of the batch, whole contigs that are swept again): where it is a small
+    // part, the chain's candidates kernel looks at the tiles' stamps first (its quick way out); where most chunks change it would only
+    // pay a round trip in front of its loads
+    {
+        double tiles = full ? double(h->n_tiles) : double(h->pending_slot >= 0 ? h->slots[size_t(h->pending_slot)].pb.tiles.size() : 0);
+        if (!full) for (size_t k : resweep) tiles += double(h->contigs[size_t(h->filt[k])].n_tiles);
+        h->sweep_tile_share = h->n_tiles > 0 ? tiles / double(h->n_tiles) : 1.0;
+    }
     time_begin(h, BOSSX_K_SWEEP);
     double resweep_sites = 0, resweep_bins = 0;
     if (!full) {
@@ -1938,6 +1954,9 @@ void launch_chain(bossx_engine *h, const ChainParams &P0, size_t lds, hipStream_
         Q.stats = getenv("BOSSX_SPEC_STATS") ? h->d_spec_stats : nullptr;
         Q.probe = nullptr;
         Q.hash = getenv("BOSSX_SPEC_NO_SKIP") ? nullptr : h->d_spec_hash;
+        // (a chunk is ~51 tiles and a row looks one window back: with a tenth of the tiles rewritten hardly a row is left standing)
+        const bool stamps = !getenv("BOSSX_SPEC_NO_STAMPS") && (h->sweep_tile_share < 0.05 || getenv("BOSSX_SPEC_STAMPS"));
+        Q.row_meta = h->d_row_meta; Q.tile_stamp = stamps ? h->d_tile_stamp : nullptr; Q.stamp_now = h->stamp_counter;
         Q.strict = getenv("BOSSX_SPEC_STRICT") ? atoi(getenv("BOSSX_SPEC_STRICT")) : 0;
 #ifdef BOSSX_CAND_PROBE
         {
@@ -3027,6 +3046,12 @@ int bossx_import(bossx_engine *h, int32_t contig, int32_t which, const void *src
             for (int64_t b = 0; b < nb; ++b)
                 HIPCHK(hipMemcpy(h->d_ds + b * h->B + c.bin_off, static_cast<const double *>(src) + b * nbin, size_t(nbin) * 8,
                                  hipMemcpyHostToDevice));
+            // (bin sums written behind the sweep's back: every tile of the contig counts as rewritten — chain_candidates_kernel's stamps)
+            if (h->d_tile_stamp && !c.remote) {
+                ++h->stamp_counter;
+                std::vector<uint32_t> st(size_t(c.n_tiles), h->stamp_counter);
+                HIPCHK(hipMemcpy(h->d_tile_stamp + c.tile_off, st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            }
             break;
         }
         case 5: {
