@@ -1430,7 +1430,7 @@ def test_lookahead_staging_vs_oracle(in_tmp, nb, ploidy):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["default", "spoiled", "serial"])
+@pytest.mark.parametrize("mode", ["default", "spoiled", "serial", "stamps"])
 def test_chunk_parallel_chain_vs_oracle(in_tmp, monkeypatch, mode):
     """The benefit chain, chunk-parallel (chain_candidates_kernel -> chain_stitch_kernel -> segments, the default):
     contigs of several 4096-bin segments, a stack of reads that caps a stretch (bin sums 10^5 times smaller
@@ -1438,7 +1438,9 @@ def test_chunk_parallel_chain_vs_oracle(in_tmp, monkeypatch, mode):
     and a stretch without reads.  additional_benefit, thresholds and masks must equal the oracle's
     sequential move_sum bit for bit in every update.  `spoiled`: BOSSX_SPEC_SELFTEST flips the last bit
     of one stitched start value — the segment before it must notice and the serial kernel enqueued
-    behind must redo the launch, same results.  `serial`: BOSSX_CHAIN_SPEC=0."""
+    behind must redo the launch, same results.  `serial`: BOSSX_CHAIN_SPEC=0.  `stamps`: the candidates kernel's quick
+    way out forced on (BOSSX_SPEC_STAMPS=1; by default it is taken only where an update rewrites under 5 % of the tiles):
+    table rows over the stretch without reads must be left standing by their tiles' stamps alone — and nothing may change."""
     from boss_runs_amd import synth
     from boss_runs_amd.config import BossConfig
     from boss_runs_amd.runs import BossRuns
@@ -1447,6 +1449,10 @@ def test_chunk_parallel_chain_vs_oracle(in_tmp, monkeypatch, mode):
     monkeypatch.setenv("BOSSX_CHAIN_SPEC", "0" if mode == "serial" else "2")
     if mode == "spoiled":
         monkeypatch.setenv("BOSSX_SPEC_SELFTEST", "1")
+    if mode == "stamps":
+        monkeypatch.setenv("BOSSX_SPEC_STAMPS", "1")
+        monkeypatch.setenv("BOSSX_SPEC_STATS", "1")
+        monkeypatch.setenv("BOSSX_SPEC_NO_PAUSE", "1")     # (small contigs: the engine's estimate would hand the later updates to the serial kernel)
     lens = [1_350_000, 620_000]
     names = ["cp0", "cp1"]
     contigs = synth.make_reference(lens, seed=91, names=names)
@@ -1459,10 +1465,15 @@ def test_chunk_parallel_chain_vs_oracle(in_tmp, monkeypatch, mode):
     o = OracleRuns(strs, ploidy=1, nbarcodes=1, bucket_threshold=0)
     rng = np.random.default_rng(5)
     for b in range(4):
-        batch = synth.make_batch(contigs, 2500, seed=9100 + b, mean_len=5000.0, nbarcodes=1)
-        batch = _drop_mappings_into(batch, "cp0", 700_000, 790_000)
-        spans = [(int(s), int(s) + 30_000) for s in rng.integers(200_000, 230_000, size=12)]
-        paf2, seqs2 = _exact_reads(contigs, "cp0", spans, "stack%d" % b)
+        batch = synth.make_batch(contigs, 300 if mode == "stamps" else 2500, seed=9100 + b, mean_len=5000.0, nbarcodes=1)
+        # (`stamps`: shallow batches — no contig's dropout threshold moves, so nothing is swept again whole — and from the second one on
+        # no read at all in the long contig: every row over it must be left standing by the stamps)
+        if mode == "stamps" and b >= 1:
+            batch = _drop_mappings_into(batch, "cp0", 0, lens[0])
+        else:
+            batch = _drop_mappings_into(batch, "cp0", 700_000, 790_000)
+        spans = [] if (mode == "stamps" and b >= 1) else [(int(s), int(s) + 30_000) for s in rng.integers(200_000, 230_000, size=12)]
+        paf2, seqs2 = _exact_reads(contigs, "cp0", spans, "stack%d" % b) if spans else ("", {})
         paf = batch["paf"].rstrip("\n") + "\n" + paf2
         seqs = dict(batch["seqs"]); seqs.update(seqs2)
         rl = dict(batch["read_lengths"])
@@ -1479,10 +1490,13 @@ def test_chunk_parallel_chain_vs_oracle(in_tmp, monkeypatch, mode):
             assert np.array_equal(pc.strat, oc.strat), (b, n)
     assert o.threshold is not None
     cov = o.contigs["cp0"].coverage.sum(axis=1)[:, 0] if o.contigs["cp0"].coverage.ndim == 3 else o.contigs["cp0"].coverage.sum(axis=1)
-    assert cov[210_000:225_000].min() >= 30 and cov[720_000:780_000].max() == 0      # the capped and the empty stretch exist
+    assert (mode == "stamps" or cov[210_000:225_000].min() >= 30) and cov[720_000:780_000].max() == 0      # the capped and the empty stretch exist
     st = runs.engine.chain_stats()
-    if mode == "default":
+    if mode in ("default", "stamps"):
         assert st["chunk_parallel_launches"] > 0 and st["failed_checks"] == 0, st
+        if mode == "stamps":
+            cn = runs.engine.chain_counters()
+            assert cn["rows_left_standing"] > 0 and cn["rows_built"] > 0, (cn, st)
     elif mode == "spoiled":
         assert st["failed_checks"] >= 1, st              # ... and every result above was still the oracle's
     else:
