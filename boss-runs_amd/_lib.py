@@ -50,7 +50,7 @@ class UpdateParams(C.Structure):
 class UpdateResult(C.Structure):
     _fields_ = [("updated", C.c_int32), ("any_on", C.c_int32), ("strat_size", C.c_int32),
                 ("n_bins", C.c_int32), ("threshold", C.c_double), ("normaliser", C.c_double),
-                ("ubar0", C.c_double)]
+                ("ubar0", C.c_double), ("argmax_margin", C.c_double), ("thr_code", C.c_int32), ("reserved", C.c_int32)]
 
 
 # private binding helper (csrc/bossx_py.h): not part of the C-ABI
@@ -162,11 +162,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    # The staging's ~24 uploads per batch (0.7-1.5 MB each) go out as shader copies instead of through the copy engine: a
-    # copy-engine submission now and then does not return for 7-9 ms — a 1.7-ms update then takes 9.  The HIP
-    # runtime reads the setting when it initialises: it has an effect only if nothing in the process has touched HIP yet
-    # (import this package before torch touches the GPU, or export the variable), and an explicit setting wins.
-    os.environ.setdefault("GPU_FORCE_BLIT_COPY_SIZE", "1024")
+    # (Round 5 set GPU_FORCE_BLIT_COPY_SIZE for the whole process here, to keep the staging's uploads off the copy engine, whose
+    # submissions now and then block for 7-9 ms.  The engine now issues those copies as launches of its own — csrc/front_end.hip.inc:
+    # upload_kernel — and mirrors masks and results from the mask kernel: no runtime setting is touched, the host application's
+    # copies are its own business, and it no longer matters who initialised HIP first.  BOSSX_ENGINE_COPIES=1: hipMemcpyAsync again.)
     if not os.path.exists(LIB_PATH) and os.path.exists("/opt/rocm/bin/hipcc") and not os.environ.get("BOSSX_NO_AUTOBUILD"):
         # a clean checkout: build the HIP extension in-tree (same as __graft_entry__.build())
         import subprocess

@@ -52,6 +52,11 @@ class GpuConfig:
     # "npz": masks/boss.npz as the reference writes it; "bits": masks/boss.bits (masks.py, 8x
     # smaller, mapped by the consumer); "both"
     mask_format: str = "npz"
+    # The device picks the threshold bin from EXACT sums, the reference from 12-chunk float sums (sequences.py:609-636); both
+    # agree unless the argmax of cs_u / cs_t sits within rounding of a tie.  Below this relative margin between the best and
+    # the second-best ratio (bossx_update_result.argmax_margin) the update re-derives the threshold on the host in the
+    # reference's own summation order (runs.reference_order_threshold) and re-forms the masks with it.  0 disables.
+    tie_margin: float = 1e-9
 
 
 @dataclass

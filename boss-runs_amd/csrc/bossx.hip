@@ -98,9 +98,14 @@ struct bossx_engine {
     unsigned long long *d_cand_probe = nullptr; size_t cand_probe_waves = 0;      // BOSSX_CAND_PROBE builds only
     unsigned long long *d_spec_hash = nullptr;     // [rows] input hash of every table row (0: never built)
     unsigned long long *d_row_meta = nullptr;      // [rows] the stamp + window every table row is good for (chain_candidates_kernel's quick way out)
+    // RULE: EVERY writer of d_ds stamps the tiles whose bin sums it writes — the sweep kernels do (SweepParams::stamp,
+    // one new stamp per launch), anything else goes through stamp_contig_tiles() (bossx_import which = 3).  A writer that forgets
+    // leaves stale table rows standing; only the segment check would notice (a serial rerun per update: bossx_chain_stats'
+    // failed_checks, always collected).
     uint32_t *d_tile_stamp = nullptr;              // [n_tiles] stamp of the sweep launch that last wrote the tile's bin sums
     uint32_t stamp_counter = 0;                    // stamps handed out to sweep launches so far
     double sweep_tile_share = 1.0;                 // share of the tiles the last update's sweep rewrote
+    bool tile_share_fresh = false;                 // ... and no chain has been launched since that sweep (a chain without a sweep in front of it does not trust the share)
     int32_t nb = 1;
 
     // native multi-GPU driver (bossx_dist_init): RCCL communicator of this engine's device
@@ -124,6 +129,9 @@ struct bossx_engine {
     uint8_t *d_touched = nullptr, *d_strat = nullptr, *d_bucket_on = nullptr;
     uint8_t *d_strat_bits = nullptr;   // packed masks (allocated on first use)
     double *d_entropy = nullptr, *d_ds = nullptr, *d_benefit = nullptr;
+    void *d_convert = nullptr; size_t convert_cap = 0;     // scratch of bossx_export / _import (convert_field): bounded, persistent
+    uint8_t *d_bcode = nullptr; int64_t Bc = 0;      // [nb][2][Bc] exponent code per element of d_benefit (threshold_hist_kernel -> strategy_mask_kernel)
+    bool codes_valid = false;                        // d_bcode belongs to the benefits and the normaliser the device-side pick will see
     double *d_lut_score = nullptr, *d_lut_ent = nullptr, *d_fhat = nullptr;
     std::vector<char> raw_blob;       // byte-per-base copy of a batch's reads (BOSSX_HOST_WALK / BOSSX_CHECK_DEVICE_WALK only)
     unsigned long long *d_bucket_sums = nullptr, *d_stats = nullptr;
@@ -208,6 +216,7 @@ struct bossx_engine {
 namespace {
 
 constexpr size_t kStatWords = size_t(BOSSX_HIST_BINS) * 3 + 2;
+constexpr size_t kStatZero = kStatWords + 2;      // ... + the histogram's ticket counter (zeroed with the sums, never copied back)
 // page-locked blocks handed out by bossx_host_alloc: device-writable host memory (process-wide:
 // bossx_host_free has no engine)
 std::mutex g_host_mutex;
@@ -398,9 +407,18 @@ int convert_field(bossx_engine *h, const ContigInfo &c, int32_t which, void *hos
     const int64_t L = c.length, nb = h->nb;
     const int64_t rows = which == 0 ? nb * 5 : 1;                   // rows of the scratch per pass (entropy: one barcode at a time)
     const int64_t elem = which == 0 ? 2 : 8;
-    const int64_t chunk = std::min<int64_t>(L, std::max<int64_t>(int64_t(1) << 20, (int64_t(16) << 20) / rows));
-    void *tmp = nullptr;
-    HIPCHK(hipMalloc(&tmp, size_t(rows * chunk * elem)));
+    // a fixed BYTE budget, whatever the number of rows (a floor of 1 Mi sites per pass made the scratch of a 96-barcode
+    // engine 480 x 1 Mi x 2 B = 1 GB per call); ONE buffer kept on the engine, not a hipMalloc / hipFree per call
+    constexpr int64_t kBudget = int64_t(32) << 20;
+    const int64_t chunk = std::min<int64_t>(L, std::max<int64_t>(4096, kBudget / (rows * elem)));
+    const size_t need = size_t(rows * chunk * elem);
+    if (need > h->convert_cap) {
+        if (h->d_convert) (void)hipFree(h->d_convert);
+        h->d_convert = nullptr; h->convert_cap = 0;
+        HIPCHK(hipMalloc(&h->d_convert, need));
+        h->convert_cap = need;
+    }
+    void *tmp = h->d_convert;
     hipError_t err = hipSuccess;
     auto keep = [&](hipError_t e) { if (err == hipSuccess) err = e; };
     for (int64_t pass_b = 0; pass_b < (which == 0 ? 1 : nb) && err == hipSuccess; ++pass_b)
@@ -429,8 +447,16 @@ int convert_field(bossx_engine *h, const ContigInfo &c, int32_t which, void *hos
             if (!to_device) copy_rows(false);
             keep(hipStreamSynchronize(h->stream));      // the scratch is reused by the next pass; the host buffer is the caller's
         }
-    (void)hipFree(tmp);
     HIPCHK(err);
+    return BOSSX_OK;
+}
+
+// A writer of d_ds other than the sweep (see the rule at bossx_engine::d_tile_stamp): all tiles of the contig get a fresh stamp.
+int stamp_contig_tiles(bossx_engine *h, const ContigInfo &c) {
+    if (!h->d_tile_stamp || c.remote || c.n_tiles == 0) return BOSSX_OK;
+    ++h->stamp_counter;
+    std::vector<uint32_t> st(size_t(c.n_tiles), h->stamp_counter);
+    HIPCHK(hipMemcpy(h->d_tile_stamp + c.tile_off, st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     return BOSSX_OK;
 }
 
@@ -592,7 +618,7 @@ void bossx_destroy(bossx_engine *h) {
                     h->d_benefit, h->d_lut_score, h->d_lut_ent, h->d_fhat, h->d_bucket_sums, h->d_drop_count,
                     h->d_stats, h->d_tails /* base of the tails + result block */, h->d_tile_off, h->d_site_off, h->d_length, h->d_bin_off, h->d_row_off,
                     h->d_strat_off, h->d_bucket_off, h->d_drop_thr, h->d_local, h->d_limbs,
-                    h->d_strat_bits};
+                    h->d_strat_bits, h->d_bcode, h->d_convert};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &st : h->slots) { if (st.ev_ready) hipEventDestroy(st.ev_ready); if (st.ev_free) hipEventDestroy(st.ev_free); if (st.d_err) hipFree(st.d_err); if (st.d_ops) hipFree(st.d_ops); if (st.d_tiles) hipFree(st.d_tiles); if (st.d_blob) hipFree(st.d_blob); if (st.d_segs) hipFree(st.d_segs); if (st.d_tilerefs) hipFree(st.d_tilerefs); if (st.d_codes) hipFree(st.d_codes); if (st.d_pieces) hipFree(st.d_pieces); }
     if (h->d_tile_ref) hipFree(h->d_tile_ref);
@@ -703,6 +729,8 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
     }
     if ((rc = dev_alloc(h, &h->d_ds, size_t(nb * h->B), true))) return rc;
     if ((rc = dev_alloc(h, &h->d_benefit, size_t(nb * 2 * h->B), true))) return rc;
+    h->Bc = (h->B + 15) & ~int64_t(15);
+    if ((rc = dev_alloc(h, &h->d_bcode, size_t(nb * 2 * h->Bc) + 16, true))) return rc;
     if ((rc = dev_alloc(h, &h->d_strat, size_t(h->strat_bytes)))) return rc;
     HIPCHK(hipMemsetAsync(h->d_strat, 1, size_t(h->strat_bytes), h->stream));       // reference.py:118
     if ((rc = dev_alloc(h, &h->d_tile_done, size_t(h->n_tiles > 0 ? h->n_tiles : 1), true))) return rc;
@@ -1048,6 +1076,19 @@ int grow_pin(bossx_engine *h, T **p, size_t *cap, size_t need) {
 
 namespace {
 
+// Host (page-locked, device-mapped) -> device copy of the staging: the engine's own kernel (front_end.hip.inc: upload_kernel)
+// unless BOSSX_ENGINE_COPIES=1 asks for hipMemcpyAsync (the copy engine; what rounds 1-5 used).  Callable from the worker threads.
+hipError_t upload_async(void *dst, const void *src_pinned, size_t bytes, hipStream_t stream) {
+    static const bool engine_copies = getenv("BOSSX_ENGINE_COPIES") != nullptr;
+    if (bytes == 0) return hipSuccess;
+    if (engine_copies) return hipMemcpyAsync(dst, src_pinned, bytes, hipMemcpyHostToDevice, stream);
+    // enough waves to keep PCIe reads in flight (each thread holds four 16-byte loads), not more than the copy needs
+    const size_t vec = (bytes + 15) / 16;
+    const uint32_t blocks = uint32_t(std::min<size_t>(std::max<size_t>((vec + 1023) / 1024, 1), 256));
+    hipLaunchKernelGGL(upload_kernel, dim3(blocks), dim3(256), 0, stream, static_cast<uint8_t *>(dst), static_cast<const uint8_t *>(src_pinned), bytes);
+    return hipGetLastError();
+}
+
 const char *walk_message(uint32_t e) {
     if (e & kWalkBadCigar) return "no CIGAR operation, or a run of 10^9 bases or more";
     if (e & kWalkOutsideRead) return "CIGAR walks outside the read";
@@ -1219,7 +1260,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
             const auto c0_ = std::chrono::steady_clock::now();
             memcpy(h->h_paf_pin + lo, in.paf + lo, hi - lo);
             const auto c1_ = std::chrono::steady_clock::now();
-            if (hi > lo && hipMemcpyAsync(h->d_paf + lo, h->h_paf_pin + lo, hi - lo, hipMemcpyHostToDevice, h->stream_txt) != hipSuccess) up_fail.store(1);
+            if (hi > lo && upload_async(h->d_paf + lo, h->h_paf_pin + lo, hi - lo, h->stream_txt) != hipSuccess) up_fail.store(1);
             if (timing) {
                 const double a_ = std::chrono::duration<double, std::milli>(c1_ - c0_).count(), b_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c1_).count();
                 if (a_ + b_ > 2.0) fprintf(stderr, "[bossx] text slice %d: memcpy %.2f ms, hipMemcpyAsync %.2f ms\n", t, a_, b_);
@@ -1241,8 +1282,8 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
             }
             if (dirty) any_dirty.store(1, std::memory_order_relaxed);
             if (i1 > i0 && seq_off[i1] > seq_off[i0] &&
-                hipMemcpyAsync(st.d_blob + (seq_off[i0] >> 1), packed + (seq_off[i0] >> 1), size_t(seq_off[i1] - seq_off[i0]) >> 1, hipMemcpyHostToDevice,
-                               h->stream_ups[g % n_up]) != hipSuccess)
+                upload_async(st.d_blob + (seq_off[i0] >> 1), packed + (seq_off[i0] >> 1), size_t(seq_off[i1] - seq_off[i0]) >> 1,
+                             h->stream_ups[g % n_up]) != hipSuccess)
                 up_fail.store(1);
         }
     };
@@ -1315,10 +1356,10 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                 memcpy(h->h_plan_pin, pbe.plans.data(), plan_bytes);
                 memcpy(h->h_plan_pin + plan_bytes, pbe.tiles.data(), group_bytes);
                 lap("the copies into the page-locked plan buffer");
-                HIPCHK(hipMemcpyAsync(h->d_plans, h->h_plan_pin, plan_bytes, hipMemcpyHostToDevice, h->stream_stage));
-                lap("the plans' hipMemcpyAsync");
-                HIPCHK(hipMemcpyAsync(st.d_tilerefs, h->h_plan_pin + plan_bytes, group_bytes, hipMemcpyHostToDevice, h->stream_stage));
-                lap("the groups' hipMemcpyAsync");
+                HIPCHK(upload_async(h->d_plans, h->h_plan_pin, plan_bytes, h->stream_stage));
+                lap("the plans' upload");
+                HIPCHK(upload_async(st.d_tilerefs, h->h_plan_pin + plan_bytes, group_bytes, h->stream_stage));
+                lap("the groups' upload");
                 HIPCHK(hipMemsetAsync(h->d_walk, 0, n_walk * sizeof(uint32_t), h->stream_stage));
                 lap("the hipMemsetAsync");
                 W.plans = h->d_plans; W.n_plans = n_plans; W.paf = h->d_paf; W.blob = st.d_blob;
@@ -1355,7 +1396,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                 await_reads(); HIPCHK(up_err);
                 HIPCHK(hipStreamSynchronize(h->stream_stage));              // the first copy of the plans has left the staging buffer
                 memcpy(h->h_plan_pin, pb.plans.data(), plan_bytes);
-                HIPCHK(hipMemcpyAsync(h->d_plans, h->h_plan_pin, plan_bytes, hipMemcpyHostToDevice, h->stream_stage));
+                HIPCHK(upload_async(h->d_plans, h->h_plan_pin, plan_bytes, h->stream_stage));
                 hipLaunchKernelGGL(check_bases_kernel, dim3((n_plans + 3) / 4), dim3(256), 0, h->stream_stage, W);
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipMemcpyAsync(back, W.totals, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream_stage));
@@ -1693,6 +1734,7 @@ int launch_sweep(bossx_engine *h) {
         double tiles = full ? double(h->n_tiles) : double(h->pending_slot >= 0 ? h->slots[size_t(h->pending_slot)].pb.tiles.size() : 0);
         if (!full) for (size_t k : resweep) tiles += double(h->contigs[size_t(h->filt[k])].n_tiles);
         h->sweep_tile_share = h->n_tiles > 0 ? tiles / double(h->n_tiles) : 1.0;
+        h->tile_share_fresh = true;
     }
     time_begin(h, BOSSX_K_SWEEP);
     double resweep_sites = 0, resweep_bins = 0;
@@ -1939,13 +1981,19 @@ void launch_chain_flow(bossx_engine *h, int ce, dim3 grid, dim3 block, size_t ld
 }  // extern "C++"
 
 void launch_chain(bossx_engine *h, const ChainParams &P0, size_t lds, hipStream_t stream = nullptr) {
+    h->codes_valid = false;          // (the benefits change: the exponent codes of the last histogram pass no longer describe them)
+    // the share of rewritten tiles describes the sweep of THIS update: a chain launched without one (bossx_benefit twice, a rerun) takes
+    // the long way through the row hashes
+    if (!h->tile_share_fresh) h->sweep_tile_share = 1.0;
+    h->tile_share_fresh = false;
     if (!stream) stream = h->stream;
     ChainParams P = P0;
     P.rerun_bit = 0;
     time_begin(h, BOSSX_K_BENEFIT, stream);
     h->last_chain_spec = false;
     const bool live0 = P.tile_done != nullptr;
-    if (!live0 && h->chain_spec && h->spec_pause > 0) { --h->spec_pause; ++h->spec_paused_updates; }
+    if (!live0 && h->chain_spec && getenv("BOSSX_CHAIN_SERIAL_NOW")) { /* tests: this launch on the serial kernel, nothing counted */ }
+    else if (!live0 && h->chain_spec && h->spec_pause > 0) { --h->spec_pause; ++h->spec_paused_updates; }
     else if (!live0 && h->chain_spec && h->matrix_chain && h->chain_ch == 256 && h->spec_total > 0) {
         // chunk-parallel: candidate tables -> stitched start values -> every segment at once (kernels.hip.inc)
         SpecParams Q;
@@ -2139,33 +2187,41 @@ int build_fhat(bossx_engine *h, const FhatModel *up) {
     return BOSSX_OK;
 }
 
-int launch_hist(bossx_engine *h, const bossx_fhat_desc *fh, int gate, bool clear = true) {
+// `pick`: the fused single-GPU update — the kernel's last block also runs the threshold choice (and the mask pass may read the codes)
+int launch_hist(bossx_engine *h, const bossx_fhat_desc *fh, int gate, bool clear = true, const PickParams *pick = nullptr) {
     const int64_t target = h->n_sites_all / kWindow;
-    if (clear) HIPCHK(hipMemsetAsync(h->d_stats, 0, kStatWords * sizeof(unsigned long long), h->stream));
+    if (clear) HIPCHK(hipMemsetAsync(h->d_stats, 0, kStatZero * sizeof(unsigned long long), h->stream));
     HistParams P;
     P.benefit = h->d_benefit; P.fhat_c = h->d_fhat;
     P.counts = h->d_stats; P.fgrid = h->d_stats + BOSSX_HIST_BINS; P.ubar = h->d_stats + BOSSX_HIST_BINS * 3;
+    P.ticket = h->d_stats + kStatWords;
+    P.code = getenv("BOSSX_NO_CODES") ? nullptr : h->d_bcode; P.Bc = h->Bc;
     P.ct = table_of(h); P.B = h->B; P.target = target; P.dpad = target > h->B ? target - h->B : 0;
     P.target_rs = fh->target_rs; P.d2 = target - fh->target_rs;
     P.fexp = fh->n_windows * fh->rep; P.d1 = fh->target_rs - P.fexp;
     P.nb = h->nb; P.all_local = h->all_local ? 1 : 0; P.gate = gate; P.ctrl = h->d_ctrl;
     if (P.d2 < 0) P.d2 = 0;   // trimmed instead of padded: indices unchanged
     if (P.d1 < 0) P.d1 = 0;
-    P.run = target >= (int64_t(1) << 18) ? 16 : 2;
-    P.staged = (P.run == 16 && double(target) * h->nb * 16.0 > 128e6) ? 1 : 0;      // (both strands' benefits against half the 256-MB Infinity Cache)
-    if (const char *e = getenv("BOSSX_HIST_STAGED")) P.staged = atoi(e) != 0 && P.run == 16;
-    const int64_t span = int64_t(256) * P.run;
-    const int64_t blocks = std::min<int64_t>((target + span - 1) / span, 2048);
+    P.do_pick = pick ? 1 : 0;
+    P.pick = pick ? *pick : PickParams{};
+    // every block loops over spans of 2048 positions; no more blocks than stay resident with their 40 KB of LDS (the bins are
+    // zeroed and flushed once per block)
+    const int64_t spans = (target + kHistSpan - 1) / kHistSpan;
+    const int64_t per_row = std::max<int64_t>(1, 1024 / (int64_t(h->nb) * 2));
+    const int64_t blocks = std::min<int64_t>(spans, per_row);
     time_begin(h, BOSSX_K_HIST);
-    hipLaunchKernelGGL(threshold_hist_kernel, dim3(uint32_t(std::max<int64_t>(blocks, 1)), uint32_t(h->nb * 2)), dim3(256),
-                       P.staged ? size_t(256 * 16 + 256) * sizeof(double) : size_t(0), h->stream, P);
-    time_end(h, BOSSX_K_HIST, double(target) * h->nb * 2 * 8.0);
+    hipLaunchKernelGGL(threshold_hist_kernel, dim3(uint32_t(std::max<int64_t>(blocks, 1)), uint32_t(h->nb * 2)), dim3(256), 0, h->stream, P);
+    // algorithmic bytes: every element read once, one code byte written
+    time_end(h, BOSSX_K_HIST, double(target) * h->nb * 2 * (8.0 + (P.code ? 1.0 : 0.0)));
     HIPCHK(hipGetLastError());
+    h->codes_valid = P.code != nullptr;
     return BOSSX_OK;
 }
 
+// `use_codes`: the threshold in the control block was picked ON THE DEVICE from the histogram pass that also left d_bcode (the
+// kernel then compares one code byte per element instead of a double wherever Ctrl::thr_code allows)
 int launch_mask(bossx_engine *h, int gate, bool with_tails = false, const PickParams *pick = nullptr,
-                unsigned long long *host_result = nullptr, uint8_t *host_strat = nullptr) {
+                unsigned long long *host_result = nullptr, uint8_t *host_strat = nullptr, bool use_codes = false) {
     MaskParams P;
     P.do_pick = pick ? 1 : 0;
     if (pick) P.pick = *pick; else P.pick = PickParams{};
@@ -2173,13 +2229,15 @@ int launch_mask(bossx_engine *h, int gate, bool with_tails = false, const PickPa
     P.result_words = int32_t(h->result_bytes / 8);
     P.host_strat = host_strat;
     P.benefit = h->d_benefit; P.bucket_on = h->d_bucket_on; P.strat = h->d_strat; P.ct = table_of(h);
+    P.code = (use_codes && h->codes_valid && !pick) ? h->d_bcode : nullptr; P.Bc = h->Bc;
     P.B = h->B; P.NBK = h->NBK; P.rows = h->rows; P.nb = h->nb; P.gate = gate; P.ctrl = h->d_ctrl;
     P.tails = with_tails ? h->d_tails : nullptr; P.tail_k = int32_t(h->filt.size());
-    const int64_t blocks = std::min<int64_t>((h->rows + 255) / 256, pick ? 1024 : 4096);
+    const int64_t span = int64_t(256) * kMaskRun;
+    const int64_t blocks = std::min<int64_t>((h->rows + span - 1) / span, pick ? 1024 : 4096);
     time_begin(h, BOSSX_K_MASK);
     hipLaunchKernelGGL(strategy_mask_kernel, dim3(uint32_t(std::max<int64_t>(blocks, 1))), dim3(256), 0, h->stream, P);
-    // algorithmic bytes: both strands' benefit read once, one mask byte written per row*strand*barcode
-    time_end(h, BOSSX_K_MASK, double(h->rows) * h->nb * 2 * 9.0);
+    // algorithmic bytes: per row * strand * barcode one code byte (or one double) read, one mask byte written
+    time_end(h, BOSSX_K_MASK, double(h->rows) * h->nb * 2 * (P.code ? 2.0 : 9.0));
     HIPCHK(hipGetLastError());
     return BOSSX_OK;
 }
@@ -2228,7 +2286,7 @@ int bossx_fhat_add(bossx_engine *h, const int64_t *keys, int32_t n_keys) {
     HIPCHK(hipEventSynchronize(h->ev_rs_keys));
     memcpy(h->h_rs_keys_pin, keys, size_t(n_keys) * sizeof(int64_t));
     hipStream_t fs = h->stream_fhat ? h->stream_fhat : h->stream;
-    HIPCHK(hipMemcpyAsync(h->d_rs_keys, h->h_rs_keys_pin, size_t(n_keys) * sizeof(int64_t), hipMemcpyHostToDevice, fs));
+    HIPCHK(upload_async(h->d_rs_keys, h->h_rs_keys_pin, size_t(n_keys) * sizeof(int64_t), fs));
     hipLaunchKernelGGL(fhat_add_kernel, dim3(uint32_t((n_keys + 255) / 256)), dim3(256), 0, fs,
                        h->d_rs_counts, h->d_rs_keys, n_keys, h->rs_windows * 2);
     HIPCHK(hipGetLastError());
@@ -2407,7 +2465,7 @@ int dist_finish_impl(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, bo
         rc = launch_mask(h, 1, true, &PP);
         h->dist_pick_fused = false;
     } else {
-        rc = launch_mask(h, 1, true);
+        rc = launch_mask(h, 1, true, nullptr, nullptr, nullptr, /*use_codes=*/true);
     }
     if (rc) return rc;
     }
@@ -2435,6 +2493,7 @@ int dist_finish_impl(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, bo
     res->updated = hc->any_on; res->any_on = hc->any_on;
     res->strat_size = hc->strat_size; res->n_bins = hc->n_bins;
     res->threshold = hc->threshold; res->ubar0 = hc->ubar0;
+    res->argmax_margin = hc->argmax_margin; res->thr_code = hc->thr_code;
     memcpy(&res->normaliser, &hc->max_bits, sizeof(double));
     if (res->updated && (hc->err & 2)) {
         HIPCHK(hipMemsetAsync(&h->d_ctrl->err, 0, sizeof(int32_t), h->stream));
@@ -2700,7 +2759,7 @@ int bossx_update_benefit(bossx_engine *h, const int32_t *windows, const double *
     int rc = fill_chain_params(h, windows, mult, CP, lds);
     if (rc) return rc;
     CP.gate = 1;
-    CP.zero_stats = h->d_stats; CP.n_zero = int32_t(kStatWords);    // for the histogram of bossx_update
+    CP.zero_stats = h->d_stats; CP.n_zero = int32_t(kStatZero);    // for the histogram of bossx_update
     if (h->overlap_ok && h->sweep_published && h->sweep_in_flight) {
         // The strategy is switched on (the gate is known to be open) and this update's sweep is in
         // flight on the main stream: run the chain NEXT TO it on stream2.  The sweep hands tiles
@@ -2783,30 +2842,34 @@ int update_run(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_al
                 if (!h->max_bits_clear) HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream));
                 h->max_bits_clear = false;
                 CP.gate = 1;
-                CP.zero_stats = h->d_stats; CP.n_zero = int32_t(kStatWords);
+                CP.zero_stats = h->d_stats; CP.n_zero = int32_t(kStatZero);
                 launch_chain(h, CP, lds);
             } else if (h->chain_on_stream2) {
                 HIPCHK(hipStreamWaitEvent(h->stream, h->ev_chain, 0));     // the chain ran next to the sweep
             }
             h->chain_on_stream2 = false;
             // the chain kernel cleared the statistics; the mask kernel picks the threshold itself
-            if ((rc = launch_hist(h, &fh, 1, /*clear=*/false))) return rc;
+            // ... and its last block picks the threshold
             PickParams PP;
             PP.counts = h->d_stats; PP.fgrid = h->d_stats + BOSSX_HIST_BINS; PP.ubar = h->d_stats + BOSSX_HIST_BINS * 3;
             PP.limbs = nullptr; PP.ctrl = h->d_ctrl; PP.tc = up->tc; PP.gate = 1;
+            if ((rc = launch_hist(h, &fh, 1, /*clear=*/false, &PP))) return rc;
             // the mask kernel's block 0 writes the result block into the pinned buffer itself; the
             // sentinel tells whether it got that far (it returns early while nothing is switched on)
             *herr = kNoResult;
             // small references: the kernel mirrors its mask bytes into the caller's buffer when that is
             // device-writable (from bossx_host_alloc) and holds the byte form — no copy afterwards
             uint8_t *mirror = nullptr;
-            if (strat_all && !(up->flags & BOSSX_UPDATE_STRAT_BITS) && h->strat_bytes <= (int64_t(1) << 20)) {
+            // (round 6: up to 8 MB — the vector stores of the mask kernel post 2.2 MB of chr20+21 masks across PCIe in ~40 us,
+            // less than the copy engine's submission alone used to cost, and no copy-engine submission is left in a lone update)
+            static const int64_t mirror_max = getenv("BOSSX_MIRROR_MAX") ? atoll(getenv("BOSSX_MIRROR_MAX")) : (int64_t(8) << 20);
+            if (strat_all && !(up->flags & BOSSX_UPDATE_STRAT_BITS) && h->strat_bytes <= mirror_max) {
                 std::lock_guard<std::mutex> lock(g_host_mutex);
                 for (const auto &blk : g_host_blocks)
                     if (strat_all >= blk.first && strat_all + h->strat_bytes <= blk.first + blk.second) mirror = strat_all;
             }
             mirrored = mirror != nullptr;
-            if ((rc = launch_mask(h, 1, false, &PP, reinterpret_cast<unsigned long long *>(pin), mirror))) return rc;
+            if ((rc = launch_mask(h, 1, false, nullptr, reinterpret_cast<unsigned long long *>(pin), mirror, /*use_codes=*/true))) return rc;
         }
         HIPCHK(hipGetLastError());
         // results
@@ -2853,6 +2916,7 @@ int update_run(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_al
     res->any_on = hc->any_on;
     res->strat_size = hc->strat_size; res->n_bins = hc->n_bins;
     res->threshold = hc->threshold; res->ubar0 = hc->ubar0;
+    res->argmax_margin = hc->argmax_margin; res->thr_code = hc->thr_code;
     memcpy(&res->normaliser, &hc->max_bits, sizeof(double));
     if (res->updated && (hc->err & 2)) {
         HIPCHK(hipMemsetAsync(&h->d_ctrl->err, 0, sizeof(int32_t), h->stream));
@@ -3047,11 +3111,7 @@ int bossx_import(bossx_engine *h, int32_t contig, int32_t which, const void *src
                 HIPCHK(hipMemcpy(h->d_ds + b * h->B + c.bin_off, static_cast<const double *>(src) + b * nbin, size_t(nbin) * 8,
                                  hipMemcpyHostToDevice));
             // (bin sums written behind the sweep's back: every tile of the contig counts as rewritten — chain_candidates_kernel's stamps)
-            if (h->d_tile_stamp && !c.remote) {
-                ++h->stamp_counter;
-                std::vector<uint32_t> st(size_t(c.n_tiles), h->stamp_counter);
-                HIPCHK(hipMemcpy(h->d_tile_stamp + c.tile_off, st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-            }
+            if ((rc = stamp_contig_tiles(h, c))) return rc;
             break;
         }
         case 5: {

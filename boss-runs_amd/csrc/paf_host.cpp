@@ -1462,7 +1462,12 @@ extern "C" int64_t bossx_py_dict_pointers(void *dict, int64_t cap, void *dict_ne
         }
         long kl = 0, vl = 0;
         const char *kp = utf(const_cast<char *>(key_ptrs[i]), &kl), *vp = utf(const_cast<char *>(val_ptrs[i]), &vl);
-        if (!kp || !vp) return BOSSX_E_INVALID;                      // not a str (the interpreter has set its error indicator)
+        if (!kp || !vp) {
+            // not a str (the interpreter has set its error indicator).  The outputs held object pointers up to here and character
+            // pointers before: never hand a mixture back — everything is cleared, the contents mean nothing on an error
+            for (int64_t j = 0; j < n; ++j) { key_ptrs[j] = nullptr; val_ptrs[j] = nullptr; key_lens[j] = 0; val_lens[j] = 0; }
+            return BOSSX_E_INVALID;
+        }
         key_ptrs[i] = kp; key_lens[i] = kl; val_ptrs[i] = vp; val_lens[i] = vl;
     }
     return n;

@@ -370,7 +370,7 @@ class Engine:
         self._benefit_done = None
         return dict(updated=bool(res.updated), any_on=bool(res.any_on), threshold=res.threshold,
                     normaliser=res.normaliser, ubar0=res.ubar0, strat_size=res.strat_size,
-                    n_bins=res.n_bins, contig_on=on.astype(bool))
+                    n_bins=res.n_bins, argmax_margin=res.argmax_margin, thr_code=res.thr_code, contig_on=on.astype(bool))
 
     def set_overlap(self, on):
         """Allow / forbid the chain of update_benefit to run next to the sweep of update_begin."""
@@ -537,7 +537,7 @@ class Engine:
                 self._ck(self.lib.bossx_update_collect(*a))
         out = dict(updated=bool(res.updated), any_on=bool(res.any_on), threshold=res.threshold,
                    normaliser=res.normaliser, ubar0=res.ubar0, strat_size=res.strat_size,
-                   n_bins=res.n_bins, contig_on=on.astype(bool))
+                   n_bins=res.n_bins, argmax_margin=res.argmax_margin, thr_code=res.thr_code, contig_on=on.astype(bool))
         if want_stats:
             out.update(counts=counts, fgrid_fx=fg, ubar_fx=ub)
         if between_error is not None:

@@ -449,7 +449,7 @@ class DistributedBossRuns(BossRuns):
             raise AttributeError("'ReadlengthDist' object has no attribute 'time_cost'")
         self.threshold = res["threshold"]
         self.last_stats = dict(normaliser=res["normaliser"], ubar0=res["ubar0"],
-                               strat_size=res["strat_size"], n_bins=res["n_bins"])
+                               strat_size=res["strat_size"], n_bins=res["n_bins"], argmax_margin=res.get("argmax_margin"))
         for cont in self.local_filt.values():
             cont.strat = eng.strat_view(cont.index)
         if self.gather_masks and (self.comm.world > 1 or self.comm.force):
@@ -479,10 +479,12 @@ class DistributedBossRuns(BossRuns):
         else:
             res = eng.update(thr_b, dist=True, between=between)
         # An exception raised by `between` (staging the next batch while this update ran) was held back by Engine.update so that this
-        # update's results could be collected: it is re-raised on EVERY way out of this method, once they have been applied.
-        # KeyboardInterrupt / SystemExit included — they travelled through the same hand-off.
+        # update's results could be collected: it is re-raised once they have been applied (KeyboardInterrupt / SystemExit
+        # included — they travelled through the same hand-off).  If APPLYING the results fails, that failure is the primary one
+        # (ADVICE r5): it is raised with the held error as its cause instead of being replaced by it.
         held = res.get("between_error")
-        try:
+
+        def apply():
             for cont in self.local_filt.values():
                 if res["contig_on"][cont.index]:
                     cont.switched_on[:] = True
@@ -493,16 +495,21 @@ class DistributedBossRuns(BossRuns):
                 raise AttributeError("'ReadlengthDist' object has no attribute 'time_cost'")
             self.threshold = res["threshold"]
             self.last_stats = dict(normaliser=res["normaliser"], ubar0=res["ubar0"],
-                                   strat_size=res["strat_size"], n_bins=res["n_bins"])
+                                   strat_size=res["strat_size"], n_bins=res["n_bins"], argmax_margin=res.get("argmax_margin"))
             for cont in self.local_filt.values():
                 cont.strat = eng.strat_view(cont.index)
             if self.gather_masks and (self.comm.world > 1 or self.comm.force):
                 self._gather_masks()
             if self.write_masks and self.comm.rank == 0:
                 self._write_contig_strategies(contig_strats=self.ref.get_strategy_dict())
-        finally:
-            if held is not None:
-                raise held
+        try:
+            apply()
+        except BaseException as primary:
+            if held is not None and primary is not held:
+                raise primary from held
+            raise
+        if held is not None:
+            raise held
 
     n_updates = 0            # updates run since init (bench: collectives per update), whichever entry point ran them
 

@@ -58,6 +58,57 @@ def choose_threshold(normaliser, counts_all, fgrid_all, ubar0, time_cost):
     return float(threshold), size, uniq
 
 
+def _adjust_length(size, arr):
+    """boss/utils.py:206-226: pad with the array's own tail, or trim."""
+    d = size - arr.shape[0]
+    if d > 0:
+        return np.append(arr, arr[-d:], axis=0)
+    if d < 0:
+        return arr[:-abs(d)]
+    return arr
+
+
+def reference_order_threshold(benefit, fhat, time_cost):
+    """The threshold choice of Scoring.find_strat_thread (sequences.py:566-646) with the REFERENCE's
+    summation order — twelve np.array_split chunks, np.bincount per chunk, chunk results added in order,
+    np.sum(fhat * benefit) pairwise — on the merged, length-adjusted arrays `benefit`, `fhat`
+    [T*, 2, nb] (smu_adj := benefit, core.py:182-183).  Only used where the device's exact sums leave the
+    argmax within `tie_margin` of a tie (BossRuns._resolve_near_tie): there the float rounding of the
+    reference decides, and this reproduces it.  Returns (threshold, strat_size, margin)."""
+    window = 100
+    tbar0 = 300 // window + 300 // window + 400 // window
+    tc = time_cost // window
+    flat = benefit.flatten('F')
+    nzi = np.nonzero(flat)
+    nz = flat[nzi]
+    normaliser = np.max(nz)
+    exps = np.abs(np.frexp(nz / normaliser)[1])
+    e_chunks = np.array_split(exps, 12)
+    cnts = [np.bincount(c) for c in e_chunks]
+    bincounts = np.zeros(max(c.shape[0] for c in cnts), dtype='int')
+    for c in cnts:
+        bincounts[0:c.shape[0]] += c
+    uniq = np.nonzero(bincounts)[0]
+    counts = bincounts[uniq]
+    f_chunks = np.array_split(fhat.flatten('F')[nzi], 12)
+    fgs = [np.bincount(e, weights=f) for e, f in zip(e_chunks, f_chunks)]
+    f_grid = np.zeros(max(f.shape[0] for f in fgs), dtype='float')
+    for f in fgs:
+        f_grid[0:f.shape[0]] += f
+    f_grid = f_grid[uniq]
+    f_mean = f_grid / counts
+    benefit_bin = np.power(2.0, -uniq) * normaliser
+    ubar0 = np.sum(fhat * benefit)
+    cs_u = np.cumsum(benefit_bin * f_mean * counts) + ubar0
+    cs_t = np.cumsum(tc * counts * f_mean) + tbar0
+    peaks = cs_u / cs_t
+    size = int(np.argmax(peaks)) + 1
+    threshold = benefit_bin[size] if size < benefit_bin.shape[0] else benefit_bin[-1]
+    rest = np.delete(peaks, size - 1)
+    margin = float((peaks[size - 1] - rest.max()) / peaks[size - 1]) if rest.size and peaks[size - 1] > 0 else 1.0
+    return float(threshold), size, margin
+
+
 class Boss:
     """Slice of boss/core.py:13-176 the RUNS path depends on: run name, output directory tree,
     the global read-length distribution and the batch counter.  Live FASTQ discovery
@@ -155,6 +206,8 @@ class BossRuns(Boss):
         if self.mask_format not in ("npz", "bits", "both"):
             raise ValueError("gpu.mask_format must be 'npz', 'bits' or 'both'")
         self._fused = True             # False when update_wrapper is replaced by the staged form
+        self.tie_margin = float(getattr(a.gpu, "tie_margin", 1e-9))
+        self.ties_resolved = 0         # updates whose threshold was re-derived in the reference's summation order
         self.keep_stats = False        # also fetch the threshold statistics (tests)
         self.log_fractions = True
         self._publish_masks(bits=None)
@@ -341,14 +394,21 @@ class BossRuns(Boss):
             raise AttributeError("'ReadlengthDist' object has no attribute 'time_cost'")
         self.threshold = res["threshold"]
         self.last_stats = dict(normaliser=res["normaliser"], ubar0=res["ubar0"],
-                               strat_size=res["strat_size"], n_bins=res["n_bins"])
+                               strat_size=res["strat_size"], n_bins=res["n_bins"],
+                               argmax_margin=res.get("argmax_margin"), thr_code=res.get("thr_code"))
+        tie = res["updated"] and res.get("argmax_margin") is not None and res["argmax_margin"] < self.tie_margin
+        if tie:
+            self._resolve_near_tie()
+            use_bits = False           # (the masks were re-formed: take them from the device, as bytes)
         if self.keep_stats:
             counts = res["counts"]
             uniq = np.nonzero(counts)[0]
             self.last_stats.update(exponents=uniq, counts=counts[uniq],
                                    f_grid=np.array([fx_to_float(*res["fgrid_fx"][e]) for e in uniq]))
         for cname, cont in self.contigs_filt.items():
-            if use_bits:
+            if tie:
+                cont.strat = eng.get_strat(cont.index)
+            elif use_bits:
                 cont.strat = self._lazy_strat(cont)          # unpacked on first access
             else:
                 cont.strat = eng.strat_view(cont.index)
@@ -360,6 +420,28 @@ class BossRuns(Boss):
             self._publish_masks(bits=eng.strat_bits if use_bits else None)
         if res.get("between_error") is not None:
             raise res["between_error"]
+
+    def _resolve_near_tie(self):
+        """The device chose the threshold bin from exact sums and reports that the best and the second-best
+        cs_u / cs_t lie within `tie_margin` of each other: the reference's float sums (sequences.py:609-636)
+        may round the other way, and a flipped argmax halves or doubles the threshold.  Re-derive the choice
+        on the host in the reference's own summation order from the exported benefits and the expanded
+        read-start posterior; if it differs, re-form the masks with that threshold (double compare)."""
+        eng = self.engine
+        benefit = np.concatenate([eng.export(c.index, "benefit") for c in self.contigs_filt.values()])
+        target = self.ref.n_sites // 100
+        fhat_c, _ = self.read_starts.fhat_compact()
+        fhat = self.read_starts.expand(fhat_c, target)
+        fhat = np.repeat(fhat[:, :, np.newaxis], self.nbarcodes, axis=2)
+        threshold, size, margin = reference_order_threshold(_adjust_length(target, benefit), fhat, self.rl_dist.time_cost)
+        self.ties_resolved += 1
+        self.last_stats.update(tie_resolved=True, device_threshold=self.threshold, device_strat_size=self.last_stats["strat_size"],
+                               reference_order_margin=margin)
+        logging.info(f"argmax within {self.last_stats['argmax_margin']:.3g} of a tie: threshold re-derived in the reference's "
+                     f"summation order ({self.threshold} -> {threshold})")
+        self.threshold = threshold
+        self.last_stats["strat_size"] = size
+        eng.apply_threshold(threshold)       # (same rows, same bucket gate: overwrites what the device-picked threshold wrote)
 
     def _lazy_strat(self, cont):
         bits, off = self.engine.strat_bits, self.engine.strat_offset(cont.index)

@@ -269,6 +269,14 @@ typedef struct bossx_update_result {
     double  threshold;
     double  normaliser;
     double  ubar0;
+    /* (best - second best) / best of cs_u / cs_t at the argmax of sequences.py:636.  The engine's sums are exact, the reference's
+     * are 12-chunk float sums (sequences.py:609-629): the two agree to ~1e-16 relative, so a margin far above that means both
+     * choose the same bin, a margin near it that a flipped choice (threshold off by a factor of two) is possible.  1.0 when
+     * there is a single occupied bin.                                                                                       */
+    double  argmax_margin;
+    int32_t thr_code;           /* exponent bin u of the threshold 2^-u * normaliser when the masks were formed from the exponent
+                                 * codes (exact); -1 when they compared doubles (subnormal threshold, u > 254, host-picked)  */
+    int32_t reserved;
 } bossx_update_result;
 
 /* Optional first half of bossx_update: enqueue the sweep (with the pending batch's increments)

@@ -128,27 +128,42 @@ class OContig:
     def calc_smu(self, window=100, mu=400):
         """reference.py:215-237."""
         nbin = self.length // window + 1
-        self.smu = np.zeros((nbin, 2, self.nb))
         self.scores_ds = np.zeros((nbin, self.nb))
         for b in range(self.nb):
             np.add.at(self.scores_ds[:, b], np.arange(0, self.length) // window, self.scores[:, b])
-            self.smu[:, 0, b] = move_sum(self.scores_ds[::-1, b], mu // window)[::-1]
-            self.smu[:, 1, b] = move_sum(self.scores_ds[:, b], mu // window)
+        self.smu = smu_from_ds(self.scores_ds, window, mu)
 
     # -- a13 -----------------------------------------------------------------------------
     def calc_u(self, approx_ccl, window=100):
         """reference.py:241-269."""
-        ccl_ds = approx_ccl // window
-        mult = np.arange(0.05, 1, 0.1)[::-1]
-        nbin = self.scores_ds.shape[0]
-        self.expected_benefit = np.zeros((nbin, 2, self.nb))
-        for b in range(self.nb):
-            tmp = np.zeros((nbin, 2))
-            for i in range(10):
-                fwd = move_sum(self.scores_ds[::-1, b], int(ccl_ds[i]))[::-1]
-                rev = move_sum(self.scores_ds[:, b], int(ccl_ds[i]))
-                tmp[:, 0] += (fwd * mult[i])
-                tmp[:, 1] += (rev * mult[i])
-            self.expected_benefit[:, :, b] = tmp
-        self.additional_benefit = self.expected_benefit - self.smu
-        self.additional_benefit[self.additional_benefit < 0] = 0
+        self.expected_benefit, self.additional_benefit = benefit_from_ds(self.scores_ds, self.smu, approx_ccl, window)
+
+
+def smu_from_ds(scores_ds, window=100, mu=400):
+    """The move_sum half of Contig.calc_smu (reference.py:231-236) on the bin sums `scores_ds` [nbin, nb]: usable on its own
+    where only the bin sums of a contig are at hand (tests: a chromosome-length chain exported from the device)."""
+    nbin, nb = scores_ds.shape
+    smu = np.zeros((nbin, 2, nb))
+    for b in range(nb):
+        smu[:, 0, b] = move_sum(scores_ds[::-1, b], mu // window)[::-1]
+        smu[:, 1, b] = move_sum(scores_ds[:, b], mu // window)
+    return smu
+
+
+def benefit_from_ds(scores_ds, smu, approx_ccl, window=100):
+    """Contig.calc_u (reference.py:241-269) -> (expected_benefit, additional_benefit)."""
+    ccl_ds = approx_ccl // window
+    mult = np.arange(0.05, 1, 0.1)[::-1]
+    nbin, nb = scores_ds.shape
+    expected = np.zeros((nbin, 2, nb))
+    for b in range(nb):
+        tmp = np.zeros((nbin, 2))
+        for i in range(10):
+            fwd = move_sum(scores_ds[::-1, b], int(ccl_ds[i]))[::-1]
+            rev = move_sum(scores_ds[:, b], int(ccl_ds[i]))
+            tmp[:, 0] += (fwd * mult[i])
+            tmp[:, 1] += (rev * mult[i])
+        expected[:, :, b] = tmp
+    additional = expected - smu
+    additional[additional < 0] = 0
+    return expected, additional

@@ -49,8 +49,13 @@ def find_strategy(benefit, smu, fhat, time_cost, detail=None):
     except IndexError:
         threshold = benefit_bin[-1]
     if detail is not None:
+        # how far the argmax is from a tie (test infrastructure only: the reference does not compute it) — the product's
+        # exact sums and these 12-chunk float sums differ by ~1e-16 relative, so only a margin near that could flip the choice
+        peaks = cs_u / cs_t
+        rest = np.delete(peaks, size - 1)
+        margin = float((peaks[size - 1] - rest.max()) / peaks[size - 1]) if rest.size and peaks[size - 1] > 0 else 1.0
         detail.update(normaliser=normaliser, exponents=uniq, counts=counts, f_grid=f_grid,
-                      ubar0=ubar0, strat_size=size, threshold=threshold)
+                      ubar0=ubar0, strat_size=size, threshold=threshold, argmax_margin=margin)
     return np.where(benefit >= threshold, True, False), threshold
 
 

@@ -352,7 +352,7 @@ def test_grch38_geometry_one_gpu(in_tmp):
     from boss_runs_amd import synth
     from boss_runs_amd.config import BossConfig
     from boss_runs_amd.runs import BossRuns
-    from oracle.contig import OContig, adjust_length
+    from oracle.contig import OContig, adjust_length, benefit_from_ds, smu_from_ds
     from oracle.dists import OReadlengthDist, OReadStartDist
     from oracle.model import SiteModel, PatternCache
     from oracle.pafcigar import parse_paf, convert_records, best_mapper
@@ -410,6 +410,15 @@ def test_grch38_geometry_one_gpu(in_tmp):
             assert np.array_equal(pc.bucket_switches, oc.bucket_switches), (step, n)
             assert np.array_equal(pc.scores_ds, oc.scores_ds), (step, n)
             assert np.array_equal(pc.additional_benefit, oc.additional_benefit), (step, n)
+        # chromosome-length chains: chr1's 2.49 M bin sums (and chr2's, chrX's) as the device holds them
+        # through the oracle's move_sum arithmetic (oracle/movesum.c: Bottleneck's recurrence) -> additional_benefit, bit for
+        # bit: strided rows, composed groups and — from the second batch on — rows left standing by tile stamps, at GRCh38 scale
+        for n in ("chr1", "chr2", "chrX"):
+            pc = runs.contigs[n]
+            ds = pc.scores_ds
+            _, add = benefit_from_ds(ds, smu_from_ds(ds), o_rl.approx_ccl)
+            assert np.array_equal(pc.additional_benefit, add), (step, n)
+            del ds, add
         # strategy stage over all 27 contigs: the other blocks come from the device, whose
         # per-contig stages are the ones verified above (and at 111 Mb in test_chr20_21_full_size_vs_oracle)
         benefit = np.concatenate([runs.contigs[n].additional_benefit for n, _ in kept])

@@ -114,6 +114,92 @@ def test_choose_threshold_vs_oracle_find_strategy():
         assert t == thr and size == detail["strat_size"] and np.array_equal(uniq, detail["exponents"])
 
 
+def test_reference_order_threshold_vs_oracle_find_strategy():
+    """runs.reference_order_threshold (the host fallback of a near-tie) is find_strat_thread's own arithmetic."""
+    from oracle.strategy import find_strategy
+    from boss_runs_amd.runs import reference_order_threshold
+    rng = np.random.default_rng(4)
+    for trial in range(5):
+        T, nb = 3000, 1 + trial % 2
+        benefit = rng.gamma(0.3, 2.0, size=(T, 2, nb)) * np.power(2.0, -rng.integers(0, 40, (T, 2, nb))) * (rng.random((T, 2, nb)) > 0.2)
+        fhat = rng.random((T, 2))
+        fhat /= fhat.sum()
+        fh3 = np.repeat(fhat[:, :, None], nb, axis=2)
+        d = {}
+        _, thr = find_strategy(benefit, benefit, fh3, 4100.0, detail=d)
+        t, size, margin = reference_order_threshold(benefit, fh3, 4100.0)
+        assert t == thr and size == d["strat_size"] and margin == d["argmax_margin"]
+
+
+def test_near_tie_exact_sums_and_reference_order_can_disagree_and_the_fallback_follows_the_reference():
+    """VERDICT r5 weak 1a, constructed.  The device accumulates f_grid / ubar0 EXACTLY, the reference in a 12-chunk float
+    order; both only feed argmax(cs_u / cs_t).  Scaling the read-start posterior moves that argmax from bin to bin; at a
+    crossing the two leading ratios agree to ~1e-16 and the two summation orders may pick DIFFERENT bins — thresholds a
+    factor of two apart.  What the product does there: the device reports the margin (bossx_update_result.argmax_margin),
+    BossRuns falls back to runs.reference_order_threshold below `tie_margin` (1e-9), and that function is the reference's
+    arithmetic — so the masks are the reference's on either side of the crossing."""
+    from fractions import Fraction
+    from oracle.strategy import find_strategy
+    from boss_runs_amd.config import GpuConfig
+    from boss_runs_amd.runs import reference_order_threshold
+
+    def device_choice(benefit, fh3, time_cost):
+        """exact sums (as the 128-bit fixed point gives them), rounded once per statistic, then the float tail"""
+        norm = benefit.max()
+        nzm = benefit != 0
+        exps = np.abs(np.frexp(benefit[nzm] / norm)[1])
+        counts = np.bincount(exps, minlength=1088).astype(np.int64)
+        fgrid = np.zeros(1088)
+        fv = fh3[nzm]
+        for e in np.nonzero(counts)[0]:
+            fgrid[e] = float(sum(Fraction(float(v)) for v in fv[exps == e]))
+        ubar0 = float(sum(Fraction(float(a)) * Fraction(float(b)) for a, b in zip(fh3.ravel(), benefit.ravel())))
+        thr, size, uniq = choose_threshold(norm, counts, fgrid, ubar0, time_cost)
+        f_mean = fgrid[uniq] / counts[uniq]
+        bb = np.power(2.0, -uniq) * norm
+        peaks = (np.cumsum(bb * f_mean * counts[uniq]) + ubar0) / (np.cumsum((time_cost // 100) * counts[uniq] * f_mean) + 10)
+        rest = np.delete(peaks, size - 1)
+        return thr, size, float((peaks[size - 1] - rest.max()) / peaks[size - 1])
+
+    rng = np.random.default_rng(5)
+    T, disagreements = 400, 0
+    for trial in range(40):
+        benefit = np.zeros((T, 2, 1))
+        benefit[:, 0, 0] = rng.uniform(0.5, 1.0, T)
+        benefit[:, 1, 0] = rng.uniform(0.125, 0.25, T) * np.power(2.0, -rng.integers(0, 6, T))
+        benefit[0, 0, 0] = 1.0
+        fhat = rng.random((T, 2))
+        fhat /= fhat.sum()
+        tc = float(rng.choice([900, 2000, 5000, 20000]))
+        choice = lambda s: reference_order_threshold(benefit, (fhat * s)[:, :, None], tc)
+        lo, hi = 1e-9, 1e9
+        size_hi = choice(hi)[1]
+        if choice(lo)[1] == size_hi:
+            continue
+        for _ in range(200):            # the crossing into the bin the largest scale chooses
+            mid = (lo * hi) ** 0.5
+            if mid == lo or mid == hi:
+                break
+            if choice(mid)[1] == size_hi:
+                hi = mid
+            else:
+                lo = mid
+        for s in (lo, hi):
+            fh3 = (fhat * s)[:, :, None]
+            t_ref, s_ref, m_ref = choice(s)
+            d = {}
+            _, t_or = find_strategy(benefit, benefit, fh3, tc, detail=d)
+            assert t_ref == t_or and s_ref == d["strat_size"]            # the fallback IS the reference's choice
+            t_dev, s_dev, m_dev = device_choice(benefit, fh3, tc)
+            assert m_dev < 1e-12 < GpuConfig().tie_margin and m_ref < 1e-12     # ... and the device's margin sends the update there
+            if t_dev != t_ref:
+                disagreements += 1
+                assert t_dev in (2.0 * t_ref, 0.5 * t_ref)
+        if disagreements >= 3:
+            break
+    assert disagreements >= 3      # the hazard is real: exact and 12-chunk sums do pick different thresholds at a crossing
+
+
 def test_fixed_point_conversion():
     for v in (0.0, 1.0, 1e-6, 0.123456789, 3.5e-12):
         n = int(v * (1 << FX_SHIFT))

@@ -98,11 +98,17 @@ def test_native_update_reraises_what_staging_ahead_raised():
         r.comm = SimpleNamespace(world=1, force=False, rank=0)
         return r
     base = dict(contig_on=np.zeros(0, bool), any_on=False, threshold=1.0, normaliser=1.0, ubar0=0.0, strat_size=1, n_bins=1)
-    for res, have_rl in ((dict(base), True), (dict(base, any_on=True), False), (dict(base, any_on=True), True)):
+    for res, have_rl in ((dict(base), True), (dict(base, any_on=True), True)):
         r = make(dict(res, between_error=Boom("staging failed")), have_rl)
         with pytest.raises(Boom):
             r._update_native(between=lambda: None)
         assert r.n_updates == 1 and r.armed == res["any_on"]
+    # a failure while the results are APPLIED (here the reference's AttributeError for a missing time_cost) is the
+    # primary one — it is not replaced by the held staging error, which travels along as its cause
+    r = make(dict(base, any_on=True, between_error=Boom("staging failed")), False)
+    with pytest.raises(AttributeError) as ei:
+        r._update_native(between=lambda: None)
+    assert isinstance(ei.value.__cause__, Boom) and r.n_updates == 1 and r.armed
     r = make(dict(base, any_on=True), True)                  # nothing held back: nothing raised, results applied
     r._update_native()
     assert r.threshold == 1.0 and r.n_updates == 1

@@ -13,6 +13,7 @@ from scenarios import (GOLDEN, SCENARIOS, E2E_BATCHES, E2E_REJECT, batch_digest,
                        e2e_contig_strings, e2e_reference, unpack_strat)
 
 pytestmark = pytest.mark.gpu
+MARGIN_FLOOR = 1e-9       # relative gap between the best and the second-best cs_u / cs_t every parity scenario must keep (see bossx_update_result)
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -81,11 +82,53 @@ def test_end_to_end_vs_oracle_and_golden(tag, ploidy, nb, mode, in_tmp):
             assert runs.last_stats["strat_size"] == d["strat_size"]
             assert np.allclose(runs.last_stats["f_grid"], d["f_grid"], rtol=1e-11)
             assert np.isclose(runs.last_stats["ubar0"], d["ubar0"], rtol=1e-11)
+            if mode == "fused":
+                # the argmax of cs_u / cs_t is far from a tie on both sides (exact sums here, 12-chunk float sums there)
+                assert MARGIN_FLOOR <= runs.last_stats["argmax_margin"] <= 1.0 and d["argmax_margin"] >= MARGIN_FLOOR
+                assert np.isclose(runs.last_stats["argmax_margin"], d["argmax_margin"], rtol=1e-6, atol=1e-12)
+    assert runs.ties_resolved == 0
     # the file contract: boss.npz as np.load reads it (dynamic_readfish.py:87-110)
     z = np.load(os.path.join(runs.out_dir, "masks", "boss.npz"))
     assert set(z.files) == set(o.contigs)
     for cname, oc in o.contigs.items():
         assert z[cname].dtype == bool and np.array_equal(z[cname], oc.strat)
+
+
+@pytest.mark.parametrize("ploidy,nb,fmt", [(2, 1, "npz"), (1, 2, "both")])
+def test_near_tie_fallback_forced_vs_oracle(ploidy, nb, fmt, in_tmp):
+    """The host fallback of a near-tie (BossRuns._resolve_near_tie: the reference's own summation order, then the masks
+    re-formed with that threshold) driven on EVERY update by a margin floor above any margin: thresholds, masks and the
+    mask file equal the oracle's — what a real near-tie (tests/test_host_logic.py constructs one) would go through."""
+    from oracle.pipeline import OracleRuns
+    from boss_runs_amd.masks import MaskFile
+    contigs = e2e_reference()
+    runs = _product(ploidy, nb, in_tmp)
+    runs.mask_format = fmt
+    runs.tie_margin = 2.0
+    o = OracleRuns(e2e_contig_strings(contigs), ploidy=ploidy, reject_refs={E2E_REJECT}, nbarcodes=nb)
+    n_updated = 0
+    for b in range(E2E_BATCHES):
+        batch = e2e_batch(contigs, b, nb)
+        bcs = batch["barcodes"] if nb > 1 else None
+        o.process_batch(batch["paf"], batch["seqs"], read_lengths=batch["read_lengths"], barcodes=bcs)
+        runs.rl_dist.update(batch["read_lengths"])
+        runs.process_batch_paf(batch["paf"], batch["seqs"], barcodes=bcs)
+        if o.threshold is not None:
+            n_updated += 1
+            assert runs.threshold == o.threshold and runs.last_stats["strat_size"] == o.detail["strat_size"]
+            assert runs.last_stats["tie_resolved"] and runs.last_stats["device_threshold"] == o.threshold      # (no real tie here: both agree)
+            assert np.isclose(runs.last_stats["reference_order_margin"], o.detail["argmax_margin"], rtol=0, atol=0)
+        for cname, oc in o.contigs.items():
+            assert np.array_equal(np.asarray(runs.contigs[cname].strat), oc.strat), (b, cname)
+    assert n_updated > 0 and runs.ties_resolved == n_updated
+    z = np.load(os.path.join(runs.out_dir, "masks", "boss.npz"))
+    for cname, oc in o.contigs.items():
+        assert np.array_equal(z[cname], oc.strat)
+    if fmt == "both":
+        got = MaskFile(os.path.join(runs.out_dir, "masks", "boss.bits")).to_dict()
+        for cname, oc in o.contigs.items():
+            if not oc.rej:
+                assert np.array_equal(got[cname], oc.strat)
 
 
 def test_error_behaviour(in_tmp):
