@@ -135,6 +135,7 @@ struct bossx_engine {
     double *d_lut_score = nullptr, *d_lut_ent = nullptr, *d_fhat = nullptr;
     std::vector<char> raw_blob;       // byte-per-base copy of a batch's reads (BOSSX_HOST_WALK / BOSSX_CHECK_DEVICE_WALK only)
     unsigned long long *d_bucket_sums = nullptr, *d_stats = nullptr;
+    unsigned long long *d_stats_rep = nullptr;     // kHistRep replicas of the histogram's global sums in limb form (kernels.hip.inc: PickParams); d_stats holds the (lo, hi) form where a host asks for it
     uint32_t *d_drop_count = nullptr;
     int64_t fhat_cap = 0;
     int32_t *d_err = nullptr;
@@ -216,7 +217,7 @@ struct bossx_engine {
 namespace {
 
 constexpr size_t kStatWords = size_t(BOSSX_HIST_BINS) * 3 + 2;
-constexpr size_t kStatZero = kStatWords + 2;      // ... + the histogram's ticket counter (zeroed with the sums, never copied back)
+constexpr size_t kStatRepWords = size_t(kHistRep) * size_t(kLimbWords);      // the histogram's limb replicas (kernels.hip.inc: PickParams)
 // page-locked blocks handed out by bossx_host_alloc: device-writable host memory (process-wide:
 // bossx_host_free has no engine)
 std::mutex g_host_mutex;
@@ -618,7 +619,7 @@ void bossx_destroy(bossx_engine *h) {
                     h->d_benefit, h->d_lut_score, h->d_lut_ent, h->d_fhat, h->d_bucket_sums, h->d_drop_count,
                     h->d_stats, h->d_tails /* base of the tails + result block */, h->d_tile_off, h->d_site_off, h->d_length, h->d_bin_off, h->d_row_off,
                     h->d_strat_off, h->d_bucket_off, h->d_drop_thr, h->d_local, h->d_limbs,
-                    h->d_strat_bits, h->d_bcode, h->d_convert};
+                    h->d_strat_bits, h->d_bcode, h->d_convert, h->d_stats_rep};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &st : h->slots) { if (st.ev_ready) hipEventDestroy(st.ev_ready); if (st.ev_free) hipEventDestroy(st.ev_free); if (st.d_err) hipFree(st.d_err); if (st.d_ops) hipFree(st.d_ops); if (st.d_tiles) hipFree(st.d_tiles); if (st.d_blob) hipFree(st.d_blob); if (st.d_segs) hipFree(st.d_segs); if (st.d_tilerefs) hipFree(st.d_tilerefs); if (st.d_codes) hipFree(st.d_codes); if (st.d_pieces) hipFree(st.d_pieces); }
     if (h->d_tile_ref) hipFree(h->d_tile_ref);
@@ -873,6 +874,7 @@ int bossx_finalize(bossx_engine *h, double score0, double ent0) {
             }
     }
     if ((rc = dev_alloc(h, &h->d_stats, size_t(BOSSX_HIST_BINS * 3 + 4 + 128), true))) return rc;
+    if ((rc = dev_alloc(h, &h->d_stats_rep, kStatRepWords + 8, true))) return rc;
     // One allocation: [halo tails | control block | error flag | per-contig switches].  The tails sit
     // right before the control block, whose first field is the running maximum: the multi-GPU MAX
     // all-reduce over "tails + 1 double" reduces the normaliser in place.  The part from the
@@ -1084,7 +1086,7 @@ hipError_t upload_async(void *dst, const void *src_pinned, size_t bytes, hipStre
     if (engine_copies) return hipMemcpyAsync(dst, src_pinned, bytes, hipMemcpyHostToDevice, stream);
     // enough waves to keep PCIe reads in flight (each thread holds four 16-byte loads), not more than the copy needs
     const size_t vec = (bytes + 15) / 16;
-    const uint32_t blocks = uint32_t(std::min<size_t>(std::max<size_t>((vec + 1023) / 1024, 1), 256));
+    const uint32_t blocks = uint32_t(std::min<size_t>(std::max<size_t>((vec + 1023) / 1024, 1), 48));      // (0.8 MB in flight: far beyond what PCIe holds; the CUs are for the kernels next to it)
     hipLaunchKernelGGL(upload_kernel, dim3(blocks), dim3(256), 0, stream, static_cast<uint8_t *>(dst), static_cast<const uint8_t *>(src_pinned), bytes);
     return hipGetLastError();
 }
@@ -2187,14 +2189,13 @@ int build_fhat(bossx_engine *h, const FhatModel *up) {
     return BOSSX_OK;
 }
 
-// `pick`: the fused single-GPU update — the kernel's last block also runs the threshold choice (and the mask pass may read the codes)
-int launch_hist(bossx_engine *h, const bossx_fhat_desc *fh, int gate, bool clear = true, const PickParams *pick = nullptr) {
+// The statistics land in the limb replicas (d_stats_rep); `clear`: zero them first (the fused update lets the chain kernel do it).
+int launch_hist(bossx_engine *h, const bossx_fhat_desc *fh, int gate, bool clear = true) {
     const int64_t target = h->n_sites_all / kWindow;
-    if (clear) HIPCHK(hipMemsetAsync(h->d_stats, 0, kStatZero * sizeof(unsigned long long), h->stream));
+    if (clear) HIPCHK(hipMemsetAsync(h->d_stats_rep, 0, kStatRepWords * sizeof(unsigned long long), h->stream));
     HistParams P;
     P.benefit = h->d_benefit; P.fhat_c = h->d_fhat;
-    P.counts = h->d_stats; P.fgrid = h->d_stats + BOSSX_HIST_BINS; P.ubar = h->d_stats + BOSSX_HIST_BINS * 3;
-    P.ticket = h->d_stats + kStatWords;
+    P.replicas = h->d_stats_rep;
     P.code = getenv("BOSSX_NO_CODES") ? nullptr : h->d_bcode; P.Bc = h->Bc;
     P.ct = table_of(h); P.B = h->B; P.target = target; P.dpad = target > h->B ? target - h->B : 0;
     P.target_rs = fh->target_rs; P.d2 = target - fh->target_rs;
@@ -2202,20 +2203,38 @@ int launch_hist(bossx_engine *h, const bossx_fhat_desc *fh, int gate, bool clear
     P.nb = h->nb; P.all_local = h->all_local ? 1 : 0; P.gate = gate; P.ctrl = h->d_ctrl;
     if (P.d2 < 0) P.d2 = 0;   // trimmed instead of padded: indices unchanged
     if (P.d1 < 0) P.d1 = 0;
-    P.do_pick = pick ? 1 : 0;
-    P.pick = pick ? *pick : PickParams{};
-    // every block loops over spans of 2048 positions; no more blocks than stay resident with their 40 KB of LDS (the bins are
-    // zeroed and flushed once per block)
+    // every block loops over spans of 4096 positions; no more blocks than stay resident (two per CU: 59 KB of LDS each)
     const int64_t spans = (target + kHistSpan - 1) / kHistSpan;
-    const int64_t per_row = std::max<int64_t>(1, 1024 / (int64_t(h->nb) * 2));
+    static const int64_t cap = getenv("BOSSX_HIST_BLOCKS") ? atoll(getenv("BOSSX_HIST_BLOCKS")) : 1024;       // (experiments)
+    const int64_t per_row = std::max<int64_t>(1, cap / (int64_t(h->nb) * 2));
     const int64_t blocks = std::min<int64_t>(spans, per_row);
+    P.probe = nullptr;
+#ifdef BOSSX_HIST_PROBE
+    P.probe = reinterpret_cast<long long *>(h->d_stats + kStatWords + 8);
+#endif
     time_begin(h, BOSSX_K_HIST);
-    hipLaunchKernelGGL(threshold_hist_kernel, dim3(uint32_t(std::max<int64_t>(blocks, 1)), uint32_t(h->nb * 2)), dim3(256), 0, h->stream, P);
+    hipLaunchKernelGGL(threshold_hist_kernel, dim3(uint32_t(std::max<int64_t>(blocks, 1)), uint32_t(h->nb * 2)), dim3(kHistThreads), 0, h->stream, P);
+#ifdef BOSSX_HIST_PROBE
+    {
+        long long pr[24];
+        (void)hipStreamSynchronize(h->stream);
+        if (hipMemcpy(pr, P.probe, sizeof(pr), hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "[hist probe] %lld blocks/row; block 0: span in LDS %lld, walked %lld, sums %lld, flush issued %lld | middle block: %lld %lld %lld %lld (cycles)\n",
+                    (long long)blocks, pr[1], pr[2], pr[3], pr[4], pr[9], pr[10], pr[11], pr[12]);
+    }
+#endif
     // algorithmic bytes: every element read once, one code byte written
     time_end(h, BOSSX_K_HIST, double(target) * h->nb * 2 * (8.0 + (P.code ? 1.0 : 0.0)));
     HIPCHK(hipGetLastError());
     h->codes_valid = P.code != nullptr;
     return BOSSX_OK;
+}
+
+// The replicas' sums where somebody wants them: as limbs for the multi-GPU all-reduce (d_limbs) and / or in the C-ABI's (lo, hi)
+// form (d_stats: counts | fgrid | ubar) for a host that reads the statistics.
+void launch_fold(bossx_engine *h, bool to_limbs, bool to_canon, int gate) {
+    hipLaunchKernelGGL(fold_limbs_kernel, dim3((BOSSX_HIST_BINS + 1 + 255) / 256), dim3(256), 0, h->stream, h->d_stats_rep, int32_t(kHistRep),
+                       to_limbs ? h->d_limbs : nullptr, to_canon ? h->d_stats : nullptr, h->d_ctrl, gate);
 }
 
 // `use_codes`: the threshold in the control block was picked ON THE DEVICE from the histogram pass that also left d_bcode (the
@@ -2229,13 +2248,15 @@ int launch_mask(bossx_engine *h, int gate, bool with_tails = false, const PickPa
     P.result_words = int32_t(h->result_bytes / 8);
     P.host_strat = host_strat;
     P.benefit = h->d_benefit; P.bucket_on = h->d_bucket_on; P.strat = h->d_strat; P.ct = table_of(h);
-    P.code = (use_codes && h->codes_valid && !pick) ? h->d_bcode : nullptr; P.Bc = h->Bc;
+    P.code = (use_codes && h->codes_valid) ? h->d_bcode : nullptr; P.Bc = h->Bc;
     P.B = h->B; P.NBK = h->NBK; P.rows = h->rows; P.nb = h->nb; P.gate = gate; P.ctrl = h->d_ctrl;
     P.tails = with_tails ? h->d_tails : nullptr; P.tail_k = int32_t(h->filt.size());
     const int64_t span = int64_t(256) * kMaskRun;
-    const int64_t blocks = std::min<int64_t>((h->rows + span - 1) / span, pick ? 1024 : 4096);
+    // (with the threshold choice in every block — ~90 loads per lane of its first wave — no more blocks than CUs: each loops over its spans)
+    const int64_t blocks = std::min<int64_t>((h->rows + span - 1) / span, pick ? 256 : 4096);
     time_begin(h, BOSSX_K_MASK);
-    hipLaunchKernelGGL(strategy_mask_kernel, dim3(uint32_t(std::max<int64_t>(blocks, 1))), dim3(256), 0, h->stream, P);
+    if (pick) hipLaunchKernelGGL(strategy_mask_kernel<true>, dim3(uint32_t(std::max<int64_t>(blocks, 1))), dim3(256), 0, h->stream, P);
+    else hipLaunchKernelGGL(strategy_mask_kernel<false>, dim3(uint32_t(std::max<int64_t>(blocks, 1))), dim3(256), 0, h->stream, P);
     // algorithmic bytes: per row * strand * barcode one code byte (or one double) read, one mask byte written
     time_end(h, BOSSX_K_MASK, double(h->rows) * h->nb * 2 * (P.code ? 2.0 : 9.0));
     HIPCHK(hipGetLastError());
@@ -2307,6 +2328,7 @@ int bossx_histogram(bossx_engine *h, double normaliser, const bossx_fhat_desc *f
     HIPCHK(hipMemcpyAsync(&h->d_ctrl->max_bits, &bits, sizeof(bits), hipMemcpyHostToDevice, h->stream));
     h->max_bits_clear = false;
     if ((rc = launch_hist(h, fh, 0))) return rc;
+    launch_fold(h, false, /*to_canon=*/true, 0);
     std::vector<unsigned long long> host(kStatWords);
     HIPCHK(hipMemcpyAsync(host.data(), h->d_stats, kStatWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -2386,8 +2408,7 @@ int bossx_dist_hist(bossx_engine *h, const bossx_fhat_desc *fh) {
     else if (!h->d_fhat || fh->n_windows * 2 > h->fhat_cap) rc = fail(h, BOSSX_E_INVALID, "dist_hist without f-hat: call bossx_fhat_build first");
     if (rc) return rc;
     if ((rc = launch_hist(h, fh, 1))) return rc;
-    hipLaunchKernelGGL(stats_to_limbs_kernel, dim3((BOSSX_HIST_BINS + 1 + 255) / 256), dim3(256), 0, h->stream, h->d_stats,
-                       h->d_stats + BOSSX_HIST_BINS, h->d_stats + BOSSX_HIST_BINS * 3, h->d_limbs, h->d_ctrl, 1);
+    launch_fold(h, /*to_limbs=*/true, /*to_canon=*/false, 1);      // this device's sums, ready for the SUM all-reduce
     HIPCHK(hipGetLastError());
     return BOSSX_OK;
 }
@@ -2404,9 +2425,8 @@ int bossx_dist_pick(bossx_engine *h, double tc) {
         h->norm_in_tails = false;
         return BOSSX_OK;
     }
-    PickParams PP;
-    PP.counts = h->d_stats; PP.fgrid = h->d_stats + BOSSX_HIST_BINS; PP.ubar = h->d_stats + BOSSX_HIST_BINS * 3;
-    PP.limbs = h->d_limbs; PP.ctrl = h->d_ctrl; PP.tc = tc; PP.gate = 1;
+    PickParams PP{};
+    PP.limbs = h->d_limbs; PP.n_rep = 1; PP.ctrl = h->d_ctrl; PP.tc = tc; PP.gate = 1;
     hipLaunchKernelGGL(threshold_pick_kernel, dim3(1), dim3(64), 0, h->stream, PP);
     launch_tails(h);
     HIPCHK(hipGetLastError());
@@ -2459,10 +2479,9 @@ int dist_finish_impl(bossx_engine *h, uint8_t *strat_all, uint8_t *contig_on, bo
     { int jrc = settle_chain(h); if (jrc) return jrc; }
     h->sweep_in_flight = false;
     if (h->dist_pick_fused) {
-        PickParams PP;
-        PP.counts = h->d_stats; PP.fgrid = h->d_stats + BOSSX_HIST_BINS; PP.ubar = h->d_stats + BOSSX_HIST_BINS * 3;
-        PP.limbs = h->d_limbs; PP.ctrl = h->d_ctrl; PP.tc = h->dist_tc; PP.gate = 1;
-        rc = launch_mask(h, 1, true, &PP);
+        PickParams PP{};
+        PP.limbs = h->d_limbs; PP.n_rep = 1; PP.ctrl = h->d_ctrl; PP.tc = h->dist_tc; PP.gate = 1;
+        rc = launch_mask(h, 1, true, &PP, nullptr, nullptr, /*use_codes=*/true);
         h->dist_pick_fused = false;
     } else {
         rc = launch_mask(h, 1, true, nullptr, nullptr, nullptr, /*use_codes=*/true);
@@ -2759,7 +2778,7 @@ int bossx_update_benefit(bossx_engine *h, const int32_t *windows, const double *
     int rc = fill_chain_params(h, windows, mult, CP, lds);
     if (rc) return rc;
     CP.gate = 1;
-    CP.zero_stats = h->d_stats; CP.n_zero = int32_t(kStatZero);    // for the histogram of bossx_update
+    CP.zero_stats = h->d_stats_rep; CP.n_zero = int32_t(kStatRepWords);    // for the histogram of bossx_update
     if (h->overlap_ok && h->sweep_published && h->sweep_in_flight) {
         // The strategy is switched on (the gate is known to be open) and this update's sweep is in
         // flight on the main stream: run the chain NEXT TO it on stream2.  The sweep hands tiles
@@ -2842,18 +2861,17 @@ int update_run(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_al
                 if (!h->max_bits_clear) HIPCHK(hipMemsetAsync(&h->d_ctrl->max_bits, 0, sizeof(unsigned long long), h->stream));
                 h->max_bits_clear = false;
                 CP.gate = 1;
-                CP.zero_stats = h->d_stats; CP.n_zero = int32_t(kStatZero);
+                CP.zero_stats = h->d_stats_rep; CP.n_zero = int32_t(kStatRepWords);
                 launch_chain(h, CP, lds);
             } else if (h->chain_on_stream2) {
                 HIPCHK(hipStreamWaitEvent(h->stream, h->ev_chain, 0));     // the chain ran next to the sweep
             }
             h->chain_on_stream2 = false;
             // the chain kernel cleared the statistics; the mask kernel picks the threshold itself
-            // ... and its last block picks the threshold
-            PickParams PP;
-            PP.counts = h->d_stats; PP.fgrid = h->d_stats + BOSSX_HIST_BINS; PP.ubar = h->d_stats + BOSSX_HIST_BINS * 3;
-            PP.limbs = nullptr; PP.ctrl = h->d_ctrl; PP.tc = up->tc; PP.gate = 1;
-            if ((rc = launch_hist(h, &fh, 1, /*clear=*/false, &PP))) return rc;
+            if ((rc = launch_hist(h, &fh, 1, /*clear=*/false))) return rc;
+            if (counts) launch_fold(h, false, /*to_canon=*/true, 1);      // (a caller that wants the statistics: the (lo, hi) form in d_stats)
+            PickParams PP{};
+            PP.limbs = reinterpret_cast<const long long *>(h->d_stats_rep); PP.n_rep = kHistRep; PP.ctrl = h->d_ctrl; PP.tc = up->tc; PP.gate = 1;
             // the mask kernel's block 0 writes the result block into the pinned buffer itself; the
             // sentinel tells whether it got that far (it returns early while nothing is switched on)
             *herr = kNoResult;
@@ -2869,7 +2887,7 @@ int update_run(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_al
                     if (strat_all >= blk.first && strat_all + h->strat_bytes <= blk.first + blk.second) mirror = strat_all;
             }
             mirrored = mirror != nullptr;
-            if ((rc = launch_mask(h, 1, false, nullptr, reinterpret_cast<unsigned long long *>(pin), mirror, /*use_codes=*/true))) return rc;
+            if ((rc = launch_mask(h, 1, false, &PP, reinterpret_cast<unsigned long long *>(pin), mirror, /*use_codes=*/true))) return rc;
         }
         HIPCHK(hipGetLastError());
         // results

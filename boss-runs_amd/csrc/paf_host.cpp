@@ -1053,6 +1053,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             err = "batch too large: more than 2^32 aligned bases";
             return BOSSX_E_RANGE;
         }
+        PT(T2a);
         out.n_touched_tiles = 0;
         uint32_t last_tile = UINT32_MAX;
         for (size_t w = 0; w < marks.size(); ++w) {
@@ -1076,6 +1077,8 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
                 mp.g_first = key < n_keys ? rank[key >> 6] + uint32_t(__builtin_popcountll(marks[key >> 6] & ((1ull << (key & 63)) - 1ull))) : 0u;
             }
         }
+        PT(T2b);
+        if (getenv("BOSSX_STAGE_TIMING")) fprintf(stderr, "  [parse] device-walk tail: MapPlans + marks %.3f, groups + ranks %.3f ms\n", PTMS(T2, T2a), PTMS(T2a, T2b));
         out.ops_cap = ops_at + 1;
         out.segs_cap = seg_cap + 1;
         out.total_emit = cur_emit;

@@ -124,6 +124,33 @@ class ReadStartDist:
             fhat = np.multiply(fhat, self.on_target / total)
         return fhat, self.target_size
 
+    def fhat_expanded_reference_order(self):
+        """What ReadStartDist.update_f_pointmass returns in the reference (readstartdist.py:86-152), with ITS arithmetic: the expanded
+        array is built and normalised by numpy's pairwise sum of that array — `fhat_compact` (and the device) normalise by an
+        extended-precision sum of the compact one, which can differ in the last bit.  Materialises target_size x 2 doubles: used only
+        where the last bit may matter (BossRuns._resolve_near_tie)."""
+        merged = self.merge()
+        n = merged.shape[0]
+        nzmask = merged != 0
+        csum = np.sum(merged[nzmask])
+        rhs = (self.alpha / (2 * n * self.alpha + csum))
+        beta_num = np.exp(betaln(self.alpha, ((2 * n - 1) * self.alpha + csum)))
+        beta_denom = np.exp(betaln(self.alpha, ((2 * n - 1) * self.alpha))) or 1e-20
+        p0_bit = self.p0 / (self.p0 + (1 - self.p0))
+        expected = (1 - p0_bit * (beta_num / beta_denom)) * rhs
+        fhat = np.where(nzmask, np.divide(np.add(self.alpha, merged), 2 * n * self.alpha + csum), expected)
+        out = np.repeat(fhat, int(self.window_size // 100), axis=0)
+        d = self.target_size - out.shape[0]
+        assert d < self.window_size
+        if d > 0:
+            out = np.append(out, out[-d:], axis=0)
+        elif d < 0:
+            out = out[:-abs(d)]
+        total = np.sum(out)
+        if total != 0:
+            out = np.multiply(out, self.on_target / total)
+        return out
+
     def expand(self, fhat_c, target):
         """Materialise what the reference would pass to find_strat_thread (tests / small
         genomes only): repeat, pad/trim to target_size, then adjust_length to `target`."""

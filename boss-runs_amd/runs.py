@@ -430,10 +430,9 @@ class BossRuns(Boss):
         eng = self.engine
         benefit = np.concatenate([eng.export(c.index, "benefit") for c in self.contigs_filt.values()])
         target = self.ref.n_sites // 100
-        fhat_c, _ = self.read_starts.fhat_compact()
-        fhat = self.read_starts.expand(fhat_c, target)
+        fhat = self.read_starts.fhat_expanded_reference_order()            # (normalised as the reference normalises it: to the last bit)
         fhat = np.repeat(fhat[:, :, np.newaxis], self.nbarcodes, axis=2)
-        threshold, size, margin = reference_order_threshold(_adjust_length(target, benefit), fhat, self.rl_dist.time_cost)
+        threshold, size, margin = reference_order_threshold(_adjust_length(target, benefit), _adjust_length(target, fhat), self.rl_dist.time_cost)
         self.ties_resolved += 1
         self.last_stats.update(tie_resolved=True, device_threshold=self.threshold, device_strat_size=self.last_stats["strat_size"],
                                reference_order_margin=margin)

@@ -12,8 +12,30 @@ from scenarios import REPO, E2E_REJECT, e2e_batch, e2e_contig_strings, e2e_refer
 
 # BOSSX_DIST_SCENARIO=four: four contigs whose longest-first packing onto two ranks is NOT contiguous (owners 0 1 0 1): the row-drift
 # halo of every contig must travel whoever owns its neighbours.  Default: the end-to-end reference (two kept contigs).
+# BOSSX_DIST_SCENARIO=grch27: BASELINE configs[3]'s GEOMETRY for the eight-rank protocol — the 24 chromosome lengths of GRCh38 scaled by 1/400
+# (chr1 622 kb ... chr21 117 kb) + three scaffolds just above the 100-kb filter = 27 contigs, 8 Mb: longest-first packing onto eight ranks
+# is non-contiguous, every rank owns three or four contigs, the 26 rows of drift of `_distribute_strategy` cross ranks at nearly every
+# block boundary, the halo block is 27^2 * 2 * nb doubles and the summaries' all-gather runs at world 8.
+GRCH27_SCALE = 400
+
+
+def grch27_lengths():
+    from boss_runs_amd import synth
+    return [L // GRCH27_SCALE for L in synth.GRCH38_LENS] + [100_300, 104_100, 110_700]
+
+
+def _zero_bucket_threshold():
+    return os.environ.get("BOSSX_DIST_SCENARIO") in ("four", "grch27")
+
+
 def _scenario():
     from boss_runs_amd import synth
+    if os.environ.get("BOSSX_DIST_SCENARIO") == "grch27":
+        lens = grch27_lengths()
+        names = ["chr%d" % (i + 1) for i in range(22)] + ["chrX", "chrY", "scafA", "scafB", "scafC"]
+        contigs = synth.make_reference(lens, seed=6, names=names)
+        return contigs, [(n, synth.codes_to_str(c)) for n, c in contigs], "", \
+            (lambda b, nb: synth.make_batch(contigs, 1500, seed=700 + b, mean_len=3000.0, nbarcodes=nb))
     if os.environ.get("BOSSX_DIST_SCENARIO") == "four":
         contigs = synth.make_reference([300_000, 120_000, 110_000, 290_000], seed=5, names=["f0", "f1", "f2", "f3"])
         return contigs, [(n, synth.codes_to_str(c)) for n, c in contigs], "", \
@@ -57,7 +79,7 @@ def run_rank(rank, nb, ploidy, engine=None, device=None, comm=None):
     args.general.name = "dist%d" % rank
     args.optional.ploidy = ploidy
     args.optional.reject_refs = reject
-    if os.environ.get("BOSSX_DIST_SCENARIO") == "four":
+    if _zero_bucket_threshold():
         args.optional.bucket_threshold = 0
     if device is not None:
         args.gpu.device = device
@@ -68,16 +90,18 @@ def run_rank(rank, nb, ploidy, engine=None, device=None, comm=None):
     out = []
     for b in range(3):
         batch = make_batch(b, nb)
-        # shard the reads: a read goes to the rank owning the target of its first PAF line
-        # (reads on the short / rejected contigs and unmapped reads go to rank 0)
+        # shard the reads: a read goes to the rank owning the target of the mapping the update will CHOOSE for it (filters, then
+        # the best of what is left, paf.py:631-722 — a read whose first line is filtered out is decided by a later one, which may lie
+        # on another rank's contig); reads on the short / rejected contigs and reads without a surviving mapping go to rank 0
+        from oracle.pafcigar import parse_paf, best_mapper
+        chosen = {rid: (best_mapper(recs) if len(recs) > 1 else recs[0]).tname for rid, recs in parse_paf(batch["paf"], min_len=200).items()}
         by_read = {}
         for line in batch["paf"].split("\n"):
             by_read.setdefault(line.split("\t")[0], []).append(line)
         lines, seqs, lens = [], {}, {}
         for rid, seq in batch["seqs"].items():
             ls = by_read.get(rid, [])
-            tgt = ls[0].split("\t")[5] if ls else None
-            owner = runs.owner_of.get(tgt, 0)
+            owner = runs.owner_of.get(chosen.get(rid), 0)
             if owner == rank:
                 lines.extend(ls)
                 seqs[rid] = seq
@@ -94,7 +118,7 @@ def run_rank(rank, nb, ploidy, engine=None, device=None, comm=None):
 def oracle_expected(nb, ploidy):
     from oracle.pipeline import OracleRuns
     contigs, strings, reject, make_batch = _scenario()
-    kw = dict(bucket_threshold=0) if os.environ.get("BOSSX_DIST_SCENARIO") == "four" else {}
+    kw = dict(bucket_threshold=0) if _zero_bucket_threshold() else {}
     o = OracleRuns(strings, ploidy=ploidy, reject_refs={reject} if reject else set(), nbarcodes=nb, **kw)
     expected = []
     for b in range(3):
@@ -193,4 +217,4 @@ def main_threads(nb, ploidy, tmp, out_path, world=2):
 
 
 if __name__ == "__main__":
-    sys.exit(main_threads(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]))
+    sys.exit(main_threads(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], world=int(sys.argv[5]) if len(sys.argv) > 5 else 2))

@@ -337,7 +337,7 @@ def test_index_error_batches_ingest_nothing(in_tmp):
     good(3)
 
 
-def test_grch38_geometry_one_gpu(in_tmp):
+def test_grch38_geometry_one_gpu(in_tmp, monkeypatch):
     """BASELINE configs[3] geometry on ONE GPU (the whole 3.1 Gb reference fits one MI355X): the 24
     chromosome lengths of GRCh38 + MT (dropped by the 100-kb filter, reference.py:330-331) + three
     scaffolds >= 100 kb = 27 contigs, 1.5 M sweep tiles, 31 M bins, chr1's 2.49 M-bin move_sum chain,
@@ -486,3 +486,15 @@ def test_grch38_geometry_one_gpu(in_tmp):
     assert runs.threshold == thr1 and np.array_equal(eng.strat_bits, bits1)
     frac = float(np.mean([runs.contigs[n].strat.mean() for n in ("chr1", "chr21", "scaf_400k")]))
     assert 0.0 < frac < 1.0
+    # ... and the OTHER form of the chain at chromosome length: the same bin sums through the serial kernel (the gated fallback of
+    # the chunk-parallel form) equal the oracle's move_sum arithmetic as well
+    from boss_runs_amd.runs import MULT
+    monkeypatch.setenv("BOSSX_CHAIN_SERIAL_NOW", "1")
+    cs0 = eng.chain_stats()
+    eng.benefit(np.concatenate(([400 // 100], runs.rl_dist.approx_ccl // 100)).astype(np.int32), MULT)
+    assert eng.chain_stats()["chunk_parallel_launches"] == cs0["chunk_parallel_launches"]      # (it WAS the serial kernel)
+    for n in ("chr1", "chrX"):
+        ds = runs.contigs[n].scores_ds
+        _, add = benefit_from_ds(ds, smu_from_ds(ds), o_rl.approx_ccl)
+        assert np.array_equal(runs.contigs[n].additional_benefit, add), n
+    assert eng.chain_stats()["failed_checks"] == 0

@@ -89,6 +89,7 @@ def test_product_readstartdist_vs_oracle():
         got = p.expand(fh_c, want.shape[0])
         assert target_rs == o.target_size and got.shape == want.shape
         assert np.allclose(got, want, rtol=1e-13, atol=0)      # only the normaliser's rounding differs
+        assert np.array_equal(p.fhat_expanded_reference_order(), want)      # the near-tie fallback's form: bit for bit the reference's
 
 
 def test_choose_threshold_vs_oracle_find_strategy():

@@ -77,6 +77,29 @@ def test_noncontiguous_partition_equals_single_process_oracle(method, tmp_path, 
     dist_scenario.check(ret, expected, 2)
 
 
+def test_eight_ranks_grch38_geometry_equal_single_process_oracle(tmp_path, monkeypatch):
+    """the EIGHT-rank protocol at BASELINE configs[3]'s geometry (dist_scenario: the 27-contig GRCh38 set
+    scaled to 8 Mb), run for real — eight processes over gloo, owners from `partition_contigs(..., "lpt")`: non-contiguous, every
+    rank three or four contigs, 26 rows of drift crossing ranks, the summaries' all-gather, the MAX and the exact SUM at world
+    8.  Thresholds, statistics and every contig's mask on every rank equal the single-process oracle's, update by update."""
+    import dist_scenario
+    monkeypatch.setenv("BOSSX_DIST_SCENARIO", "grch27")
+    monkeypatch.setenv("BOSSX_PARTITION", "lpt")
+    lens = dist_scenario.grch27_lengths()
+    owners = partition_contigs(lens, 8, "lpt")
+    assert len(lens) == 27 and min(lens) >= 100_000 and set(owners) == set(range(8))
+    assert owners != sorted(owners)                                       # non-contiguous
+    assert sum(1 for a, b in zip(owners, owners[1:]) if a != b) >= 20     # nearly every block boundary separates two ranks
+    assert min(owners.count(r) for r in range(8)) >= 2
+    expected = dist_scenario.oracle_expected(1, 2)
+    assert expected[-1]["threshold"] is not None
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(dist_scenario.worker, args=(8, port, str(tmp_path), 1, 2, ret), nprocs=8, join=True)
+    dist_scenario.check(ret, expected, 8)
+
+
 def test_native_update_reraises_what_staging_ahead_raised():
     """Engine.update holds an exception of `between()` (the next batch staged while the update runs) back so that the
     update can be collected; `_update_native` must re-raise it on every way out — strategy not armed yet, read lengths missing,

@@ -1332,15 +1332,18 @@ def _loopback_rccl():
     return so
 
 
-@pytest.mark.parametrize("nb,ploidy,scenario", [(1, 2, "e2e"), (2, 1, "e2e"), (1, 2, "four")])
-def test_native_driver_two_ranks_on_one_device_vs_oracle(nb, ploidy, scenario, tmp_path, monkeypatch):
+@pytest.mark.parametrize("nb,ploidy,scenario,world", [(1, 2, "e2e", 2), (2, 1, "e2e", 2), (1, 2, "four", 2), (1, 2, "grch27", 8)])
+def test_native_driver_two_ranks_on_one_device_vs_oracle(nb, ploidy, scenario, world, tmp_path, monkeypatch):
     """The native multi-GPU driver with world = 2 on a ONE-GPU box: two engines on device 0, each owning its share of
     the contigs, driven by two threads of one process; every collective of the update — the "some strategy is on"
     flag, halo rows + normaliser, the exact histogram limbs (bossx_dist_update) and the batch summaries of the sharded
     reads (bossx_dist_allgather) — goes through the library's communicator, which BOSSX_RCCL_LIB points at the
     loopback double of librccl (tests/rccl_loopback).  Thresholds, statistics and every contig's mask on both
     ranks equal the single-process oracle's, update by update.  `four`: four contigs packed longest-first onto the two
-    ranks (owners 0 1 0 1, dist_scenario._scenario): every halo row crosses ranks."""
+    ranks (owners 0 1 0 1, dist_scenario._scenario): every halo row crosses ranks.  `grch27`, world = 8:
+    EIGHT engines on the one device, the 27-contig GRCh38 geometry scaled to 8 Mb, owners packed longest-first — the
+    8-rank protocol of BASELINE configs[3] executed with the real kernels and the library's own collectives (still not
+    real librccl over xGMI: one-GPU boxes)."""
     import pickle
     import subprocess
     import sys
@@ -1348,17 +1351,17 @@ def test_native_driver_two_ranks_on_one_device_vs_oracle(nb, ploidy, scenario, t
     so = _loopback_rccl()
     out = tmp_path / "ranks.pkl"
     monkeypatch.setenv("BOSSX_DIST_SCENARIO", scenario)
-    if scenario == "four":
+    if scenario in ("four", "grch27"):
         monkeypatch.setenv("BOSSX_PARTITION", "lpt")
     env = dict(os.environ, BOSSX_RCCL_LIB=so, PYTHONPATH=os.pathsep.join([REPO, os.path.join(REPO, "tests")]))
     env.pop("BOSSX_TORCH_COLLECTIVES", None)
-    p = subprocess.run([sys.executable, os.path.join(REPO, "tests", "dist_scenario.py"), str(nb), str(ploidy), str(tmp_path), str(out)],
+    p = subprocess.run([sys.executable, os.path.join(REPO, "tests", "dist_scenario.py"), str(nb), str(ploidy), str(tmp_path), str(out), str(world)],
                        capture_output=True, text=True, timeout=900, env=env)
     got = pickle.load(open(out, "rb")) if out.exists() else dict(ret={}, errs=[("-", "no result file")])
     assert p.returncode == 0 and not got["errs"], (p.stderr[-3000:], got["errs"])
-    dist_scenario.check(got["ret"], dist_scenario.oracle_expected(nb, ploidy), 2, full_stats=False)
+    dist_scenario.check(got["ret"], dist_scenario.oracle_expected(nb, ploidy), world, full_stats=False)
     # per update: the summaries' all-gather + two all-reduces (three until some strategy is on), all inside the library
-    assert all(got["ret"][r][-1]["collectives"] >= 3 * 3 for r in range(2))
+    assert all(got["ret"][r][-1]["collectives"] >= 3 * 3 for r in range(world))
 
 
 @pytest.mark.gpu
