@@ -40,6 +40,7 @@ struct bossx_engine {
     hipEvent_t ev_ups[kUpStreams] = {nullptr, nullptr, nullptr, nullptr};         // [0] = ev_up
     hipStream_t stream_txt = nullptr;  // the PAF text goes up on its own: the device walk needs nothing else
     hipEvent_t ev_txt = nullptr;
+    hipEvent_t ev_walk = nullptr;      // behind the copy of the device walk's totals into host memory (the staging waits for THIS, not for the stream)
     // Everything a batch being staged runs on the device (plan upload, CIGAR walk, code expansion) has a stream of
     // its own: it touches the slot's buffers and the staging scratch only, never the site state, so the NEXT batch
     // can be staged while the update of the current one (sweep, chain) is still running on `stream`.  The consumer
@@ -196,6 +197,7 @@ struct bossx_engine {
     char *d_paf = nullptr; size_t d_paf_cap = 0;
     uint8_t *h_plan_pin = nullptr; size_t plan_pin_cap = 0;   // MapPlan[] + TileRef[] + read-back block
     MapPlan *d_plans = nullptr; size_t d_plans_cap = 0;
+    uint8_t *d_marks = nullptr; size_t d_marks_cap = 0;       // bitmap of the batch's (tile, barcode) keys + per-word ranks (build_groups_kernel)
     uint32_t *d_walk = nullptr; size_t d_walk_cap = 0;        // n_runs | walk_err | ops_off | group_count | group_cursor | totals
     uint32_t *d_lane_scan = nullptr; size_t d_lane_scan_cap = 0;   // per mapping and lane: exclusive prefixes of the walk (pass 1 -> pass 2)
     std::vector<uint8_t> read_dirty;                          // per read: holds a byte other than A/C/G/T
@@ -320,7 +322,7 @@ SweepParams sweep_params(bossx_engine *h) {
     P.probe = getenv("BOSSX_SWEEP_PROBE") ? h->d_stats + kStatWords + 80 : nullptr;
     if (h->pending_slot >= 0) {
         const bossx_engine::Staged &st = h->slots[size_t(h->pending_slot)];
-        P.tiles = st.d_tilerefs; P.n_groups = uint32_t(st.pb.tiles.size()); P.pieces = st.d_pieces; P.codes = st.d_codes;
+        P.tiles = st.d_tilerefs; P.n_groups = uint32_t(st.pb.n_groups); P.pieces = st.d_pieces; P.codes = st.d_codes;
     }
     P.ds = h->d_ds; P.bucket_sums = h->d_bucket_sums; P.n_tiles = h->n_tiles;
     P.lut_score = h->d_lut_score; P.lut_ent = h->d_lut_ent; P.ct = table_of(h);
@@ -552,6 +554,7 @@ void bossx_destroy(bossx_engine *h) {
     if (h->stream_txt) { hipStreamSynchronize(h->stream_txt); hipStreamDestroy(h->stream_txt); }
     if (h->stream_stage) { hipStreamSynchronize(h->stream_stage); hipStreamDestroy(h->stream_stage); }
     if (h->ev_txt) hipEventDestroy(h->ev_txt);
+    if (h->ev_walk) hipEventDestroy(h->ev_walk);
     if (h->ev_begin) hipEventDestroy(h->ev_begin);
     if (h->ev_chain) hipEventDestroy(h->ev_chain);
     if (h->ev_sweep) hipEventDestroy(h->ev_sweep);
@@ -631,6 +634,7 @@ void bossx_destroy(bossx_engine *h) {
     if (h->d_gather) hipFree(h->d_gather);
     if (h->d_paf) hipFree(h->d_paf);
     if (h->d_plans) hipFree(h->d_plans);
+    if (h->d_marks) hipFree(h->d_marks);
     if (h->d_walk) hipFree(h->d_walk);
     if (h->d_lane_scan) hipFree(h->d_lane_scan);
     if (h->h_blob_pin) hipHostFree(h->h_blob_pin);
@@ -1086,7 +1090,10 @@ hipError_t upload_async(void *dst, const void *src_pinned, size_t bytes, hipStre
     if (engine_copies) return hipMemcpyAsync(dst, src_pinned, bytes, hipMemcpyHostToDevice, stream);
     // enough waves to keep PCIe reads in flight (each thread holds four 16-byte loads), not more than the copy needs
     const size_t vec = (bytes + 15) / 16;
-    const uint32_t blocks = uint32_t(std::min<size_t>(std::max<size_t>((vec + 1023) / 1024, 1), 48));      // (0.8 MB in flight: far beyond what PCIe holds; the CUs are for the kernels next to it)
+    // (few blocks: what a launch keeps in flight — blocks x 256 threads x 64 bytes — queues up IN FRONT of every other upload's requests on
+    // the one PCIe link; with 48 blocks per launch and five launches at once the 250 KB of plans took 112 us to cross, behind 4 MB of reads)
+    static const size_t max_blocks = getenv("BOSSX_UPLOAD_BLOCKS") ? size_t(std::max(atoi(getenv("BOSSX_UPLOAD_BLOCKS")), 1)) : 8;
+    const uint32_t blocks = uint32_t(std::min<size_t>(std::max<size_t>((vec + 1023) / 1024, 1), max_blocks));
     hipLaunchKernelGGL(upload_kernel, dim3(blocks), dim3(256), 0, stream, static_cast<uint8_t *>(dst), static_cast<const uint8_t *>(src_pinned), bytes);
     return hipGetLastError();
 }
@@ -1142,15 +1149,15 @@ int check_device_walk(bossx_engine *h, bossx_engine::Staged &st, const ParseInpu
     std::string err;
     int rc = parse_paf_batch(in, h->contigs, h->index, nullptr, pb, err);
     if (rc) return fail(h, BOSSX_E_INVALID, "device walk check: the host walk fails where the device walk passed: " + err);
-    if (pb.n_ops != dev.n_ops || pb.segs.size() != n_segs || pb.tiles.size() != dev.tiles.size() || pb.total_emit != dev.total_emit ||
+    if (pb.n_ops != dev.n_ops || pb.segs.size() != n_segs || pb.tiles.size() != dev.n_groups || pb.total_emit != dev.total_emit ||
         pb.n_touched_tiles != dev.n_touched_tiles)
         return fail(h, BOSSX_E_INVALID, "device walk check: counts differ (runs " + std::to_string(dev.n_ops) + " vs " + std::to_string(pb.n_ops) +
                                            ", segments " + std::to_string(n_segs) + " vs " + std::to_string(pb.segs.size()) +
-                                           ", groups " + std::to_string(dev.tiles.size()) + " vs " + std::to_string(pb.tiles.size()) + ")");
+                                           ", groups " + std::to_string(dev.n_groups) + " vs " + std::to_string(pb.tiles.size()) + ")");
     std::vector<EmitOp> ops(pb.n_ops), dops(pb.n_ops);
     for (const OpsChunk &ck : pb.chunks) memcpy(ops.data() + ck.dev_off, ck.host, ck.n * sizeof(EmitOp));
     std::vector<TileSeg> dsegs(n_segs);
-    std::vector<TileRef> dgroups(dev.tiles.size());
+    std::vector<TileRef> dgroups(dev.n_groups);
     if (pb.n_ops) HIPCHK(hipMemcpy(dops.data(), st.d_ops, pb.n_ops * sizeof(EmitOp), hipMemcpyDeviceToHost));
     if (n_segs) HIPCHK(hipMemcpy(dsegs.data(), st.d_segs, n_segs * sizeof(TileSeg), hipMemcpyDeviceToHost));
     if (!dgroups.empty()) HIPCHK(hipMemcpy(dgroups.data(), st.d_tilerefs, dgroups.size() * sizeof(TileRef), hipMemcpyDeviceToHost));
@@ -1243,8 +1250,13 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
     // ---- the caller's share of pass 1's parallel region --------------------------------------
     h->read_dirty.assign(size_t(n_reads), 0);
     const int n_g = blob_bytes > (size_t(1) << 20) ? parse_threads() : (n_reads > 0 ? 1 : 0);
-    const int n_c = host_walk ? 0 : (in.paf_len > (size_t(1) << 20) ? 4 : (in.paf_len ? 1 : 0));
+    // the PAF text in slices of ~384 KB (round 5: four slices behind the line tasks — the device walk then waited for the text's
+    // upload, which started when the lines were done): copied and handed to the upload stream before anything else
+    const int n_c = host_walk ? 0 : (in.paf_len > (size_t(1) << 20) ? int(std::min<size_t>(32, (in.paf_len + (size_t(384) << 10) - 1) / (size_t(384) << 10))) : (in.paf_len ? 1 : 0));
     in.extra_n = n_g + n_c;
+    // ... and then the gather of the reads, BEFORE the line tasks: the 12 MB of reads are 0.3-0.4 ms of PCIe, the longest single item
+    // of a staging — started behind the lines they arrived last of all (A/B on one box: 1.61-1.72 -> 1.55-1.61 ms per lone update)
+    in.extra_first = getenv("BOSSX_TEXT_LAST") ? 0 : (getenv("BOSSX_GATHER_LAST") ? n_c : n_c + n_g);
     // Every slice goes up as soon as it is gathered (the worker that filled it issues the copy, on a
     // stream of its own): the PCIe transfer of the 24 MB of reads overlaps with the gather instead
     // of following it.  The text slices come first and travel on a third stream: the device walk
@@ -1306,8 +1318,9 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
         for (int i = 0; i < bossx_engine::kUpStreams && up_err == hipSuccess; ++i) up_err = hipEventRecord(h->ev_ups[i], h->stream_ups[i]);
         if (!defer_reads || any_dirty.load()) await_reads();
     };
-    ParsedBatch pb;
+    ParsedBatch pb = std::move(st.pb);      // (the slot's previous batch is gone: its vectors' memory is reused — ParsedBatch::reset)
     uint32_t dev_n_segs = 0;
+    bool expand_enqueued = false;
     const auto t_pre = std::chrono::steady_clock::now();
     if (host_walk) {
         if ((rc = stage_host_walk(h, st, in, summary, pb))) return rc;
@@ -1328,7 +1341,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
         auto t_launched = std::chrono::steady_clock::now(), t_plans = t_launched;
         in.early_walk = [&](ParsedBatch &pbe) {
             t_plans = std::chrono::steady_clock::now();
-            n_plans = uint32_t(pbe.plans.size()); n_groups = uint32_t(pbe.tiles.size());
+            n_plans = uint32_t(pbe.plans.size()); n_groups = uint32_t(pbe.n_groups);
             if (!n_plans) return;
             auto go = [&]() -> int {
                 int rc2;
@@ -1352,15 +1365,24 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                 if ((rc2 = grow_dev(h, &st.d_tiles, &st.tiles_cap, size_t(pbe.total_emit / kEmitTile) + 2, 64))) return rc2;
                 const size_t n_walk = size_t(n_plans) * 3 + 1 + size_t(n_groups) * 2 + 4;
                 if ((rc2 = grow_dev(h, &h->d_walk, &h->d_walk_cap, n_walk, 64))) return rc2;
-                plan_bytes = size_t(n_plans) * sizeof(MapPlan); group_bytes = size_t(n_groups) * sizeof(TileRef);
+                // the groups travel as the bitmap of touched (tile, barcode) keys + the rank of every word: build_groups_kernel writes the list
+                const size_t n_words = pbe.marks.size();
+                const size_t marks_bytes = n_words * sizeof(uint64_t), rank_bytes = ((n_words + 1) * sizeof(uint32_t) + 7) & ~size_t(7);
+                plan_bytes = size_t(n_plans) * sizeof(MapPlan); group_bytes = marks_bytes + rank_bytes;
                 if ((rc2 = grow_pin(h, &h->h_plan_pin, &h->plan_pin_cap, plan_bytes + group_bytes + size_t(n_plans) * 4 + 64))) return rc2;
+                if ((rc2 = grow_dev(h, &h->d_marks, &h->d_marks_cap, group_bytes + 64, 4096))) return rc2;
                 lap("the buffer checks");
                 memcpy(h->h_plan_pin, pbe.plans.data(), plan_bytes);
-                memcpy(h->h_plan_pin + plan_bytes, pbe.tiles.data(), group_bytes);
+                memcpy(h->h_plan_pin + plan_bytes, pbe.marks.data(), marks_bytes);
+                memcpy(h->h_plan_pin + plan_bytes + marks_bytes, pbe.rank.data(), (n_words + 1) * sizeof(uint32_t));
                 lap("the copies into the page-locked plan buffer");
                 HIPCHK(upload_async(h->d_plans, h->h_plan_pin, plan_bytes, h->stream_stage));
                 lap("the plans' upload");
-                HIPCHK(upload_async(st.d_tilerefs, h->h_plan_pin + plan_bytes, group_bytes, h->stream_stage));
+                HIPCHK(upload_async(h->d_marks, h->h_plan_pin + plan_bytes, group_bytes, h->stream_stage));
+                if (n_words)
+                    hipLaunchKernelGGL(build_groups_kernel, dim3(uint32_t((n_words + 255) / 256)), dim3(256), 0, h->stream_stage,
+                                       reinterpret_cast<const unsigned long long *>(h->d_marks), reinterpret_cast<const uint32_t *>(h->d_marks + marks_bytes),
+                                       uint32_t(n_words), uint32_t(h->nb), st.d_tilerefs);
                 lap("the groups' upload");
                 HIPCHK(hipMemsetAsync(h->d_walk, 0, n_walk * sizeof(uint32_t), h->stream_stage));
                 lap("the hipMemsetAsync");
@@ -1377,6 +1399,12 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                 HIPCHK(hipGetLastError());
                 back = reinterpret_cast<uint32_t *>(h->h_plan_pin + plan_bytes + group_bytes);
                 HIPCHK(hipMemcpyAsync(back, W.totals, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream_stage));
+                if (!h->ev_walk) HIPCHK(hipEventCreateWithFlags(&h->ev_walk, hipEventDisableTiming));
+                HIPCHK(hipEventRecord(h->ev_walk, h->stream_stage));
+                // what the expansion writes (sized from what the host knows: every emitted base, the upper bound of the segments)
+                if ((rc2 = grow_dev(h, &st.d_codes, &st.codes_cap, size_t(pbe.total_emit) + kCodePad + size_t(kExpandTile) + 32, 4096))) return rc2;
+                if ((rc2 = grow_dev(h, &st.d_pieces, &st.pieces_cap, pbe.segs_cap, 64))) return rc2;
+                if (!st.d_err) { if ((rc2 = dev_alloc(h, &st.d_err, 1, false))) return rc2; }
                 lap("the three launches + the copy back");
                 return BOSSX_OK;
             };
@@ -1402,10 +1430,26 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                 hipLaunchKernelGGL(check_bases_kernel, dim3((n_plans + 3) / 4), dim3(256), 0, h->stream_stage, W);
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipMemcpyAsync(back, W.totals, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream_stage));
+                HIPCHK(hipEventRecord(h->ev_walk, h->stream_stage));
             }
-            HIPCHK(hipStreamSynchronize(h->stream_stage));
-            memcpy(totals, back, sizeof(totals));
             await_reads(); HIPCHK(up_err);                 // (ordered before the kernels that read the bases)
+            // ---- per-base codes and per-segment pieces, enqueued BEFORE the host looks at the walk's verdict (round 6): the kernel
+            // takes the counts from the walk's totals in HBM and does nothing if the walk refused the batch, so the GPU goes from the
+            // walk straight into the expansion (round 5: walk -> copy back -> host wakes up -> launch: ~35 us of an idle GPU)
+            if (pb.total_emit) {
+                ExpandParams X;
+                X.ops = st.d_ops; X.n_ops = 0; X.total_emit = uint32_t(pb.total_emit); X.totals = W.totals;
+                X.blob = st.d_blob; X.codes = st.d_codes; X.segs = st.d_segs; X.n_segs = 0; X.pieces = st.d_pieces;
+                HIPCHK(hipMemsetAsync(st.d_err, 0, sizeof(int32_t), h->stream_stage));
+                X.err_flag = st.d_err;
+                X.code_blocks = (X.total_emit + uint32_t(kExpandTile) - 1u) / uint32_t(kExpandTile);
+                X.tile_op = st.d_tiles;
+                hipLaunchKernelGGL(expand_codes_kernel, dim3(X.code_blocks + uint32_t((pb.segs_cap + 255) / 256)), dim3(256), 0, h->stream_stage, X);
+                HIPCHK(hipGetLastError());
+                expand_enqueued = true;
+            }
+            HIPCHK(hipEventSynchronize(h->ev_walk));       // the walk's totals are in host memory (the expansion runs on)
+            memcpy(totals, back, sizeof(totals));
             if (totals[2]) {
                 walk_err.resize(n_plans);
                 HIPCHK(hipMemcpy(walk_err.data(), W.walk_err, size_t(n_plans) * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1454,17 +1498,17 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                     std::chrono::duration<double, std::milli>(t_launched - t_plans).count(), std::chrono::duration<double, std::milli>(t1 - t_launched).count(),
                     std::chrono::duration<double, std::milli>(t2 - t1).count(), n_plans, totals[0], totals[1], n_groups);
         }
-        pb.plans.clear(); pb.plans.shrink_to_fit();
+        pb.plans.clear();
         pb.plan_read.clear(); pb.plan_gi.clear();
     }
     // ---- per-base codes and per-segment pieces: what the sweep's gather reads (asynchronous; the batch
     // has passed every check, and the read blob's upload is ordered before this point) --------------
     st.n_segs = host_walk ? uint32_t(pb.segs.size()) : dev_n_segs;
-    if (pb.n_ops) {
+    if (pb.n_ops && !expand_enqueued) {
         if ((rc = grow_dev(h, &st.d_codes, &st.codes_cap, size_t(pb.total_emit) + kCodePad + size_t(kExpandTile) + 32, 4096))) return rc;
         if ((rc = grow_dev(h, &st.d_pieces, &st.pieces_cap, size_t(st.n_segs), 64))) return rc;
         ExpandParams X;
-        X.ops = st.d_ops; X.n_ops = uint32_t(pb.n_ops); X.total_emit = uint32_t(pb.total_emit);
+        X.ops = st.d_ops; X.n_ops = uint32_t(pb.n_ops); X.total_emit = uint32_t(pb.total_emit); X.totals = nullptr;
         X.blob = st.d_blob; X.codes = st.d_codes; X.segs = st.d_segs; X.n_segs = st.n_segs; X.pieces = st.d_pieces;
         // (the slot's own error word: a batch staged ahead must not raise in the update of the batch before it)
         if (!st.d_err) { if ((rc = dev_alloc(h, &st.d_err, 1, false))) return rc; }
@@ -1630,7 +1674,7 @@ int launch_sweep(bossx_engine *h) {
         const double mean = double(c.cov_total) / double(c.length * int64_t(h->nb));
         thr[k] = (!c.remote && mean > 5) ? int32_t(mean / 8) : -1;
     }
-    const size_t n_groups = h->pending_slot >= 0 ? h->slots[size_t(h->pending_slot)].pb.tiles.size() : 0;
+    const size_t n_groups = h->pending_slot >= 0 ? h->slots[size_t(h->pending_slot)].pb.n_groups : 0;
     const size_t n_touched = h->pending_slot >= 0 ? h->slots[size_t(h->pending_slot)].pb.n_touched_tiles : 0;
     // With several barcodes a touched tile costs nb scoring passes at the ingest variant's low
     // occupancy (LDS staging, 4 blocks/CU): split the work instead — an ingest-only launch applies
@@ -1710,7 +1754,7 @@ int launch_sweep(bossx_engine *h) {
         h->work_ctr_used = 0;
         if (h->pending_slot >= 0) {
             const bossx_engine::Staged &st = h->slots[size_t(h->pending_slot)];
-            PR.tiles = st.d_tilerefs; PR.n_tiles = uint32_t(st.pb.tiles.size());
+            PR.tiles = st.d_tilerefs; PR.n_tiles = uint32_t(st.pb.n_groups);
         }
         if (thr.size() <= 32) {
             PR.n_thr = int32_t(thr.size());
@@ -1733,7 +1777,7 @@ int launch_sweep(bossx_engine *h) {
     // part, the chain's candidates kernel looks at the tiles' stamps first (its quick way out); where most chunks change it would only
     // pay a round trip in front of its loads
     {
-        double tiles = full ? double(h->n_tiles) : double(h->pending_slot >= 0 ? h->slots[size_t(h->pending_slot)].pb.tiles.size() : 0);
+        double tiles = full ? double(h->n_tiles) : double(h->pending_slot >= 0 ? h->slots[size_t(h->pending_slot)].pb.n_groups : 0);
         if (!full) for (size_t k : resweep) tiles += double(h->contigs[size_t(h->filt[k])].n_tiles);
         h->sweep_tile_share = h->n_tiles > 0 ? tiles / double(h->n_tiles) : 1.0;
         h->tile_share_fresh = true;

@@ -150,8 +150,13 @@ struct ParsedBatch {
     std::vector<OpsChunk> chunks;
     size_t n_ops = 0;
     std::vector<TileSeg> segs;             // grouped by tile; op_lo/op_hi are device indices
-    std::vector<TileRef> tiles;            // (tile, barcode) groups, ascending
+    std::vector<TileRef> tiles;            // (tile, barcode) groups, ascending (host walk; the device walk builds the list in HBM from `marks`)
+    size_t n_groups = 0;                   // how many of them
     size_t n_touched_tiles = 0;            // distinct tiles among them
+    // device walk: one bit per (tile, barcode) key = tile * nbarcodes + barcode that some mapping touches, and per 64-bit word
+    // the number of bits set in front of it — 11 KB for chr20+21 where the group list itself is 218 KB (build_groups_kernel)
+    std::vector<uint64_t> marks;
+    std::vector<uint32_t> rank;
     uint64_t total_emit = 0;
     std::vector<uint64_t> emitted_per_contig;   // indexed by contig add order
     int32_t n_rec = 0;
@@ -164,6 +169,14 @@ struct ParsedBatch {
     int64_t pre_range_gi = -1; std::string pre_range_msg;            // first IndexError class failure of the pre-pass
     size_t ops_cap = 0, segs_cap = 0;      // capacities the device buffers need
     bool any_check_bases = false;          // some plan was flagged kPlanCheckBases after early_walk had been called
+    // Empty again, but with the vectors' memory kept: a batch's plans / groups are ~1 MB, fresh from mmap with every call they
+    // cost a page fault per 4 KB — 0.15-0.2 ms of the SERIAL part of a lone update's staging (round 6).
+    void reset() {
+        chunks.clear(); n_ops = 0; segs.clear(); tiles.clear(); n_groups = 0; n_touched_tiles = 0; total_emit = 0; emitted_per_contig.clear(); n_rec = 0;
+        marks.clear(); rank.clear();
+        plans.clear(); plan_read.clear(); plan_gi.clear(); pre_code = 0; pre_msg.clear(); pre_gi = -1; pre_range_gi = -1; pre_range_msg.clear();
+        ops_cap = segs_cap = 0; any_check_bases = false;
+    }
 };
 
 struct ParseInput {
@@ -188,6 +201,7 @@ struct ParseInput {
     // `after_pass1` runs on the calling thread right after that region (start the uploads).
     std::function<void(int)> extra_fn;
     int extra_n = 0;
+    int extra_first = 0;         // how many of them the workers take BEFORE the line tasks (where the caller takes no task itself: streamed grouping)
     std::function<void()> after_pass1;
     // device walk: called with the finished plans / groups BEFORE the caller's extra tasks are collected
     // (the plans carry no kPlanCheckBases flags yet: ParsedBatch::any_check_bases tells whether a

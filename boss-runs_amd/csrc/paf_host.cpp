@@ -39,6 +39,7 @@ namespace {
 
 struct Rec {
     std::string qname, tname;
+    int32_t cidx = -1;               // index of tname in the contig table (-1: not there), resolved by the line task
     int64_t qlen, qstart, qend, tstart, tend, alnlen, mapq, as;
     bool rev;
     const char *cg; size_t cg_len;   // points into the PAF text
@@ -260,7 +261,7 @@ struct LineOut {
 //   alignment block length that is not an integer   TypeError      (str < int, paf.py:666)
 // Other non-integer columns stay strings there and only matter if the path computes with them
 // (Rec::bad_cols; the unused ones — tlen, number of matches — never do).
-void parse_lines(const char *p, const char *end, int64_t min_len, LineOut &lo) {
+void parse_lines(const char *p, const char *end, int64_t min_len, LineOut &lo, const std::unordered_map<std::string, int32_t> *contig_index = nullptr) {
     std::vector<std::string_view> f;
     auto fail = [&](int code, const char *msg) { lo.err_line = lo.n_lines; lo.err_code = code; lo.err_msg = msg; };
     while (p < end) {
@@ -330,6 +331,10 @@ void parse_lines(const char *p, const char *end, int64_t min_len, LineOut &lo) {
         r.key_err = (r.bad_cols & (1u << 11)) ? BOSSX_E_PARSE : (mapq_big || as_big) ? BOSSX_E_OVERFLOW : 0;
         r.qname = normalise_name(f[0]);
         r.tname = normalise_name(f[5]);
+        if (contig_index) {              // (a read-only table: looked up here, in parallel, instead of in the serial pre-pass)
+            if (!lo.recs.empty() && lo.recs.back().tname == r.tname) r.cidx = lo.recs.back().cidx;
+            else { auto it = contig_index->find(r.tname); r.cidx = it != contig_index->end() ? it->second : -1; }
+        }
         lo.recs.push_back(std::move(r));
     }
 }
@@ -572,6 +577,8 @@ class WorkPool {
         std::atomic<int> next_first{0}, next_rest{0}, pending_first{0}, pending{0};
     };
     static WorkPool &get() { static WorkPool p; return p; }
+    // worker threads a job of n tasks would run on (besides the caller)
+    int workers_for(int n) { ensure(n - 1); std::lock_guard<std::mutex> lk(m_); return int(threads_.size()); }
     void run(int n, const std::function<void(int)> &fn) {
         auto job = start(n, n, fn);
         if (job) wait_all(*job);
@@ -703,7 +710,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
                     const std::unordered_map<std::string, int32_t> &contig_index,
                     bossx_batch_summary *summary, ParsedBatch &out, std::string &err) {
     PT(T0);
-    out = ParsedBatch();
+    out.reset();                     // (keeps the vectors' memory: see ParsedBatch::reset)
     out.emitted_per_contig.assign(contigs.size(), 0);
 
     // read id -> index in the batch (built by one task of pass 1's parallel region): open addressing over
@@ -768,7 +775,11 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
     // with the grouping and the plans as soon as THOSE are done — then whatever independent work the
     // caller brought along (gathering the reads, copying the text, their uploads), which the workers
     // finish meanwhile and which is collected before the device walk is launched.
-    std::vector<Group> groups;
+    // (scratch that keeps its memory between calls, like ParsedBatch: fresh 100-350 KB vectors come from mmap and fault page by page)
+    // (bound to plain references: a lambda that runs on a pool thread would otherwise see THAT thread's instance of a thread_local)
+    static thread_local std::vector<Group> tl_groups;
+    std::vector<Group> &groups = tl_groups;
+    groups.clear();
     // Many small line ranges, pulled dynamically: a worker that wakes up late finds nothing left instead of
     // holding a sixteenth of the text back (one straggler used to set the pace: 0.28 ms against a mean of 0.06).
     size_t task_kb = 48;
@@ -784,6 +795,9 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         cuts[size_t(t)] = nl ? nl + 1 : in.paf + in.paf_len;
     }
     std::vector<LineOut> los(static_cast<size_t>(nt));
+    // (line task t has left its records: the calling thread groups them in line order WHILE the later tasks still run)
+    std::unique_ptr<std::atomic<uint8_t>[]> line_done(new std::atomic<uint8_t>[size_t(nt)]);
+    for (int t = 0; t < nt; ++t) line_done[size_t(t)].store(0, std::memory_order_relaxed);
     const bool trace = getenv("BOSSX_STAGE_TIMING") != nullptr;
     std::vector<double> tb, te;
     const auto r0 = std::chrono::steady_clock::now();
@@ -791,7 +805,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
     if (trace) { tb.assign(size_t(n_tasks), 0.0); te.assign(size_t(n_tasks), 0.0); }
     const std::function<void(int)> pass1_fn = [&](int t) {
         if (trace) tb[size_t(t)] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count();
-        if (t < nt) parse_lines(cuts[size_t(t)], cuts[size_t(t) + 1], in.min_len, los[size_t(t)]);
+        if (t < nt) { parse_lines(cuts[size_t(t)], cuts[size_t(t) + 1], in.min_len, los[size_t(t)], &contig_index); line_done[size_t(t)].store(1, std::memory_order_release); }
         else if (t == nt) build_read_index();
         else in.extra_fn(t - nt - 1);
         if (trace) te[size_t(t)] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count();
@@ -811,16 +825,31 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         }
         if (in.after_pass1) in.after_pass1();
     };
-    pass1.job = WorkPool::get().start(n_tasks, nt, pass1_fn);       // (the caller goes on once the LINES are done)
+    // Streamed grouping (round 6): with enough workers the calling thread takes no line task — it consumes the tasks' records in
+    // line order as they appear (the grouping is inherently serial; it used to START when the last line task had finished).
+    // BOSSX_STREAM_GROUPING=0: the caller parses lines too and groups afterwards.
+    static const bool stream_env = !(getenv("BOSSX_STREAM_GROUPING") && atoi(getenv("BOSSX_STREAM_GROUPING")) == 0);
+    const bool streamed = stream_env && in.device_walk && !in.summary_only && nt >= 8 && WorkPool::get().workers_for(n_tasks) >= 4;
+    // Order in which the workers pull the tasks when the caller takes none: the name index first (the grouping waits for it at the
+    // first record that is out of order — as task nt it started when the lines were done and ended 0.09 ms after them), then the
+    // caller's `extra_first` tasks (copies of the PAF text: the device walk needs the text in HBM, and the upload needs nothing of
+    // the parse), the lines, the rest of the caller's tasks.
+    std::vector<int> task_order(static_cast<size_t>(n_tasks));
+    for (int j = 0; j < n_tasks; ++j) task_order[size_t(j)] = j;
+    if (streamed) {
+        const int ef = std::min(std::max(in.extra_first, 0), in.extra_n);
+        int j = 0;
+        task_order[size_t(j++)] = nt;
+        for (int e = 0; e < ef; ++e) task_order[size_t(j++)] = nt + 1 + e;
+        for (int t = 0; t < nt; ++t) task_order[size_t(j++)] = t;
+        for (int e = ef; e < in.extra_n; ++e) task_order[size_t(j++)] = nt + 1 + e;
+    }
+    const std::function<void(int)> pass1_ordered = [&](int j) { pass1_fn(task_order[size_t(j)]); };
+    pass1.job = WorkPool::get().start(n_tasks, streamed ? 0 : nt, pass1_ordered);       // (the caller goes on once the LINES are done — or, streamed, at once)
     if (!pass1.job) index_ready.store(true);                         // everything ran inline
     if (trace) fprintf(stderr, "  [pass1] lines + name index done after %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count());
     if (!in.device_walk || in.summary_only) collect_pass1();     // nothing to overlap with on these paths
     {
-        int64_t line_base = 0;
-        for (const LineOut &lo : los) {          // first failing line in file order
-            if (lo.err_line) { err = "PAF line " + std::to_string(line_base + lo.err_line) + lo.err_msg; return lo.err_code; }
-            line_base += lo.n_lines;
-        }
         // best record per query name, groups in first-appearance order.  Names are resolved to batch
         // indices here; only names that are NOT in the batch — a KeyError for the reference — need a
         // map of their own.
@@ -831,62 +860,73 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         // at the first record that is out of order.  Duplicate names in the batch (a dict keeps the last
         // one; impossible from a Python dict, possible through the C-ABI) show when the index is done:
         // the grouping is then repeated on freshly parsed lines with index lookups only.
-        auto do_grouping = [&](bool use_cursor) {
-            std::vector<int32_t> group_of_read(size_t(in.n_reads), -1);
-            std::unordered_map<std::string_view, int32_t> group_of_unknown;
-            size_t n_recs = 0;
-            for (const LineOut &lo : los) n_recs += lo.recs.size();
+        static thread_local std::vector<int32_t> tl_group_of_read;
+        std::vector<int32_t> &group_of_read = tl_group_of_read;
+        std::unordered_map<std::string_view, int32_t> group_of_unknown;
+        int32_t cursor = -1;
+        auto group_reset = [&]() {
+            group_of_read.assign(size_t(in.n_reads), -1);
+            group_of_unknown.clear();
             groups.clear();
-            groups.reserve(n_recs);
-            int32_t cursor = -1;
-            for (LineOut &lo : los) {
-                for (Rec &r : lo.recs) {
-                    int32_t read = -1;
-                    const std::string_view qn(r.qname);
-                    if (use_cursor) {
-                        // the previous record's read, or one of the next few of the batch (reads without a
-                        // surviving mapping are skipped over): a handful of name compares, no hash
-                        if (cursor >= 0 && read_name(cursor) == qn) read = cursor;
-                        else
-                            for (int32_t k = cursor + 1, ke = std::min<int64_t>(int64_t(cursor) + 25, in.n_reads); k < ke; ++k)
-                                if (read_name(k) == qn) { read = k; break; }
-                    }
-                    if (read < 0) {
-                        wait_index();
-                        read = read_index.find(qn);
-                    }
-                    if (read >= 0) cursor = read;
-                    int32_t *slot = nullptr;
-                    int32_t unknown_slot = -1;
-                    if (read >= 0) slot = &group_of_read[size_t(read)];
-                    else {
-                        auto it = group_of_unknown.find(qn);
-                        if (it != group_of_unknown.end()) unknown_slot = it->second;
-                        slot = &unknown_slot;
-                    }
-                    const int key_err = r.key_err;
-                    if (*slot < 0) {
-                        groups.push_back(Group{&r, r.mapq, r.as, read, 1, key_err});
-                        if (read >= 0) *slot = int32_t(groups.size() - 1);
-                        else group_of_unknown.emplace(std::string_view(r.qname), int32_t(groups.size() - 1));     // (the key views the FIRST record's name: it stays in place)
-                    } else {
-                        Group &g = groups[size_t(*slot)];
-                        ++g.n_recs;
-                        if (!g.key_err) g.key_err = key_err;
-                        // argsort by (mapq, AS), last element wins; stable for ties (paf.py:716-721)
-                        if (r.mapq > g.key_q || (r.mapq == g.key_q && r.as >= g.key_dp)) {
-                            g.key_q = r.mapq; g.key_dp = r.as;
-                            g.best = &r;
-                        }
+            groups.reserve(size_t(in.n_reads) + 64);
+            cursor = -1;
+        };
+        auto group_feed = [&](LineOut &lo, bool use_cursor) {
+            for (Rec &r : lo.recs) {
+                int32_t read = -1;
+                const std::string_view qn(r.qname);
+                if (use_cursor) {
+                    // the previous record's read, or one of the next few of the batch (reads without a
+                    // surviving mapping are skipped over): a handful of name compares, no hash
+                    if (cursor >= 0 && read_name(cursor) == qn) read = cursor;
+                    else
+                        for (int32_t k = cursor + 1, ke = std::min<int64_t>(int64_t(cursor) + 25, in.n_reads); k < ke; ++k)
+                            if (read_name(k) == qn) { read = k; break; }
+                }
+                if (read < 0) {
+                    wait_index();
+                    read = read_index.find(qn);
+                }
+                if (read >= 0) cursor = read;
+                int32_t *slot = nullptr;
+                int32_t unknown_slot = -1;
+                if (read >= 0) slot = &group_of_read[size_t(read)];
+                else {
+                    auto it = group_of_unknown.find(qn);
+                    if (it != group_of_unknown.end()) unknown_slot = it->second;
+                    slot = &unknown_slot;
+                }
+                const int key_err = r.key_err;
+                if (*slot < 0) {
+                    groups.push_back(Group{&r, r.mapq, r.as, read, 1, key_err});
+                    if (read >= 0) *slot = int32_t(groups.size() - 1);
+                    else group_of_unknown.emplace(std::string_view(r.qname), int32_t(groups.size() - 1));     // (the key views the FIRST record's name: it stays in place)
+                } else {
+                    Group &g = groups[size_t(*slot)];
+                    ++g.n_recs;
+                    if (!g.key_err) g.key_err = key_err;
+                    // argsort by (mapq, AS), last element wins; stable for ties (paf.py:716-721)
+                    if (r.mapq > g.key_q || (r.mapq == g.key_q && r.as >= g.key_dp)) {
+                        g.key_q = r.mapq; g.key_dp = r.as;
+                        g.best = &r;
                     }
                 }
             }
         };
-        do_grouping(true);
+        group_reset();
+        int64_t line_base = 0;
+        for (int t = 0; t < nt; ++t) {          // line order: the first failing line in file order is the one reported
+            for (int sp = 0; !line_done[size_t(t)].load(std::memory_order_acquire); ++sp) { if (sp < 4000) __builtin_ia32_pause(); else std::this_thread::yield(); }
+            LineOut &lo = los[size_t(t)];
+            if (lo.err_line) { err = "PAF line " + std::to_string(line_base + lo.err_line) + lo.err_msg; return lo.err_code; }
+            line_base += lo.n_lines;
+            group_feed(lo, true);
+        }
         wait_index();
         if (dup_names) {
-            for (int t = 0; t < nt; ++t) { los[size_t(t)] = LineOut(); parse_lines(cuts[size_t(t)], cuts[size_t(t) + 1], in.min_len, los[size_t(t)]); }
-            do_grouping(false);
+            for (int t = 0; t < nt; ++t) { los[size_t(t)] = LineOut(); parse_lines(cuts[size_t(t)], cuts[size_t(t) + 1], in.min_len, los[size_t(t)], &contig_index); }
+            group_reset();
+            for (int t = 0; t < nt; ++t) group_feed(los[size_t(t)], false);
         }
     }
 
@@ -895,7 +935,9 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
     // out the emit order.  A failing record stops the pre-pass; records before it are still
     // walked so that the first failure in record order is the one reported (the reference
     // raises inside its per-record loop, sequences.py:700-735).
-    std::vector<Plan> plans;
+    static thread_local std::vector<Plan> tl_plans;
+    std::vector<Plan> &plans = tl_plans;
+    plans.clear();
     plans.reserve(groups.size());
     WalkError pre_err, pre_range;
     uint64_t cur_emit = 0;
@@ -913,9 +955,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             break;                      // seqs[rec.qname], sequences.py:708/713
         }
         const int32_t read = groups[gi].read;
-        int32_t cidx = -1;
-        auto ci = contig_index.find(r.tname);
-        if (ci != contig_index.end()) cidx = ci->second;
+        const int32_t cidx = r.cidx;
         if (summary) {
             summary->read_idx[n_rec] = read;
             summary->contig_idx[n_rec] = cidx;
@@ -991,8 +1031,9 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         // lands on a local contig, the (tile, barcode) groups its emitted stretch touches, and the
         // buffer sizes the device needs.  Errors of the pre-pass are reported by the caller after the
         // device walk, so that an earlier record's CIGAR error still wins (record order).
-        static thread_local std::vector<uint64_t> marks;
+        std::vector<uint64_t> &marks = out.marks;
         const size_t n_keys = size_t(in.n_tiles) * size_t(in.nbarcodes);
+        if (n_keys >= (size_t(1) << 32)) { err = "more than 2^32 (tile, barcode) keys"; return BOSSX_E_RANGE; }
         marks.assign((n_keys + 63) / 64, 0);
         out.plans.reserve(plans.size());
         out.plan_read.reserve(plans.size());
@@ -1054,31 +1095,37 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             return BOSSX_E_RANGE;
         }
         PT(T2a);
-        out.n_touched_tiles = 0;
-        uint32_t last_tile = UINT32_MAX;
-        for (size_t w = 0; w < marks.size(); ++w) {
-            uint64_t bits = marks[w];
-            while (bits) {
-                const size_t key = (w << 6) + size_t(__builtin_ctzll(bits));
-                bits &= bits - 1;
-                const uint32_t t = uint32_t(key / size_t(in.nbarcodes)), bc = uint32_t(key % size_t(in.nbarcodes));
-                if (t != last_tile) { ++out.n_touched_tiles; last_tile = t; }
-                out.tiles.push_back(TileRef{t, 0u, 0u, bc});
-            }
-        }
-        // index of every mapping's first (tile, barcode) group in that sorted list: rank of its key among the marked ones
+        // The (tile, barcode) groups = the set bits, in key order: the LIST is built on the device (build_groups_kernel) from the
+        // bitmap and the per-word ranks — the host only counts (round 5 pushed 13.6 k TileRefs here, 0.1 ms of the serial part,
+        // and uploaded 218 KB).  Rank of a key among the marked ones = index of its group.
         {
-            static thread_local std::vector<uint32_t> rank;
+            std::vector<uint32_t> &rank = out.rank;
             rank.resize(marks.size() + 1);
             uint32_t acc = 0;
             for (size_t w = 0; w < marks.size(); ++w) { rank[w] = acc; acc += uint32_t(__builtin_popcountll(marks[w])); }
+            rank[marks.size()] = acc;
+            out.n_groups = acc;
+            if (in.nbarcodes == 1) out.n_touched_tiles = acc;
+            else {
+                out.n_touched_tiles = 0;
+                uint32_t last_tile = UINT32_MAX;
+                for (size_t w = 0; w < marks.size(); ++w) {
+                    uint64_t bits = marks[w];
+                    while (bits) {
+                        const uint32_t key = uint32_t((w << 6) + size_t(__builtin_ctzll(bits)));
+                        bits &= bits - 1;
+                        const uint32_t t = key / uint32_t(in.nbarcodes);
+                        if (t != last_tile) { ++out.n_touched_tiles; last_tile = t; }
+                    }
+                }
+            }
             for (MapPlan &mp : out.plans) {
                 const size_t key = size_t(mp.site0 / kTileSites) * size_t(in.nbarcodes) + size_t(mp.flags & 0xffu);
                 mp.g_first = key < n_keys ? rank[key >> 6] + uint32_t(__builtin_popcountll(marks[key >> 6] & ((1ull << (key & 63)) - 1ull))) : 0u;
             }
         }
         PT(T2b);
-        if (getenv("BOSSX_STAGE_TIMING")) fprintf(stderr, "  [parse] device-walk tail: MapPlans + marks %.3f, groups + ranks %.3f ms\n", PTMS(T2, T2a), PTMS(T2a, T2b));
+        if (getenv("BOSSX_STAGE_TIMING")) fprintf(stderr, "  [parse] device-walk tail: MapPlans + marks %.3f, ranks %.3f ms\n", PTMS(T2, T2a), PTMS(T2a, T2b));
         out.ops_cap = ops_at + 1;
         out.segs_cap = seg_cap + 1;
         out.total_emit = cur_emit;
@@ -1203,6 +1250,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
     }
     PT(T4);
     PTREPORT();
+    out.n_groups = out.tiles.size();
     out.total_emit = cur_emit;
     out.n_rec = n_rec;
     return BOSSX_OK;
@@ -1331,14 +1379,28 @@ extern "C" int bossx_host_parse(const char *const *contig_names, const int64_t *
         if (pd.total_emit != pb.total_emit || pd.n_rec != pb.n_rec || pd.emitted_per_contig != pb.emitted_per_contig)
             return fail(BOSSX_E_INVALID, "device-walk planning: totals differ");
         if (pd.ops_cap < pb.n_ops || pd.segs_cap < pb.segs.size()) return fail(BOSSX_E_INVALID, "device-walk planning: capacity too small");
-        if (pd.tiles.size() != pb.tiles.size() || pd.n_touched_tiles != pb.n_touched_tiles)
+        // the group list as build_groups_kernel writes it from the bitmap and the ranks (front_end.hip.inc), here on the CPU
+        std::vector<TileRef> dg(pd.n_groups);
+        if (pd.rank.size() != pd.marks.size() + 1 || pd.rank.back() != pd.n_groups) return fail(BOSSX_E_INVALID, "device-walk planning: ranks do not add up");
+        for (size_t w = 0; w < pd.marks.size(); ++w) {
+            uint64_t bits = pd.marks[w];
+            uint32_t at = pd.rank[w];
+            while (bits) {
+                const uint32_t key = uint32_t((w << 6) + size_t(__builtin_ctzll(bits)));
+                bits &= bits - 1;
+                if (at >= dg.size()) return fail(BOSSX_E_INVALID, "device-walk planning: rank beyond the group count");
+                const uint32_t t = key / uint32_t(nbarcodes);
+                dg[at++] = TileRef{t, 0u, 0u, key - t * uint32_t(nbarcodes)};
+            }
+        }
+        if (dg.size() != pb.tiles.size() || pd.n_touched_tiles != pb.n_touched_tiles)
             return fail(BOSSX_E_INVALID, "device-walk planning: group count differs");
-        for (size_t i = 0; i < pd.tiles.size(); ++i)
-            if (pd.tiles[i].tile != pb.tiles[i].tile || pd.tiles[i].bc != pb.tiles[i].bc)
+        for (size_t i = 0; i < dg.size(); ++i)
+            if (dg[i].tile != pb.tiles[i].tile || dg[i].bc != pb.tiles[i].bc)
                 return fail(BOSSX_E_INVALID, "device-walk planning: groups differ");
         for (const MapPlan &mp : pd.plans) {       // the group index the device walk starts from
             const uint32_t t0 = uint32_t(mp.site0 / kTileSites), bc = mp.flags & 0xffu;
-            if (mp.span && (mp.g_first >= pd.tiles.size() || pd.tiles[mp.g_first].tile != t0 || pd.tiles[mp.g_first].bc != bc))
+            if (mp.span && (mp.g_first >= dg.size() || dg[mp.g_first].tile != t0 || dg[mp.g_first].bc != bc))
                 return fail(BOSSX_E_INVALID, "device-walk planning: first group of a mapping is wrong");
         }
         uint64_t span_sum = 0;
