@@ -22,6 +22,9 @@
 #include "engine.hpp"
 #include "kernels.hip.inc"
 #include "front_end.hip.inc"
+#include <execinfo.h>
+#include <csignal>
+#include <unistd.h>
 
 using namespace bossx;
 
@@ -492,7 +495,21 @@ hipError_t create_stage_stream(hipStream_t *s) {
 }
 } }
 
+extern "C++" { namespace {
+// BOSSX_BACKTRACE=1: a crash inside the library prints the native frames (module + offset: resolve with addr2line on the same .so)
+void crash_backtrace(int sig) {
+    void *frames[48];
+    const int n = backtrace(frames, 48);
+    const char msg[] = "[bossx] fatal signal, native frames:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+} }
+
 int bossx_create(const bossx_config *cfg, bossx_engine **out) {
+    if (getenv("BOSSX_BACKTRACE")) { signal(SIGFPE, crash_backtrace); signal(SIGSEGV, crash_backtrace); signal(SIGABRT, crash_backtrace); }
     if (!cfg || !out) return BOSSX_E_INVALID;
     *out = nullptr;
     std::unique_ptr<bossx_engine> e(new bossx_engine());
@@ -1254,9 +1271,10 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
     // upload, which started when the lines were done): copied and handed to the upload stream before anything else
     const int n_c = host_walk ? 0 : (in.paf_len > (size_t(1) << 20) ? int(std::min<size_t>(32, (in.paf_len + (size_t(384) << 10) - 1) / (size_t(384) << 10))) : (in.paf_len ? 1 : 0));
     in.extra_n = n_g + n_c;
-    // ... and then the gather of the reads, BEFORE the line tasks: the 12 MB of reads are 0.3-0.4 ms of PCIe, the longest single item
-    // of a staging — started behind the lines they arrived last of all (A/B on one box: 1.61-1.72 -> 1.55-1.61 ms per lone update)
-    in.extra_first = getenv("BOSSX_TEXT_LAST") ? 0 : (getenv("BOSSX_GATHER_LAST") ? n_c : n_c + n_g);
+    // The text slices come first; the gather of the reads BEHIND the line tasks: the device walk needs the text and the plans (lines ->
+    // grouping -> plans, all on the host's critical path), the 12 MB of reads (0.3 ms of PCIe) are wanted only when the walk is over.
+    // (Gather first was tried: alternated update by update in one process — scripts/ab_inproc.py — it costs 0.1 ms; BOSSX_GATHER_FIRST=1.)
+    in.extra_first = getenv("BOSSX_TEXT_LAST") ? 0 : (getenv("BOSSX_GATHER_FIRST") ? n_c + n_g : n_c);
     // Every slice goes up as soon as it is gathered (the worker that filled it issues the copy, on a
     // stream of its own): the PCIe transfer of the 24 MB of reads overlaps with the gather instead
     // of following it.  The text slices come first and travel on a third stream: the device walk

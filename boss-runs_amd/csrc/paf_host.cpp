@@ -352,6 +352,8 @@ struct Plan {
     size_t ops_at;           // where its emit runs start in the caller's buffer (upper-bound spacing)
     int64_t tlo, thi;        // the sites it emits to, [tlo, thi) (np's slice of the coverage array: both ends below zero wrap)
     int64_t q_first, q_len;  // read[q_first] is the first base the walk reads ('-': walks down from there), q_len how many the slice holds
+    uint64_t span_add = 0;   // what it adds to the emit order / to the run capacity (0 for a mapping the walk is not given): summed in
+    size_t ops_add = 0;      // record order once every mapping has been looked at (the look itself runs in parallel)
 };
 
 // seq[start:end] of a Python sequence of n elements: first index and length.
@@ -810,25 +812,10 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         else in.extra_fn(t - nt - 1);
         if (trace) te[size_t(t)] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count();
     };
-    JobGuard pass1;                        // (declared after everything its tasks touch: collected first on every way out)
-    auto collect_pass1 = [&]() {
-        pass1.finish();
-        if (trace) {
-            auto stat = [&](int a, int b, const char *what) {
-                if (b <= a) return;
-                double s0 = 1e9, e1 = 0, dsum = 0, dmax = 0;
-                for (int i = a; i < b; ++i) { s0 = std::min(s0, tb[size_t(i)]); e1 = std::max(e1, te[size_t(i)]); dsum += te[size_t(i)] - tb[size_t(i)]; dmax = std::max(dmax, te[size_t(i)] - tb[size_t(i)]); }
-                fprintf(stderr, "  [pass1] %-6s %2d tasks: first start %.3f, last end %.3f, mean %.3f, max %.3f ms\n", what, b - a, s0, e1, dsum / (b - a), dmax);
-            };
-            stat(0, nt, "parse"); stat(nt, nt + 1, "index"); stat(nt + 1, n_tasks, "extra");
-            fprintf(stderr, "  [pass1] all tasks collected after %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count());
-        }
-        if (in.after_pass1) in.after_pass1();
-    };
     // Streamed grouping (round 6): with enough workers the calling thread takes no line task — it consumes the tasks' records in
     // line order as they appear (the grouping is inherently serial; it used to START when the last line task had finished).
     // BOSSX_STREAM_GROUPING=0: the caller parses lines too and groups afterwards.
-    static const bool stream_env = !(getenv("BOSSX_STREAM_GROUPING") && atoi(getenv("BOSSX_STREAM_GROUPING")) == 0);
+    const bool stream_env = !(getenv("BOSSX_STREAM_GROUPING") && atoi(getenv("BOSSX_STREAM_GROUPING")) == 0);
     const bool streamed = stream_env && in.device_walk && !in.summary_only && nt >= 8 && WorkPool::get().workers_for(n_tasks) >= 4;
     // Order in which the workers pull the tasks when the caller takes none: the name index first (the grouping waits for it at the
     // first record that is out of order — as task nt it started when the lines were done and ended 0.09 ms after them), then the
@@ -845,6 +832,21 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         for (int e = ef; e < in.extra_n; ++e) task_order[size_t(j++)] = nt + 1 + e;
     }
     const std::function<void(int)> pass1_ordered = [&](int j) { pass1_fn(task_order[size_t(j)]); };
+    JobGuard pass1;                        // (declared after everything its tasks touch: collected first on every way out)
+    auto collect_pass1 = [&]() {
+        pass1.finish();
+        if (trace) {
+            auto stat = [&](int a, int b, const char *what) {
+                if (b <= a) return;
+                double s0 = 1e9, e1 = 0, dsum = 0, dmax = 0;
+                for (int i = a; i < b; ++i) { s0 = std::min(s0, tb[size_t(i)]); e1 = std::max(e1, te[size_t(i)]); dsum += te[size_t(i)] - tb[size_t(i)]; dmax = std::max(dmax, te[size_t(i)] - tb[size_t(i)]); }
+                fprintf(stderr, "  [pass1] %-6s %2d tasks: first start %.3f, last end %.3f, mean %.3f, max %.3f ms\n", what, b - a, s0, e1, dsum / (b - a), dmax);
+            };
+            stat(0, nt, "parse"); stat(nt, nt + 1, "index"); stat(nt + 1, n_tasks, "extra");
+            fprintf(stderr, "  [pass1] all tasks collected after %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count());
+        }
+        if (in.after_pass1) in.after_pass1();
+    };
     pass1.job = WorkPool::get().start(n_tasks, streamed ? 0 : nt, pass1_ordered);       // (the caller goes on once the LINES are done — or, streamed, at once)
     if (!pass1.job) index_ready.store(true);                         // everything ran inline
     if (trace) fprintf(stderr, "  [pass1] lines + name index done after %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count());
@@ -931,56 +933,63 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
     }
 
     PT(T1);
-    // ---- pass 2a (sequential, O(#reads)): resolve every chosen mapping, fill the summary, lay
-    // out the emit order.  A failing record stops the pre-pass; records before it are still
-    // walked so that the first failure in record order is the one reported (the reference
-    // raises inside its per-record loop, sequences.py:700-735).
+    // ---- pass 2a: resolve every chosen mapping, fill the summary, lay out the emit order.  A failing
+    // record stops the pre-pass; records before it are still walked so that the first failure in record
+    // order is the one reported (the reference raises inside its per-record loop, sequences.py:700-735).
+    // Round 6: what a record needs of its predecessors is two running sums; everything else about it —
+    // the checks, the slice of the read, the range of sites — is looked at for all records IN PARALLEL
+    // (ranges of records on the pool's workers, idle by now), each range stopping at its own first failure;
+    // the first failure overall, the running sums and the first IndexError-class finding follow in one
+    // cheap serial sweep.  Small batches and hosts without workers take the same code as one range.
     static thread_local std::vector<Plan> tl_plans;
     std::vector<Plan> &plans = tl_plans;
     plans.clear();
-    plans.reserve(groups.size());
-    WalkError pre_err, pre_range;
-    uint64_t cur_emit = 0;
-    size_t ops_at = 0;
-    int32_t n_rec = 0;
-    for (size_t gi = 0; gi < groups.size(); ++gi) {
+    plans.resize(groups.size());
+    struct RangeState {
+        WalkError fail; bool fail_counted = false;      // first failure of the range (fail_counted: the record had reached the summary)
+        WalkError range;                                // first IndexError-class finding of the range
+    };
+    auto plan_one = [&](size_t gi, RangeState &rs) -> bool {       // false: the range stops here
         const Rec &r = *groups[gi].best;
-        auto pre_fail = [&](int code, std::string msg) { pre_err.group = int64_t(gi); pre_err.code = code; pre_err.msg = std::move(msg); };
+        auto pre_fail = [&](int code, std::string msg, bool counted) { rs.fail.group = int64_t(gi); rs.fail.code = code; rs.fail.msg = std::move(msg); rs.fail_counted = counted; };
         if (groups[gi].n_recs > 1 && groups[gi].key_err) {
-            pre_fail(groups[gi].key_err, "read '" + r.qname + "': mapping quality / AS of one of its mappings is not an int64");   // choose_best_mapper, paf.py:716-718
-            break;
+            pre_fail(groups[gi].key_err, "read '" + r.qname + "': mapping quality / AS of one of its mappings is not an int64", false);   // choose_best_mapper, paf.py:716-718
+            return false;
         }
         if (groups[gi].read < 0) {
-            pre_fail(BOSSX_E_KEY, "read '" + r.qname + "' is mapped in the PAF but absent from the batch");
-            break;                      // seqs[rec.qname], sequences.py:708/713
+            pre_fail(BOSSX_E_KEY, "read '" + r.qname + "' is mapped in the PAF but absent from the batch", false);
+            return false;               // seqs[rec.qname], sequences.py:708/713
         }
         const int32_t read = groups[gi].read;
         const int32_t cidx = r.cidx;
-        if (summary) {
-            summary->read_idx[n_rec] = read;
-            summary->contig_idx[n_rec] = cidx;
-            summary->rev[n_rec] = r.rev ? 1 : 0;
-            summary->tstart[n_rec] = r.tstart;
-            summary->tend[n_rec] = r.tend;
-            summary->qlen[n_rec] = r.qlen;
+        // (record gi is entry gi: nothing is skipped in front of a failure, and a failing batch's summary is void — records BEHIND a
+        // read that is not in the batch may have an index beyond the caller's arrays, which hold one entry per read of the batch)
+        if (summary && gi < size_t(in.n_reads)) {
+            summary->read_idx[gi] = read;
+            summary->contig_idx[gi] = cidx;
+            summary->rev[gi] = r.rev ? 1 : 0;
+            summary->tstart[gi] = r.tstart;
+            summary->tend[gi] = r.tend;
+            summary->qlen[gi] = r.qlen;
         }
-        ++n_rec;
-        if (in.summary_only) continue;
+        Plan &pl = plans[gi];
+        pl = Plan{&r, int64_t(gi), read, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (in.summary_only) return true;
         // columns that stayed strings: the reference computes qlen - qend / qlen - qstart on '-' mappings
         // (sequences.py:709-710) before it looks at the CIGAR, slices with qstart / qend on '+' ones only after
         // tokenising it (:790), and takes min / max of the target coordinates after that (:730-731) — a
         // TypeError each, at its place in that order (check_cigar_text); a '+' mapping never looks at qlen
         const uint32_t bad_q = r.bad_cols & ((1u << 2) | (1u << 3) | (r.rev ? (1u << 1) : 0u));
         const uint32_t bad_t = r.bad_cols & ((1u << 7) | (1u << 8));
-        if (r.rev && bad_q) { pre_fail(BOSSX_E_TYPE, "read '" + r.qname + "': query coordinate is not an integer"); break; }
+        if (r.rev && bad_q) { pre_fail(BOSSX_E_TYPE, "read '" + r.qname + "': query coordinate is not an integer", true); return false; }
         if (!r.has_cg) {
-            pre_fail(BOSSX_E_ASSERT, "read '" + r.qname + "': mapping without cg tag");   // assert rec.cigar is not None
-            break;
+            pre_fail(BOSSX_E_ASSERT, "read '" + r.qname + "': mapping without cg tag", true);   // assert rec.cigar is not None
+            return false;
         }
-        if (r.cg_not_str) { pre_fail(BOSSX_E_TYPE, "read '" + r.qname + "': cg tag is not a string"); break; }      // re.findall on an int / float
+        if (r.cg_not_str) { pre_fail(BOSSX_E_TYPE, "read '" + r.qname + "': cg tag is not a string", true); return false; }      // re.findall on an int / float
         const bool local = cidx >= 0 && !contigs[size_t(cidx)].rejected && !contigs[size_t(cidx)].remote;
         const bool remote = cidx >= 0 && !contigs[size_t(cidx)].rejected && contigs[size_t(cidx)].remote;
-        Plan pl{&r, int64_t(gi), read, local ? cidx : -1, 0, cur_emit, ops_at, 0, 0, 0, 0};
+        pl.cidx = local ? cidx : -1;
         const int64_t seq_len = in.seq_len ? in.seq_len[read] : in.seq_off[read + 1] - in.seq_off[read];
         if (!bad_q) read_slice(r, seq_len, pl.q_first, pl.q_len);
         pl.tlo = std::min(r.tstart, r.tend);
@@ -1005,10 +1014,10 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         if (!walk_it && !remote) {
             std::string msg;
             const int code = check_cigar_text(r.cg, r.cg_len, pl.q_len, pl.thi - pl.tlo, !bad_q, !bad_t, msg);
-            if (code) { pre_fail(code, "read '" + r.qname + "': " + msg); break; }
-            if (range_bad && !pre_range.code) {
-                pre_range.group = int64_t(gi); pre_range.code = BOSSX_E_RANGE;
-                pre_range.msg = "read '" + r.qname + "': mapping lies outside " + contigs[size_t(cidx)].name;
+            if (code) { pre_fail(code, "read '" + r.qname + "': " + msg, true); return false; }
+            if (range_bad && !rs.range.code) {
+                rs.range.group = int64_t(gi); rs.range.code = BOSSX_E_RANGE;
+                rs.range.msg = "read '" + r.qname + "': mapping lies outside " + contigs[size_t(cidx)].name;
             }
         }
         if (!walk_it) {
@@ -1016,14 +1025,43 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         } else {
             pl.bc = in.barcodes ? in.barcodes[read] : 0;
             if (pl.bc < 0 || pl.bc >= in.nbarcodes) {
-                if (!pre_range.code) { pre_range.group = int64_t(gi); pre_range.code = BOSSX_E_RANGE; pre_range.msg = "read '" + r.qname + "': barcode index out of range"; }
+                if (!rs.range.code) { rs.range.group = int64_t(gi); rs.range.code = BOSSX_E_RANGE; rs.range.msg = "read '" + r.qname + "': barcode index out of range"; }
                 pl.bc = 0;
             }
-            cur_emit += uint64_t(pl.thi - pl.tlo);
-            ops_at += r.cg_len / 2 + 1;           // every run is at least one digit + one letter
+            pl.span_add = uint64_t(pl.thi - pl.tlo);
+            pl.ops_add = r.cg_len / 2 + 1;            // every run is at least one digit + one letter
         }
-        plans.push_back(pl);
+        return true;
+    };
+    // ranges of records: as many as the pool has hands for, none below ~256 records (BOSSX_PLAN_RANGE: tests force small ranges)
+    const char *plan_range_env = getenv("BOSSX_PLAN_RANGE");
+    const size_t plan_range_min = plan_range_env ? size_t(std::max(atoi(plan_range_env), 1)) : 256;
+    const int pool_hands = getenv("BOSSX_PLAN_SERIAL") ? 1 : (in.n_threads > 0 ? in.n_threads : WorkPool::get().workers_for(64) + 1);
+    const size_t n_ranges = std::max<size_t>(1, std::min<size_t>(size_t(pool_hands), groups.size() / plan_range_min));
+    std::vector<RangeState> range_state(n_ranges);
+    auto range_lo = [&](size_t k) { return groups.size() * k / n_ranges; };
+    {
+        const std::function<void(int)> plan_range = [&](int k) {
+            RangeState &rs = range_state[size_t(k)];
+            for (size_t gi = range_lo(size_t(k)), ge = range_lo(size_t(k) + 1); gi < ge; ++gi)
+                if (!plan_one(gi, rs)) break;
+        };
+        if (n_ranges == 1) plan_range(0); else pool_run(int(n_ranges), plan_range);
     }
+    // the serial sweep: first failure in record order, first IndexError-class finding in front of it, the running sums
+    WalkError pre_err, pre_range;
+    bool pre_err_counted = false;
+    for (RangeState &rs : range_state)
+        if (rs.fail.code && rs.fail.group < pre_err.group) { pre_err = std::move(rs.fail); pre_err_counted = rs.fail_counted; }
+    const size_t n_ok = pre_err.code ? size_t(pre_err.group) : groups.size();      // records in front of the first failure
+    for (RangeState &rs : range_state)
+        if (rs.range.code && rs.range.group < int64_t(n_ok) && rs.range.group < pre_range.group) pre_range = std::move(rs.range);
+    plans.resize(n_ok);
+    uint64_t cur_emit = 0;
+    size_t ops_at = 0;
+    for (Plan &pl : plans) { pl.emit0 = cur_emit; pl.ops_at = ops_at; cur_emit += pl.span_add; ops_at += pl.ops_add; }
+    const int32_t n_rec = int32_t(n_ok) + (pre_err_counted ? 1 : 0);
+    if (in.summary_only) plans.clear();
 
     PT(T2);
     if (in.device_walk && !in.summary_only) {
@@ -1035,60 +1073,89 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         const size_t n_keys = size_t(in.n_tiles) * size_t(in.nbarcodes);
         if (n_keys >= (size_t(1) << 32)) { err = "more than 2^32 (tile, barcode) keys"; return BOSSX_E_RANGE; }
         marks.assign((n_keys + 63) / 64, 0);
-        out.plans.reserve(plans.size());
-        out.plan_read.reserve(plans.size());
-        out.plan_gi.reserve(plans.size());
-        size_t seg_cap = 0;
-        for (const Plan &pl : plans) {
+        // which plans travel: those on a local contig, in front of the first mapping of 2^32 bases or more (a span no contig holds:
+        // the reference fails on it as well; records after it are not walked).  Their slots in the upload are their ranks.
+        static thread_local std::vector<uint32_t> tl_slot;
+        std::vector<uint32_t> &slot = tl_slot;
+        slot.assign(plans.size(), UINT32_MAX);
+        uint32_t n_up = 0;
+        for (size_t i = 0; i < plans.size(); ++i) {
+            const Plan &pl = plans[i];
             if (pl.cidx < 0) continue;
             const Rec &r = *pl.rec;
-            const ContigInfo &c = contigs[size_t(pl.cidx)];
-            const int64_t seq_b = in.seq_off[pl.read], seq_len = in.seq_len ? in.seq_len[pl.read] : in.seq_off[pl.read + 1] - seq_b;
-            const int64_t tlo = pl.tlo, thi = pl.thi;
-            const int64_t q = pl.q_first, q_need = pl.q_len;
-            if (r.cg_len > size_t(UINT32_MAX) || thi - tlo > int64_t(UINT32_MAX)) {
-                // (a span no contig holds: the reference fails on it as well); records after it are not walked
+            if (r.cg_len > size_t(UINT32_MAX) || pl.thi - pl.tlo > int64_t(UINT32_MAX)) {
                 if (!pre_err.code || pl.gi < pre_err.group) {
                     pre_err.group = pl.gi;
-                    pre_err.code = check_cigar_text(r.cg, r.cg_len, q_need, thi - tlo, true, true, pre_err.msg);
+                    pre_err.code = check_cigar_text(r.cg, r.cg_len, pl.q_len, pl.thi - pl.tlo, true, true, pre_err.msg);
                     if (!pre_err.code) { pre_err.code = BOSSX_E_RANGE; pre_err.msg = "mapping of 2^32 bases or more"; }
                     pre_err.msg = "read '" + r.qname + "': " + pre_err.msg;
                 }
                 break;
             }
-            MapPlan mp{};
-            mp.cg_off = uint32_t(size_t(r.cg - in.paf) + size_t(in.paf_base));
-            mp.cg_len = uint32_t(r.cg_len);
-            mp.emit0 = uint32_t(pl.emit0);
-            mp.span = uint32_t(thi - tlo);
-            mp.site0 = uint64_t(c.site_off + tlo);
-            mp.q_rel = int32_t(q);
-            mp.q0 = uint32_t(seq_b + (q >= 0 && q < seq_len ? q : 0));
-            mp.q_need = uint32_t(q_need);
-            mp.seq_b = uint32_t(seq_b);
-            mp.seq_len = uint32_t(seq_len);
-            const int64_t room = c.length - tlo;
-            mp.room = uint32_t(room < 0 ? 0 : (room > int64_t(UINT32_MAX) ? int64_t(UINT32_MAX) : room));
-            mp.ops_cap = uint32_t(r.cg_len / 2 + 1);
-            mp.flags = uint32_t(pl.bc & 0xff) | (r.rev ? kPlanRev : 0u) | (q_need == 1 ? kPlanBroadcast : 0u);      // (kPlanCheckBases: below, once the reads have been looked at)
-            // groups: every sweep tile the stretch [site0, site0 + span) touches, for this barcode.
-            // A stretch that runs past its contig (an IndexError reported by the device walk) is
-            // clipped here so that no key outside the table is marked.
-            int64_t s_end = c.site_off + thi;
-            const int64_t c_end = c.site_off + c.n_tiles * kTileSites;
-            if (s_end > c_end) s_end = c_end;
-            uint32_t ntile = 0;
-            for (int64_t t = int64_t(mp.site0) / kTileSites; thi > tlo && t * kTileSites < s_end; ++t) {      // (a mapping of insertions only emits nothing)
-                const size_t key = size_t(t) * size_t(in.nbarcodes) + size_t(pl.bc);
-                if (key < n_keys) marks[key >> 6] |= 1ull << (key & 63);
-                ++ntile;
+            slot[i] = n_up++;
+        }
+        out.plans.resize(n_up);
+        out.plan_read.resize(n_up);
+        out.plan_gi.resize(n_up);
+        // the MapPlans and the bitmap of touched (tile, barcode) keys: ranges of plans in parallel (bits set with atomic ORs)
+        const size_t n_cr = std::max<size_t>(1, std::min<size_t>(size_t(pool_hands), plans.size() / plan_range_min));
+        std::vector<size_t> seg_part(n_cr, 0);
+        std::vector<std::vector<uint64_t>> emit_part(n_cr, std::vector<uint64_t>(contigs.size(), 0));
+        const std::function<void(int)> map_range = [&](int k) {
+            size_t seg_sum = 0;
+            std::vector<uint64_t> &emitted = emit_part[size_t(k)];
+            for (size_t i = plans.size() * size_t(k) / n_cr, ie = plans.size() * (size_t(k) + 1) / n_cr; i < ie; ++i) {
+                if (slot[i] == UINT32_MAX) continue;
+                const Plan &pl = plans[i];
+                const Rec &r = *pl.rec;
+                const ContigInfo &c = contigs[size_t(pl.cidx)];
+                const int64_t seq_b = in.seq_off[pl.read], seq_len = in.seq_len ? in.seq_len[pl.read] : in.seq_off[pl.read + 1] - seq_b;
+                const int64_t tlo = pl.tlo, thi = pl.thi;
+                const int64_t q = pl.q_first, q_need = pl.q_len;
+                MapPlan mp{};
+                mp.cg_off = uint32_t(size_t(r.cg - in.paf) + size_t(in.paf_base));
+                mp.cg_len = uint32_t(r.cg_len);
+                mp.emit0 = uint32_t(pl.emit0);
+                mp.span = uint32_t(thi - tlo);
+                mp.site0 = uint64_t(c.site_off + tlo);
+                mp.q_rel = int32_t(q);
+                mp.q0 = uint32_t(seq_b + (q >= 0 && q < seq_len ? q : 0));
+                mp.q_need = uint32_t(q_need);
+                mp.seq_b = uint32_t(seq_b);
+                mp.seq_len = uint32_t(seq_len);
+                const int64_t room = c.length - tlo;
+                mp.room = uint32_t(room < 0 ? 0 : (room > int64_t(UINT32_MAX) ? int64_t(UINT32_MAX) : room));
+                mp.ops_cap = uint32_t(r.cg_len / 2 + 1);
+                mp.flags = uint32_t(pl.bc & 0xff) | (r.rev ? kPlanRev : 0u) | (q_need == 1 ? kPlanBroadcast : 0u);      // (kPlanCheckBases: below, once the reads have been looked at)
+                // groups: every sweep tile the stretch [site0, site0 + span) touches, for this barcode.
+                // A stretch that runs past its contig (an IndexError reported by the device walk) is
+                // clipped here so that no key outside the table is marked.
+                int64_t s_end = c.site_off + thi;
+                const int64_t c_end = c.site_off + c.n_tiles * kTileSites;
+                if (s_end > c_end) s_end = c_end;
+                uint32_t ntile = 0;
+                for (int64_t t = int64_t(mp.site0) / kTileSites; thi > tlo && t * kTileSites < s_end; ++t) {      // (a mapping of insertions only emits nothing)
+                    const size_t key = size_t(t) * size_t(in.nbarcodes) + size_t(pl.bc);
+                    if (key < n_keys) {
+                        const uint64_t bit = 1ull << (key & 63);
+                        if (n_cr == 1) marks[key >> 6] |= bit; else __atomic_fetch_or(&marks[key >> 6], bit, __ATOMIC_RELAXED);
+                    }
+                    ++ntile;
+                }
+                mp.seg_cap = mp.span / kSegMax + ntile + 1;
+                seg_sum += mp.seg_cap;
+                emitted[size_t(pl.cidx)] += uint64_t(thi - tlo);
+                out.plans[slot[i]] = mp;
+                out.plan_read[slot[i]] = pl.read;
+                out.plan_gi[slot[i]] = pl.gi;
             }
-            mp.seg_cap = mp.span / kSegMax + ntile + 1;
-            seg_cap += mp.seg_cap;
-            out.emitted_per_contig[size_t(pl.cidx)] += uint64_t(thi - tlo);
-            out.plans.push_back(mp);
-            out.plan_read.push_back(pl.read);
-            out.plan_gi.push_back(pl.gi);
+            seg_part[size_t(k)] = seg_sum;
+        };
+        if (n_cr == 1) map_range(0); else pool_run(int(n_cr), map_range);
+        size_t seg_cap = 0;
+        for (size_t k = 0; k < n_cr; ++k) {
+            seg_cap += seg_part[k];
+            for (size_t c = 0; c < contigs.size(); ++c) out.emitted_per_contig[c] += emit_part[k][c];
         }
         if (cur_emit >= (1ull << 32) - kEmitTile) {
             err = "batch too large: more than 2^32 aligned bases";

@@ -290,13 +290,16 @@ def _oracle_expansion(paf_text, seqs, contig_names, barcodes=None, min_len=200):
     return cat(oc, np.int32), cat(op, np.int64), cat(ocode, np.uint8), cat(obc, np.uint8)
 
 
-@pytest.mark.parametrize("threads", [1, 3, 8])
-def test_native_parser_vs_oracle_expansion(threads):
+@pytest.mark.parametrize("threads", [1, 3, 8, -3])
+def test_native_parser_vs_oracle_expansion(threads, monkeypatch):
     """The C++ PAF/CIGAR front end (threaded line parse + CIGAR walk, tile segments) against the
     oracle's restatement of Paf.parse_PAF / choose_best_mapper / _parse_cigar, base by base, on
     the golden CIGAR fixture and on a synthetic 1500-read batch.  No device involved."""
     from boss_runs_amd import synth
     from boss_runs_amd.engine import host_parse
+    if threads < 0:         # (three threads, the pre-pass over the chosen mappings in ranges of 50 records: its parallel form)
+        threads = -threads
+        monkeypatch.setenv("BOSSX_PLAN_RANGE", "50")
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g_cigar.npz"))
     paf_text = g["paf"].tobytes().decode()
     seqs = dict(zip(g["read_ids"].tolist(), g["read_seqs"].tolist()))
@@ -564,13 +567,16 @@ def test_readlength_fast_path_equals_float_scan():
     assert np.array_equal(p.approx_ccl, o.approx_ccl) and p.lam == o.lam and p.longest_read == o.longest_read == 3000
 
 
-def test_native_front_end_error_classes_equal_the_reference():
+@pytest.mark.parametrize("plan_range", [None, "1"])
+def test_native_front_end_error_classes_equal_the_reference(plan_range, monkeypatch):
     """The native PAF / CIGAR front end against tests/golden/g_errors.json (what the reference itself does
     with 60-odd malformed / unusual batches, scenarios.error_cases): the same exception class where the
     reference raises, the same coverage where it does not — truncated lines (IndexError), non-integer
     columns (TypeError only where the reference ever looks at them), tag syntax (ValueError / KeyError),
     CIGAR text the reference's regex skips over, shape mismatches (ValueError) vs span assertions
     (AssertionError), reads with other letters (IndexError) ..."""
+    if plan_range:          # (the pre-pass in ranges of one record on the pool's threads: see the fuzz test below)
+        monkeypatch.setenv("BOSSX_PLAN_RANGE", plan_range)
     import json
     from scenarios import GOLDEN, digest, error_cases
     from boss_runs_amd.engine import host_parse
@@ -595,8 +601,12 @@ def test_native_front_end_error_classes_equal_the_reference():
     assert not bad, bad
 
 
-def test_native_front_end_fuzz_error_classes_equal_the_reference():
-    """The native PAF / CIGAR front end (bossx_host_parse: line parser, grouping, pre-pass, host walk, and the plans
+@pytest.mark.parametrize("plan_range", [None, "1"])
+def test_native_front_end_fuzz_error_classes_equal_the_reference(plan_range, monkeypatch):
+    """(`plan_range` = "1": the pre-pass over the chosen mappings split into ranges of ONE record on the pool's threads — the form a
+    4000-read batch takes with ranges of 256+, forced onto these small batches: the first failure in record order, the summary, the
+    running sums and the bitmap of touched tiles must come out as from the single range.)
+    The native PAF / CIGAR front end (bossx_host_parse: line parser, grouping, pre-pass, host walk, and the plans
     of the device walk) against tests/golden/g_errors_fuzz.json — what the reference itself does with 2,000 seeded
     random mutations (scenarios.fuzz_error_cases), case by case: the same exception class where it raises, the same
     coverage where it goes on (Python slicing of the read and of the coverage array included: a qlen column of 0
@@ -604,6 +614,8 @@ def test_native_front_end_fuzz_error_classes_equal_the_reference():
     import json
     from scenarios import GOLDEN, digest, fuzz_error_cases
     from boss_runs_amd.engine import host_parse
+    if plan_range:
+        monkeypatch.setenv("BOSSX_PLAN_RANGE", plan_range)
     contigs, cases = fuzz_error_cases()
     gold = json.load(open(os.path.join(GOLDEN, "g_errors_fuzz.json")))
     clist = [(n, c.shape[0], 0) for n, c in contigs]
