@@ -211,6 +211,7 @@ struct bossx_engine {
     std::vector<int32_t> drop_thr_host;
     // timing
     bool timing = false;
+    int timing_only = -1;       // >= 0: only this kernel is bracketed by events (every event pair is two marker packets between the update's kernels)
     hipEvent_t ev0[BOSSX_K_COUNT]{}, ev1[BOSSX_K_COUNT]{};
     bool ev_pending[BOSSX_K_COUNT]{};
     float ms_last[BOSSX_K_COUNT]{};
@@ -288,7 +289,7 @@ int join_chain(bossx_engine *h) {
 }
 
 void time_begin(bossx_engine *h, int k, hipStream_t stream = nullptr) {
-    if (!h->timing) return;
+    if (!h->timing || (h->timing_only >= 0 && k != h->timing_only)) return;
     if (h->ev_pending[k]) {      // collect the previous launch before re-recording
         hipEventSynchronize(h->ev1[k]);
         float ms = 0;
@@ -301,7 +302,7 @@ void time_begin(bossx_engine *h, int k, hipStream_t stream = nullptr) {
 void time_end(bossx_engine *h, int k, double bytes, hipStream_t stream = nullptr) {
     h->launches[k]++;
     h->bytes_last[k] = bytes;
-    if (!h->timing) return;
+    if (!h->timing || (h->timing_only >= 0 && k != h->timing_only)) return;
     hipEventRecord(h->ev1[k], stream ? stream : h->stream);
     h->ev_pending[k] = true;
 }
@@ -1416,7 +1417,8 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                 hipLaunchKernelGGL(cigar_walk_kernel<true>, grid, block, 0, h->stream_stage, W);
                 HIPCHK(hipGetLastError());
                 back = reinterpret_cast<uint32_t *>(h->h_plan_pin + plan_bytes + group_bytes);
-                HIPCHK(hipMemcpyAsync(back, W.totals, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream_stage));
+                hipLaunchKernelGGL(store_host_kernel, dim3(1), dim3(64), 0, h->stream_stage, W.totals, back, 4u);
+                HIPCHK(hipGetLastError());
                 if (!h->ev_walk) HIPCHK(hipEventCreateWithFlags(&h->ev_walk, hipEventDisableTiming));
                 HIPCHK(hipEventRecord(h->ev_walk, h->stream_stage));
                 // what the expansion writes (sized from what the host knows: every emitted base, the upper bound of the segments)
@@ -1447,7 +1449,8 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                 HIPCHK(upload_async(h->d_plans, h->h_plan_pin, plan_bytes, h->stream_stage));
                 hipLaunchKernelGGL(check_bases_kernel, dim3((n_plans + 3) / 4), dim3(256), 0, h->stream_stage, W);
                 HIPCHK(hipGetLastError());
-                HIPCHK(hipMemcpyAsync(back, W.totals, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream_stage));
+                hipLaunchKernelGGL(store_host_kernel, dim3(1), dim3(64), 0, h->stream_stage, W.totals, back, 4u);
+                HIPCHK(hipGetLastError());
                 HIPCHK(hipEventRecord(h->ev_walk, h->stream_stage));
             }
             await_reads(); HIPCHK(up_err);                 // (ordered before the kernels that read the bases)
@@ -2943,7 +2946,8 @@ int update_run(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_al
             // (round 6: up to 8 MB — the vector stores of the mask kernel post 2.2 MB of chr20+21 masks across PCIe in ~40 us,
             // less than the copy engine's submission alone used to cost, and no copy-engine submission is left in a lone update)
             static const int64_t mirror_max = getenv("BOSSX_MIRROR_MAX") ? atoll(getenv("BOSSX_MIRROR_MAX")) : (int64_t(8) << 20);
-            if (strat_all && !(up->flags & BOSSX_UPDATE_STRAT_BITS) && h->strat_bytes <= mirror_max) {
+            // (one barcode only beyond 1 MB: there the kernel stores whole 16-byte vectors; several barcodes go byte by byte — fine into HBM, not across PCIe)
+            if (strat_all && !(up->flags & BOSSX_UPDATE_STRAT_BITS) && h->strat_bytes <= (h->nb == 1 ? mirror_max : std::min<int64_t>(mirror_max, int64_t(1) << 20))) {
                 std::lock_guard<std::mutex> lock(g_host_mutex);
                 for (const auto &blk : g_host_blocks)
                     if (strat_all >= blk.first && strat_all + h->strat_bytes <= blk.first + blk.second) mirror = strat_all;
@@ -3262,6 +3266,8 @@ int bossx_preload_coverage(bossx_engine *h, double depth, uint64_t seed) {
 int bossx_enable_timing(bossx_engine *h, int32_t on) {
     if (!h) return BOSSX_E_INVALID;
     h->timing = on != 0;
+    h->timing_only = on >= 2 ? on - 2 : -1;      // 2 + k: events around kernel k alone (BOSSX_K_*)
+    if (h->timing_only >= BOSSX_K_COUNT) h->timing_only = -1;
     return BOSSX_OK;
 }
 

@@ -1036,15 +1036,21 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
     // ranges of records: as many as the pool has hands for, none below ~256 records (BOSSX_PLAN_RANGE: tests force small ranges)
     const char *plan_range_env = getenv("BOSSX_PLAN_RANGE");
     const size_t plan_range_min = plan_range_env ? size_t(std::max(atoi(plan_range_env), 1)) : 256;
-    const int pool_hands = getenv("BOSSX_PLAN_SERIAL") ? 1 : (in.n_threads > 0 ? in.n_threads : WorkPool::get().workers_for(64) + 1);
+    // (One range unless asked for: on the GPU boxes the ranges measured SLOWER than the single one — 0.07-0.13 + 0.19-0.21 ms against
+    // 0.09 + 0.07 — because the workers are still gathering reads at this point and a job waits for the slowest hand.  BOSSX_PLAN_PARALLEL=1,
+    // or an explicit thread count (tests), takes the ranges.)
+    const int pool_hands = in.n_threads > 0 ? in.n_threads : (getenv("BOSSX_PLAN_PARALLEL") ? WorkPool::get().workers_for(64) + 1 : 1);
     const size_t n_ranges = std::max<size_t>(1, std::min<size_t>(size_t(pool_hands), groups.size() / plan_range_min));
     std::vector<RangeState> range_state(n_ranges);
     auto range_lo = [&](size_t k) { return groups.size() * k / n_ranges; };
     {
         const std::function<void(int)> plan_range = [&](int k) {
             RangeState &rs = range_state[size_t(k)];
-            for (size_t gi = range_lo(size_t(k)), ge = range_lo(size_t(k) + 1); gi < ge; ++gi)
+            for (size_t gi = range_lo(size_t(k)), ge = range_lo(size_t(k) + 1); gi < ge; ++gi) {
+                // (the chosen records lie all over the line tasks' vectors: ask for the one eight ahead while this one is looked at)
+                if (gi + 8 < ge) { const char *nx = reinterpret_cast<const char *>(groups[gi + 8].best); __builtin_prefetch(nx); __builtin_prefetch(nx + 64); __builtin_prefetch(nx + 128); }
                 if (!plan_one(gi, rs)) break;
+            }
         };
         if (n_ranges == 1) plan_range(0); else pool_run(int(n_ranges), plan_range);
     }
@@ -1105,6 +1111,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             size_t seg_sum = 0;
             std::vector<uint64_t> &emitted = emit_part[size_t(k)];
             for (size_t i = plans.size() * size_t(k) / n_cr, ie = plans.size() * (size_t(k) + 1) / n_cr; i < ie; ++i) {
+                if (i + 8 < ie) { const char *nx = reinterpret_cast<const char *>(plans[i + 8].rec); __builtin_prefetch(nx); __builtin_prefetch(nx + 64); __builtin_prefetch(nx + 128); }
                 if (slot[i] == UINT32_MAX) continue;
                 const Plan &pl = plans[i];
                 const Rec &r = *pl.rec;

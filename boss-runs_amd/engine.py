@@ -653,8 +653,10 @@ class Engine:
         self._ck(self.lib.bossx_preload_coverage(self.h, float(depth), int(seed)))
 
     # ---- measurement ---------------------------------------------------------------------
-    def enable_timing(self, on=True):
-        self._ck(self.lib.bossx_enable_timing(self.h, int(on)))
+    def enable_timing(self, on=True, only=None):
+        """HIP events around every kernel (`on`), or around kernel `only` (a name of _lib.K_NAMES) alone."""
+        code = 0 if not on else (1 if only is None else 2 + _lib.K_NAMES.index(only))
+        self._ck(self.lib.bossx_enable_timing(self.h, code))
 
     def kernel_stats(self):
         n = len(_lib.K_NAMES)

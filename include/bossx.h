@@ -441,7 +441,10 @@ int bossx_preload_coverage(bossx_engine *h, double depth, uint64_t seed);
 #define BOSSX_K_MASK     4
 #define BOSSX_K_COUNT    5
 /* HIP-event time of the last launch of each kernel (ms) and launch counts; enabling timing
- * brackets each kernel with hipEvents on the engine stream.                                 */
+ * brackets each kernel with hipEvents on the engine stream.  `on` = 1: every kernel; 2 + k: kernel k
+ * (BOSSX_K_*) alone — every event pair is two marker packets between the kernels of an update,
+ * ~10 us of an idle GPU each: a measurement that wants ONE kernel's time inside a timed region
+ * asks for that kernel only.  0: off.                                                       */
 int bossx_enable_timing(bossx_engine *h, int32_t on);
 int bossx_kernel_ms(bossx_engine *h, float *ms_last /*[BOSSX_K_COUNT]*/,
                     double *ms_total /*[BOSSX_K_COUNT]*/, int64_t *launches /*[BOSSX_K_COUNT]*/);
