@@ -1374,13 +1374,14 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                 lap("the wait for the text slices");
                 if (up_fail.load()) return fail(h, BOSSX_E_HIP, "upload of the PAF text failed");
                 HIPCHK(hipEventRecord(h->ev_txt, h->stream_txt));
-                HIPCHK(hipStreamWaitEvent(h->stream_stage, h->ev_txt, 0));
+                const bool two_pass = getenv("BOSSX_TWO_PASS_WALK") != nullptr;       // the round-5 form of the walk (count, scan, emit)
+                if (two_pass) HIPCHK(hipStreamWaitEvent(h->stream_stage, h->ev_txt, 0));      // (single pass: only the walk itself waits for the text)
                 lap("event record + stream wait");
                 if ((rc2 = grow_dev(h, &st.d_ops, &st.ops_cap, pbe.ops_cap, 1024))) return rc2;
                 if ((rc2 = grow_dev(h, &st.d_segs, &st.segs_cap, pbe.segs_cap, 64))) return rc2;
                 if ((rc2 = grow_dev(h, &st.d_tilerefs, &st.tilerefs_cap, size_t(n_groups), 64))) return rc2;
                 if ((rc2 = grow_dev(h, &h->d_plans, &h->d_plans_cap, size_t(n_plans), 64))) return rc2;
-                if ((rc2 = grow_dev(h, &h->d_lane_scan, &h->d_lane_scan_cap, size_t(n_plans) * 64 * 3, 4096))) return rc2;
+                if (two_pass && (rc2 = grow_dev(h, &h->d_lane_scan, &h->d_lane_scan_cap, size_t(n_plans) * 64 * 3, 4096))) return rc2;
                 if ((rc2 = grow_dev(h, &st.d_tiles, &st.tiles_cap, size_t(pbe.total_emit / kEmitTile) + 2, 64))) return rc2;
                 const size_t n_walk = size_t(n_plans) * 3 + 1 + size_t(n_groups) * 2 + 4;
                 if ((rc2 = grow_dev(h, &h->d_walk, &h->d_walk_cap, n_walk, 64))) return rc2;
@@ -1406,15 +1407,31 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                 HIPCHK(hipMemsetAsync(h->d_walk, 0, n_walk * sizeof(uint32_t), h->stream_stage));
                 lap("the hipMemsetAsync");
                 W.plans = h->d_plans; W.n_plans = n_plans; W.paf = h->d_paf; W.blob = st.d_blob;
-                W.n_runs = h->d_walk; W.walk_err = W.n_runs + n_plans; W.ops_off = W.walk_err + n_plans;
-                W.group_count = W.ops_off + n_plans + 1; W.group_cursor = W.group_count + n_groups;
-                W.totals = W.group_cursor + n_groups;
                 W.ops = st.d_ops; W.groups = st.d_tilerefs; W.n_groups = n_groups; W.segs = st.d_segs;
-                W.emit_tile_op = st.d_tiles; W.lane_scan = h->d_lane_scan; W.nb = h->nb;
+                W.emit_tile_op = st.d_tiles; W.nb = h->nb;
                 const dim3 grid((n_plans + 3) / 4), block(256);
-                hipLaunchKernelGGL(cigar_walk_kernel<false>, grid, block, 0, h->stream_stage, W);
-                hipLaunchKernelGGL(walk_scan_kernel, dim3(1), dim3(1024), 0, h->stream_stage, W);
-                hipLaunchKernelGGL(cigar_walk_kernel<true>, grid, block, 0, h->stream_stage, W);
+                if (two_pass) {
+                    W.n_runs = h->d_walk; W.walk_err = W.n_runs + n_plans; W.ops_off = W.walk_err + n_plans;
+                    W.group_count = W.ops_off + n_plans + 1; W.group_cursor = W.group_count + n_groups;
+                    W.totals = W.group_cursor + n_groups;
+                    W.lane_scan = h->d_lane_scan; W.scan_state = nullptr;
+                    hipLaunchKernelGGL(cigar_walk_kernel<false>, grid, block, 0, h->stream_stage, W);
+                    hipLaunchKernelGGL(walk_scan_kernel, dim3(1), dim3(1024), 0, h->stream_stage, W);
+                    hipLaunchKernelGGL(cigar_walk_kernel<true>, grid, block, 0, h->stream_stage, W);
+                } else {
+                    // single pass (front_end.hip.inc: cigar_walk_fused_kernel): the look-back's state in the words of the two-pass
+                    // walk's run counts and offsets; the segment counts per group from the plans alone — launched BEFORE the
+                    // stream waits for the text
+                    W.scan_state = reinterpret_cast<unsigned long long *>(h->d_walk);
+                    W.n_runs = nullptr; W.ops_off = nullptr; W.lane_scan = nullptr;
+                    W.walk_err = h->d_walk + 2 * size_t(n_plans);
+                    W.group_count = h->d_walk + 3 * size_t(n_plans) + 1; W.group_cursor = W.group_count + n_groups;
+                    W.totals = W.group_cursor + n_groups;
+                    hipLaunchKernelGGL(plan_groups_kernel, dim3((n_plans + 255) / 256), dim3(256), 0, h->stream_stage, W);
+                    hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, h->stream_stage, W);
+                    HIPCHK(hipStreamWaitEvent(h->stream_stage, h->ev_txt, 0));
+                    hipLaunchKernelGGL(cigar_walk_fused_kernel, grid, block, 0, h->stream_stage, W);
+                }
                 HIPCHK(hipGetLastError());
                 back = reinterpret_cast<uint32_t *>(h->h_plan_pin + plan_bytes + group_bytes);
                 hipLaunchKernelGGL(store_host_kernel, dim3(1), dim3(64), 0, h->stream_stage, W.totals, back, 4u);
@@ -2317,8 +2334,11 @@ int launch_mask(bossx_engine *h, int gate, bool with_tails = false, const PickPa
     P.B = h->B; P.NBK = h->NBK; P.rows = h->rows; P.nb = h->nb; P.gate = gate; P.ctrl = h->d_ctrl;
     P.tails = with_tails ? h->d_tails : nullptr; P.tail_k = int32_t(h->filt.size());
     const int64_t span = int64_t(256) * kMaskRun;
-    // (with the threshold choice in every block — ~90 loads per lane of its first wave — no more blocks than CUs: each loops over its spans)
-    const int64_t blocks = std::min<int64_t>((h->rows + span - 1) / span, pick ? 256 : 4096);
+    // (with the threshold choice in every block — ~90 loads per lane of its first wave — one block per CU for small references, each
+    // looping over its spans; more where there are many spans per block to pay for it: at GRCh38 256 blocks were ONE wave per SIMD and
+    // the kernel waited for its own loads, 585 us for 124 MB)
+    const int64_t spans = (h->rows + span - 1) / span;
+    const int64_t blocks = std::min<int64_t>(spans, pick ? std::min<int64_t>(std::max<int64_t>(spans / 4, 256), 2048) : 4096);
     time_begin(h, BOSSX_K_MASK);
     if (pick) hipLaunchKernelGGL(strategy_mask_kernel<true>, dim3(uint32_t(std::max<int64_t>(blocks, 1))), dim3(256), 0, h->stream, P);
     else hipLaunchKernelGGL(strategy_mask_kernel<false>, dim3(uint32_t(std::max<int64_t>(blocks, 1))), dim3(256), 0, h->stream, P);

@@ -8,7 +8,7 @@ import bench
 arms = sys.argv[1:] or ["-"]
 w = "chr20_21"
 bench._GEN[w] = bench.make_reference(w, 0)
-N = 8 + 12 * len(arms)
+N = 8 + int(os.environ.get("AB_PER_ARM", "12")) * len(arms)
 batches = bench.generate_batches([(w, 1000 + i, 4000, 1) for i in range(N)])
 os.chdir(tempfile.mkdtemp())
 runs, nb = bench.make_runs(w, bench._GEN[w], 0, 1, 0, True)
