@@ -604,10 +604,21 @@ void bossx_destroy(bossx_engine *h) {
     if (h->d_spec_stats && getenv("BOSSX_SPEC_STATS")) {
         unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st2[2] = {0, 0};
 #ifdef BOSSX_STITCH_PROBE
-        unsigned long long pr[6] = {0, 0, 0, 0, 0, 0};
-        if (hipMemcpy(pr, h->d_spec_stats + 72, sizeof(pr), hipMemcpyDeviceToHost) == hipSuccess)
+        unsigned long long pr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpy(pr, h->d_spec_stats + 72, sizeof(pr), hipMemcpyDeviceToHost) == hipSuccess && pr[8])
+            fprintf(stderr, "[bossx] stitch probe: plain evaluations: %llu ticks loading + rounding-grid test, %llu ticks in the add loop, %llu steps of four bins (%.0f ticks per step)\n", pr[6], pr[7], pr[8], double(pr[7]) / double(pr[8]));
+        if (hipMemcpy(pr, h->d_spec_stats + 72, sizeof(unsigned long long) * 6, hipMemcpyDeviceToHost) == hipSuccess)
             fprintf(stderr, "[bossx] stitch probe (clock64 ticks, all launches): slowest wave ever %llu; sums over waves: cut rows %llu, other slow rows %llu, pieces %llu, whole waves %llu; most cut-row time on one wave (cumulative max) %llu\n", pr[0], pr[1], pr[2], pr[3], pr[4], pr[5]);
 #endif
+        {
+            long long ml[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (hipMemcpy(ml, h->d_spec_stats + 84, sizeof(ml), hipMemcpyDeviceToHost) == hipSuccess && ml[0]) {
+                double got, want, from;
+                memcpy(&got, &ml[5], 8); memcpy(&want, &ml[6], 8); memcpy(&from, &ml[7], 8);
+                fprintf(stderr, "[bossx] first failed segment check: contig %lld, strand %lld, window %lld (= %lld bins), the segment that ends at chunk %lld: started from %a, ended on %a, the stitch had predicted %a\n",
+                        ml[1], ml[2], ml[3], ml[8], ml[4], from, got, want);
+            }
+        }
         if (hipMemcpy(st2, h->d_spec_stats + 69, sizeof(st2), hipMemcpyDeviceToHost) == hipSuccess)
             fprintf(stderr, "[bossx] stitch: %llu cut rows walked piece by piece, %llu stretches evaluated on one rounding grid (each a round trip to the bin sums)\n", st2[1], st2[0]);
         {
@@ -2015,6 +2026,7 @@ int fill_chain_params(bossx_engine *h, const int32_t *windows, const double *mul
     P.never_ready = 0;
     P.zero_stats = nullptr; P.n_zero = 0;
     P.probe = getenv("BOSSX_CHAIN_PROBE") ? reinterpret_cast<long long *>(h->d_stats + kStatWords + 8) : nullptr;
+    P.mismatch_log = (getenv("BOSSX_SPEC_STATS") && h->d_spec_stats) ? reinterpret_cast<long long *>(h->d_spec_stats + 84) : nullptr;
     P.carry_ring = nullptr;
     if (h->chain_gc) {      // one ring per chain block
         const size_t need = n_blocks * size_t(kCarryRing) * (256 / 4 / 2) * 64;
