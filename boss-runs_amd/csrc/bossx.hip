@@ -160,6 +160,7 @@ struct bossx_engine {
         EmitOp *d_ops = nullptr; size_t ops_cap = 0;
         uint32_t *d_tiles = nullptr; size_t tiles_cap = 0;
         uint8_t *d_blob = nullptr; size_t blob_cap = 0;
+        uint32_t blob_bits = 4;          // bits per base of the blob as uploaded (2: nothing but A C G T in the batch)
         TileSeg *d_segs = nullptr; size_t segs_cap = 0;
         TileRef *d_tilerefs = nullptr; size_t tilerefs_cap = 0;
         uint8_t *d_codes = nullptr; size_t codes_cap = 0;          // per emitted base (expand_codes_kernel)
@@ -181,6 +182,7 @@ struct bossx_engine {
     std::vector<Staged> slots = std::vector<Staged>(1);
     int32_t slot = 0;
     int32_t pending_slot = -1;      // staged batch whose increments the next sweep applies
+    bool pending_err_unmerged = false;   // ... and whose own error word has not joined d_err yet
     double pending_emit = 0, pending_ops = 0;
     bool touched_dirty = false;     // the `touched` byte array holds flags the next sweep must read
     bool full_sweep_needed = true;  // bin sums / bucket sums are not current everywhere (start, import, preload): sweep every tile
@@ -200,6 +202,9 @@ struct bossx_engine {
     char *d_paf = nullptr; size_t d_paf_cap = 0;
     uint8_t *h_plan_pin = nullptr; size_t plan_pin_cap = 0;   // MapPlan[] + TileRef[] + read-back block
     MapPlan *d_plans = nullptr; size_t d_plans_cap = 0;
+    uint64_t nibble_repacks = 0;       // batches packed a second time, four bits per base (a byte other than A C G T in a read with a mapping)
+    uint32_t walk_token = 0; uint64_t walk_spin_timeouts = 0;   // the token the walk stores behind its totals; spins that gave up (0 expected)
+    bool walk_zeroed = false;          // d_walk is all zero (filled behind the batch before)
     uint8_t *d_marks = nullptr; size_t d_marks_cap = 0;       // bitmap of the batch's (tile, barcode) keys + per-word ranks (build_groups_kernel)
     uint32_t *d_walk = nullptr; size_t d_walk_cap = 0;        // n_runs | walk_err | ops_off | group_count | group_cursor | totals
     uint32_t *d_lane_scan = nullptr; size_t d_lane_scan_cap = 0;   // per mapping and lane: exclusive prefixes of the walk (pass 1 -> pass 2)
@@ -367,13 +372,15 @@ int flush_pending(bossx_engine *h) {
                            uint32_t(pb.n_ops), n_tiles, st.d_tiles);
         st.emit_tiles_built = true;
     }
+    if (h->pending_err_unmerged && st.d_err) hipLaunchKernelGGL(merge_err_kernel, dim3(1), dim3(1), 0, h->stream, st.d_err, h->d_err);
+    h->pending_err_unmerged = false;
     time_begin(h, BOSSX_K_INGEST);
     const EntSave X = ent_save_of(h);
     if (X.E)         // derived entropy: the scatter modifies patterns without looking the sites up — their entropies are saved first
         hipLaunchKernelGGL(ingest_scatter_kernel<true>, dim3(n_tiles), dim3(256), 0, h->stream, st.d_ops, st.d_tiles,
-                           uint32_t(pb.n_ops), pb.total_emit, st.d_blob, SiteState{h->d_state, h->nb}, h->d_touched, h->d_err, X);
+                           uint32_t(pb.n_ops), pb.total_emit, st.d_blob, st.blob_bits, SiteState{h->d_state, h->nb}, h->d_touched, h->d_err, X);
     hipLaunchKernelGGL(ingest_scatter_kernel<false>, dim3(n_tiles), dim3(256), 0, h->stream, st.d_ops, st.d_tiles,
-                       uint32_t(pb.n_ops), pb.total_emit, st.d_blob, SiteState{h->d_state, h->nb},
+                       uint32_t(pb.n_ops), pb.total_emit, st.d_blob, st.blob_bits, SiteState{h->d_state, h->nb},
                        h->d_touched, h->d_err, X);
     time_end(h, BOSSX_K_INGEST, 6.0 * double(pb.total_emit) + 16.0 * double(pb.n_ops));
     HIPCHK(hipGetLastError());
@@ -1076,6 +1083,50 @@ __attribute__((target("avx2"))) bool pack_read_avx2(const char *p, size_t n, uin
     if (i < n) dirty |= pack_read_scalar(p + i, n - i, dst + (i >> 1));
     return dirty;
 }
+// Two bits per base (engine.hpp), from a byte boundary on: true — and the read's bytes are void — if some byte is not A / C / G / T
+// (the whole batch is then packed again, as nibbles).
+bool pack_read2_scalar(const char *p, size_t n, uint8_t *dst) {
+    unsigned dirty = 0;
+    size_t i = 0;
+    for (; i + 4 <= n; i += 4) {
+        const unsigned a = kNib.t[static_cast<unsigned char>(p[i])], b = kNib.t[static_cast<unsigned char>(p[i + 1])];
+        const unsigned c = kNib.t[static_cast<unsigned char>(p[i + 2])], d = kNib.t[static_cast<unsigned char>(p[i + 3])];
+        dirty |= (a | b | c | d) >> 2;
+        dst[i >> 2] = uint8_t((a & 3u) | ((b & 3u) << 2) | ((c & 3u) << 4) | ((d & 3u) << 6));
+    }
+    if (i < n) {
+        unsigned v = 0;
+        for (size_t k = i; k < n; ++k) { const unsigned a = kNib.t[static_cast<unsigned char>(p[k])]; dirty |= a >> 2; v |= (a & 3u) << ((k - i) * 2); }
+        dst[i >> 2] = uint8_t(v);
+    }
+    return dirty != 0;
+}
+__attribute__((target("avx2"))) bool pack_read2_avx2(const char *p, size_t n, uint8_t *dst) {
+    const __m256i lut = _mm256_setr_epi8(-1, 0x41, -1, 0x43, 0x54, -1, -1, 0x47, -1, -1, -1, -1, -1, -1, -1, 0,
+                                         -1, 0x41, -1, 0x43, 0x54, -1, -1, 0x47, -1, -1, -1, -1, -1, -1, -1, 0);
+    const __m256i code = _mm256_setr_epi8(0, 0, 0, 1, 3, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 3, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m256i low = _mm256_set1_epi8(0x0f), pair = _mm256_set1_epi16(0x0401), quad = _mm256_set1_epi32(0x00100001);
+    bool dirty = false;
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(p + i));
+        const __m256i lo = _mm256_and_si256(v, low);
+        if (_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_shuffle_epi8(lut, lo), v)) != -1) { dirty = true; continue; }
+        const __m256i w = _mm256_maddubs_epi16(_mm256_shuffle_epi8(code, lo), pair);      // even + 4 * odd, per pair of bytes
+        const __m256i q = _mm256_madd_epi16(w, quad);                                      // ... + 16 * the next pair: one byte per four bases, in 32-bit lanes
+        const __m256i h16 = _mm256_packus_epi32(q, q);
+        const __m256i b8 = _mm256_packus_epi16(h16, h16);                                  // bytes 0..3 in the low 128-bit lane's first dword, 4..7 in the high lane's
+        const uint32_t lo4 = uint32_t(_mm256_extract_epi32(b8, 0)), hi4 = uint32_t(_mm256_extract_epi32(b8, 4));
+        const uint64_t out = uint64_t(lo4) | (uint64_t(hi4) << 32);
+        memcpy(dst + (i >> 2), &out, 8);
+    }
+    if (i < n) dirty |= pack_read2_scalar(p + i, n - i, dst + (i >> 2));
+    return dirty;
+}
+bool pack_read2(const char *p, size_t n, uint8_t *dst) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    return avx2 ? pack_read2_avx2(p, n, dst) : pack_read2_scalar(p, n, dst);
+}
 bool pack_read(const char *p, size_t n, uint8_t *dst) {
     static const bool avx2 = __builtin_cpu_supports("avx2");
     return avx2 ? pack_read_avx2(p, n, dst) : pack_read_scalar(p, n, dst);
@@ -1113,7 +1164,7 @@ namespace {
 
 // Host (page-locked, device-mapped) -> device copy of the staging: the engine's own kernel (front_end.hip.inc: upload_kernel)
 // unless BOSSX_ENGINE_COPIES=1 asks for hipMemcpyAsync (the copy engine; what rounds 1-5 used).  Callable from the worker threads.
-hipError_t upload_async(void *dst, const void *src_pinned, size_t bytes, hipStream_t stream) {
+hipError_t upload_async(void *dst, const void *src_pinned, size_t bytes, hipStream_t stream, size_t want_blocks = 0) {
     static const bool engine_copies = getenv("BOSSX_ENGINE_COPIES") != nullptr;
     if (bytes == 0) return hipSuccess;
     if (engine_copies) return hipMemcpyAsync(dst, src_pinned, bytes, hipMemcpyHostToDevice, stream);
@@ -1122,7 +1173,9 @@ hipError_t upload_async(void *dst, const void *src_pinned, size_t bytes, hipStre
     // (few blocks: what a launch keeps in flight — blocks x 256 threads x 64 bytes — queues up IN FRONT of every other upload's requests on
     // the one PCIe link; with 48 blocks per launch and five launches at once the 250 KB of plans took 112 us to cross, behind 4 MB of reads)
     static const size_t max_blocks = getenv("BOSSX_UPLOAD_BLOCKS") ? size_t(std::max(atoi(getenv("BOSSX_UPLOAD_BLOCKS")), 1)) : 8;
-    const uint32_t blocks = uint32_t(std::min<size_t>(std::max<size_t>((vec + 1023) / 1024, 1), max_blocks));
+    // (`want_blocks`: a small upload the device waits for — the plans — asks for all of its bytes in ONE round of requests, so it queues once
+    // behind what the bulk uploads have in flight instead of once per round)
+    const uint32_t blocks = uint32_t(std::min<size_t>(std::max<size_t>((vec + 1023) / 1024, 1), want_blocks ? want_blocks : max_blocks));
     hipLaunchKernelGGL(upload_kernel, dim3(blocks), dim3(256), 0, stream, static_cast<uint8_t *>(dst), static_cast<const uint8_t *>(src_pinned), bytes);
     return hipGetLastError();
 }
@@ -1276,6 +1329,10 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
         if ((rc = grow_pin(h, &h->h_paf_pin, &h->paf_pin_cap, in.paf_len + 64))) return rc;
         if ((rc = grow_dev(h, &h->d_paf, &h->d_paf_cap, in.paf_len + 64, 4096))) return rc;
     }
+    // two bits per base on the way up (engine.hpp) unless a read turns out to hold something else than A C G T; BOSSX_BLOB_NIBBLES=1: round 5's four
+    const bool two_bits = !getenv("BOSSX_BLOB_NIBBLES") && !getenv("BOSSX_HOST_WALK");
+    const int blob_shift = two_bits ? 2 : 1;
+    st.blob_bits = two_bits ? 2u : 4u;
     // ---- the caller's share of pass 1's parallel region --------------------------------------
     h->read_dirty.assign(size_t(n_reads), 0);
     const int n_g = blob_bytes > (size_t(1) << 20) ? parse_threads() : (n_reads > 0 ? 1 : 0);
@@ -1320,13 +1377,14 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
             for (int32_t i = i0; i < i1; ++i) {
                 const size_t len = size_t(seq_len[i]);
                 if (raw_copy) memcpy(seqs + seq_off[i], seq_ptrs[i], len);
-                const bool d = pack_read(seq_ptrs[i], len, packed + (seq_off[i] >> 1));      // (what is not A C G T is looked at again where it is aligned)
+                // (what is not A C G T is looked at again where it is aligned — after the whole batch has been packed again, as nibbles)
+                const bool d = two_bits ? pack_read2(seq_ptrs[i], len, packed + (seq_off[i] >> 2)) : pack_read(seq_ptrs[i], len, packed + (seq_off[i] >> 1));
                 h->read_dirty[size_t(i)] = d ? 1 : 0;
                 dirty |= d;
             }
             if (dirty) any_dirty.store(1, std::memory_order_relaxed);
             if (i1 > i0 && seq_off[i1] > seq_off[i0] &&
-                upload_async(st.d_blob + (seq_off[i0] >> 1), packed + (seq_off[i0] >> 1), size_t(seq_off[i1] - seq_off[i0]) >> 1,
+                upload_async(st.d_blob + (seq_off[i0] >> blob_shift), packed + (seq_off[i0] >> blob_shift), size_t(seq_off[i1] - seq_off[i0]) >> blob_shift,
                              h->stream_ups[g % n_up]) != hipSuccess)
                 up_fail.store(1);
         }
@@ -1367,6 +1425,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
         uint32_t n_plans = 0, n_groups = 0;
         WalkParams W{};
         uint32_t *back = nullptr;
+        uint32_t back_token = 0;          // != 0: the walk itself stores its totals to `back`, this token last
         size_t plan_bytes = 0, group_bytes = 0;
         auto t_launched = std::chrono::steady_clock::now(), t_plans = t_launched;
         in.early_walk = [&](ParsedBatch &pbe) {
@@ -1391,31 +1450,42 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                 if ((rc2 = grow_dev(h, &st.d_ops, &st.ops_cap, pbe.ops_cap, 1024))) return rc2;
                 if ((rc2 = grow_dev(h, &st.d_segs, &st.segs_cap, pbe.segs_cap, 64))) return rc2;
                 if ((rc2 = grow_dev(h, &st.d_tilerefs, &st.tilerefs_cap, size_t(n_groups), 64))) return rc2;
-                if ((rc2 = grow_dev(h, &h->d_plans, &h->d_plans_cap, size_t(n_plans), 64))) return rc2;
+                // (the plans and the bitmap of groups in ONE device buffer, as they lie in the page-locked one: one upload)
+                if ((rc2 = grow_dev(h, &h->d_plans, &h->d_plans_cap, size_t(n_plans) + (((pbe.marks.size() * 3 + 3) / 2) * sizeof(uint64_t) + 128) / sizeof(MapPlan) + 2, 64))) return rc2;
                 if (two_pass && (rc2 = grow_dev(h, &h->d_lane_scan, &h->d_lane_scan_cap, size_t(n_plans) * 64 * 3, 4096))) return rc2;
                 if ((rc2 = grow_dev(h, &st.d_tiles, &st.tiles_cap, size_t(pbe.total_emit / kEmitTile) + 2, 64))) return rc2;
-                const size_t n_walk = size_t(n_plans) * 3 + 1 + size_t(n_groups) * 2 + 4;
-                if ((rc2 = grow_dev(h, &h->d_walk, &h->d_walk_cap, n_walk, 64))) return rc2;
+                const size_t n_walk_front = (size_t(n_plans) * 3 + 1 + size_t(n_groups) * 2 + 4 + 1) & ~size_t(1);     // (what follows is 64-bit words)
+                const size_t n_walk = n_walk_front + 2 * (size_t(n_plans) / 64 + 1);
+                { const uint32_t *was = h->d_walk; if ((rc2 = grow_dev(h, &h->d_walk, &h->d_walk_cap, n_walk, 64))) return rc2; if (h->d_walk != was) h->walk_zeroed = false; }
                 // the groups travel as the bitmap of touched (tile, barcode) keys + the rank of every word: build_groups_kernel writes the list
                 const size_t n_words = pbe.marks.size();
                 const size_t marks_bytes = n_words * sizeof(uint64_t), rank_bytes = ((n_words + 1) * sizeof(uint32_t) + 7) & ~size_t(7);
                 plan_bytes = size_t(n_plans) * sizeof(MapPlan); group_bytes = marks_bytes + rank_bytes;
                 if ((rc2 = grow_pin(h, &h->h_plan_pin, &h->plan_pin_cap, plan_bytes + group_bytes + size_t(n_plans) * 4 + 64))) return rc2;
-                if ((rc2 = grow_dev(h, &h->d_marks, &h->d_marks_cap, group_bytes + 64, 4096))) return rc2;
+                const bool split_plan_upload = getenv("BOSSX_SPLIT_PLAN_UPLOAD") != nullptr;     // (round 5: two uploads of eight blocks)
+                if (split_plan_upload) { if ((rc2 = grow_dev(h, &h->d_marks, &h->d_marks_cap, group_bytes + 64, 4096))) return rc2; }
+                uint8_t *const d_marks = split_plan_upload ? h->d_marks : reinterpret_cast<uint8_t *>(h->d_plans) + plan_bytes;
                 lap("the buffer checks");
                 memcpy(h->h_plan_pin, pbe.plans.data(), plan_bytes);
                 memcpy(h->h_plan_pin + plan_bytes, pbe.marks.data(), marks_bytes);
                 memcpy(h->h_plan_pin + plan_bytes + marks_bytes, pbe.rank.data(), (n_words + 1) * sizeof(uint32_t));
                 lap("the copies into the page-locked plan buffer");
-                HIPCHK(upload_async(h->d_plans, h->h_plan_pin, plan_bytes, h->stream_stage));
+                if (split_plan_upload) {
+                    HIPCHK(upload_async(h->d_plans, h->h_plan_pin, plan_bytes, h->stream_stage));
+                    HIPCHK(upload_async(d_marks, h->h_plan_pin + plan_bytes, group_bytes, h->stream_stage));
+                } else {
+                    HIPCHK(upload_async(h->d_plans, h->h_plan_pin, plan_bytes + group_bytes, h->stream_stage, 64));
+                }
                 lap("the plans' upload");
-                HIPCHK(upload_async(h->d_marks, h->h_plan_pin + plan_bytes, group_bytes, h->stream_stage));
                 if (n_words)
                     hipLaunchKernelGGL(build_groups_kernel, dim3(uint32_t((n_words + 255) / 256)), dim3(256), 0, h->stream_stage,
-                                       reinterpret_cast<const unsigned long long *>(h->d_marks), reinterpret_cast<const uint32_t *>(h->d_marks + marks_bytes),
+                                       reinterpret_cast<const unsigned long long *>(d_marks), reinterpret_cast<const uint32_t *>(d_marks + marks_bytes),
                                        uint32_t(n_words), uint32_t(h->nb), st.d_tilerefs);
                 lap("the groups' upload");
-                HIPCHK(hipMemsetAsync(h->d_walk, 0, n_walk * sizeof(uint32_t), h->stream_stage));
+                // (the walk's words are zeroed BEHIND the batch that used them — see the end of this function — so no fill stands between
+                // the plans' upload and the walk; a fresh or regrown buffer, or a batch that left early, is zeroed here)
+                if (!h->walk_zeroed) HIPCHK(hipMemsetAsync(h->d_walk, 0, n_walk * sizeof(uint32_t), h->stream_stage));
+                h->walk_zeroed = false;
                 lap("the hipMemsetAsync");
                 W.plans = h->d_plans; W.n_plans = n_plans; W.paf = h->d_paf; W.blob = st.d_blob;
                 W.ops = st.d_ops; W.groups = st.d_tilerefs; W.n_groups = n_groups; W.segs = st.d_segs;
@@ -1425,7 +1495,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                     W.n_runs = h->d_walk; W.walk_err = W.n_runs + n_plans; W.ops_off = W.walk_err + n_plans;
                     W.group_count = W.ops_off + n_plans + 1; W.group_cursor = W.group_count + n_groups;
                     W.totals = W.group_cursor + n_groups;
-                    W.lane_scan = h->d_lane_scan; W.scan_state = nullptr;
+                    W.lane_scan = h->d_lane_scan; W.scan_state = nullptr; W.group_state = nullptr;
                     hipLaunchKernelGGL(cigar_walk_kernel<false>, grid, block, 0, h->stream_stage, W);
                     hipLaunchKernelGGL(walk_scan_kernel, dim3(1), dim3(1024), 0, h->stream_stage, W);
                     hipLaunchKernelGGL(cigar_walk_kernel<true>, grid, block, 0, h->stream_stage, W);
@@ -1434,10 +1504,20 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                     // walk's run counts and offsets; the segment counts per group from the plans alone — launched BEFORE the
                     // stream waits for the text
                     W.scan_state = reinterpret_cast<unsigned long long *>(h->d_walk);
+                    W.group_state = reinterpret_cast<unsigned long long *>(h->d_walk + n_walk_front);
                     W.n_runs = nullptr; W.ops_off = nullptr; W.lane_scan = nullptr;
                     W.walk_err = h->d_walk + 2 * size_t(n_plans);
                     W.group_count = h->d_walk + 3 * size_t(n_plans) + 1; W.group_cursor = W.group_count + n_groups;
                     W.totals = W.group_cursor + n_groups;
+                    if (!st.d_err) { if ((rc2 = dev_alloc(h, &st.d_err, 1, false))) return rc2; }
+                    W.expand_err = st.d_err;
+                    back = reinterpret_cast<uint32_t *>(h->h_plan_pin + plan_bytes + group_bytes);
+                    if (!getenv("BOSSX_WALK_STORE_KERNEL")) {         // (the round-5 way back: a launch behind the walk + an event)
+                        if (++h->walk_token == 0) h->walk_token = 1;
+                        __atomic_store_n(back + 3, 0u, __ATOMIC_RELEASE);
+                        W.host_back = back; W.host_token = h->walk_token;
+                        back_token = h->walk_token;
+                    }
                     hipLaunchKernelGGL(plan_groups_kernel, dim3((n_plans + 255) / 256), dim3(256), 0, h->stream_stage, W);
                     hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, h->stream_stage, W);
                     HIPCHK(hipStreamWaitEvent(h->stream_stage, h->ev_txt, 0));
@@ -1445,7 +1525,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                 }
                 HIPCHK(hipGetLastError());
                 back = reinterpret_cast<uint32_t *>(h->h_plan_pin + plan_bytes + group_bytes);
-                hipLaunchKernelGGL(store_host_kernel, dim3(1), dim3(64), 0, h->stream_stage, W.totals, back, 4u);
+                if (!back_token) hipLaunchKernelGGL(store_host_kernel, dim3(1), dim3(64), 0, h->stream_stage, W.totals, back, 4u);
                 HIPCHK(hipGetLastError());
                 if (!h->ev_walk) HIPCHK(hipEventCreateWithFlags(&h->ev_walk, hipEventDisableTiming));
                 HIPCHK(hipEventRecord(h->ev_walk, h->stream_stage));
@@ -1473,10 +1553,20 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                 // reads are on their way (the plans go up again, with their flags)
                 await_reads(); HIPCHK(up_err);
                 HIPCHK(hipStreamSynchronize(h->stream_stage));              // the first copy of the plans has left the staging buffer
+                if (st.blob_bits == 2u) {
+                    // ... and the reads go up again, as nibbles: two bits have no room for the digits the reference counts, nor for "refused"
+                    // (rare — a basecaller writes A C G T — so one thread and one upload: ~3 ms for a 4000-read batch)
+                    for (int i = 0; i < bossx_engine::kUpStreams; ++i) HIPCHK(hipStreamSynchronize(h->stream_ups[i]));
+                    for (int32_t i = 0; i < n_reads; ++i) pack_read(seq_ptrs[i], size_t(seq_len[i]), packed + (seq_off[i] >> 1));
+                    HIPCHK(upload_async(st.d_blob, packed, blob_bytes / 2, h->stream_stage, 64));
+                    st.blob_bits = 4u;
+                    ++h->nibble_repacks;
+                }
                 memcpy(h->h_plan_pin, pb.plans.data(), plan_bytes);
                 HIPCHK(upload_async(h->d_plans, h->h_plan_pin, plan_bytes, h->stream_stage));
                 hipLaunchKernelGGL(check_bases_kernel, dim3((n_plans + 3) / 4), dim3(256), 0, h->stream_stage, W);
                 HIPCHK(hipGetLastError());
+                back_token = 0;             // (the verdict now includes the bases: it comes back behind this launch)
                 hipLaunchKernelGGL(store_host_kernel, dim3(1), dim3(64), 0, h->stream_stage, W.totals, back, 4u);
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipEventRecord(h->ev_walk, h->stream_stage));
@@ -1488,8 +1578,8 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
             if (pb.total_emit) {
                 ExpandParams X;
                 X.ops = st.d_ops; X.n_ops = 0; X.total_emit = uint32_t(pb.total_emit); X.totals = W.totals;
-                X.blob = st.d_blob; X.codes = st.d_codes; X.segs = st.d_segs; X.n_segs = 0; X.pieces = st.d_pieces;
-                HIPCHK(hipMemsetAsync(st.d_err, 0, sizeof(int32_t), h->stream_stage));
+                X.blob = st.d_blob; X.blob_bits = st.blob_bits; X.codes = st.d_codes; X.segs = st.d_segs; X.n_segs = 0; X.pieces = st.d_pieces;
+                if (!W.expand_err) HIPCHK(hipMemsetAsync(st.d_err, 0, sizeof(int32_t), h->stream_stage));       // (single pass: group_scan_kernel has zeroed it)
                 X.err_flag = st.d_err;
                 X.code_blocks = (X.total_emit + uint32_t(kExpandTile) - 1u) / uint32_t(kExpandTile);
                 X.tile_op = st.d_tiles;
@@ -1497,8 +1587,22 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                 HIPCHK(hipGetLastError());
                 expand_enqueued = true;
             }
-            HIPCHK(hipEventSynchronize(h->ev_walk));       // the walk's totals are in host memory (the expansion runs on)
+            // the walk's totals: its own stores into page-locked memory, the token last (the host spins on that word: no event, no wake-up;
+            // a store that does not show within a millisecond — memory that is not coherent mid-launch — is waited for the round-5 way)
+            bool got = false;
+            if (back_token) {
+                const auto spin0 = std::chrono::steady_clock::now();
+                for (uint32_t sp = 0; !got; ++sp) {
+                    got = __atomic_load_n(back + 3, __ATOMIC_ACQUIRE) == back_token;
+                    if (got) break;
+                    _mm_pause();
+                    if ((sp & 255u) == 255u && std::chrono::steady_clock::now() - spin0 > std::chrono::milliseconds(1)) break;
+                }
+                if (!got) ++h->walk_spin_timeouts;
+            }
+            if (!got) HIPCHK(hipEventSynchronize(h->ev_walk));
             memcpy(totals, back, sizeof(totals));
+            if (back_token) totals[3] = 0;
             if (totals[2]) {
                 walk_err.resize(n_plans);
                 HIPCHK(hipMemcpy(walk_err.data(), W.walk_err, size_t(n_plans) * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1558,7 +1662,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
         if ((rc = grow_dev(h, &st.d_pieces, &st.pieces_cap, size_t(st.n_segs), 64))) return rc;
         ExpandParams X;
         X.ops = st.d_ops; X.n_ops = uint32_t(pb.n_ops); X.total_emit = uint32_t(pb.total_emit); X.totals = nullptr;
-        X.blob = st.d_blob; X.codes = st.d_codes; X.segs = st.d_segs; X.n_segs = st.n_segs; X.pieces = st.d_pieces;
+        X.blob = st.d_blob; X.blob_bits = st.blob_bits; X.codes = st.d_codes; X.segs = st.d_segs; X.n_segs = st.n_segs; X.pieces = st.d_pieces;
         // (the slot's own error word: a batch staged ahead must not raise in the update of the batch before it)
         if (!st.d_err) { if ((rc = dev_alloc(h, &st.d_err, 1, false))) return rc; }
         HIPCHK(hipMemsetAsync(st.d_err, 0, sizeof(int32_t), h->stream_stage));
@@ -1576,6 +1680,10 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
     if (aligned_bases) *aligned_bases = int64_t(pb.total_emit);
     if (!st.ev_ready) HIPCHK(hipEventCreateWithFlags(&st.ev_ready, hipEventDisableTiming));
     HIPCHK(hipEventRecord(st.ev_ready, h->stream_stage));
+    if (!host_walk && h->d_walk && !h->walk_zeroed && !getenv("BOSSX_WALK_ZERO_IN_FRONT")) {       // (behind ev_ready: nobody waits for it)
+        HIPCHK(hipMemsetAsync(h->d_walk, 0, h->d_walk_cap * sizeof(uint32_t), h->stream_stage));
+        h->walk_zeroed = true;
+    }
     if (timing) fprintf(stderr, "[bossx] stage_batch: %.2f ms inside the staging core\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     st.pb = std::move(pb);
     st.valid = true;
@@ -1599,7 +1707,7 @@ int bossx_stage_batch(bossx_engine *h, const char *paf, size_t paf_len, const ch
         plen[size_t(i)] = seq_off[i + 1] - seq_off[i];
         if (plen[size_t(i)] < 0) return fail(h, BOSSX_E_INVALID, "seq_off must not decrease");
         ptrs[size_t(i)] = seqs + seq_off[i];
-        poff[size_t(i) + 1] = poff[size_t(i)] + ((plen[size_t(i)] + 1) & ~int64_t(1));
+        poff[size_t(i) + 1] = poff[size_t(i)] + ((plen[size_t(i)] + 3) & ~int64_t(3));
     }
     return stage_core(h, paf, paf_len, names, name_off, poff.data(), plen.data(), ptrs.data(), barcodes, n_reads, min_len,
                       summary, n_rec, aligned_bases);
@@ -1617,7 +1725,7 @@ int bossx_stage_batch_ptrs(bossx_engine *h, const char *paf, size_t paf_len, con
     std::vector<int64_t> name_off(size_t(n_reads) + 1, 0), seq_off(size_t(n_reads) + 1, 0);
     for (int32_t i = 0; i < n_reads; ++i) {
         name_off[size_t(i) + 1] = name_off[size_t(i)] + name_lens[i];
-        seq_off[size_t(i) + 1] = seq_off[size_t(i)] + ((seq_lens[i] + 1) & ~int64_t(1));      // (every read on an even base index: two bases per byte)
+        seq_off[size_t(i) + 1] = seq_off[size_t(i)] + ((seq_lens[i] + 3) & ~int64_t(3));      // (every read on a base index that is a multiple of four: a byte boundary at two bits per base, and at four)
     }
     std::string names(size_t(name_off[size_t(n_reads)]), '\0');
     for (int32_t i = 0; i < n_reads; ++i) memcpy(&names[size_t(name_off[size_t(i)])], name_ptrs[i], size_t(name_lens[i]));
@@ -1630,6 +1738,13 @@ int bossx_pack_reads(const char *bases, int64_t n, uint8_t *dst, int32_t *dirty)
     if (n < 0 || (n > 0 && (!bases || !dst))) return BOSSX_E_INVALID;
     // BOSSX_PACK_SCALAR: the table alone (what the vector path is held to)
     const bool d = getenv("BOSSX_PACK_SCALAR") ? pack_read_scalar(bases, size_t(n), dst) : pack_read(bases, size_t(n), dst);
+    if (dirty) *dirty = d ? 1 : 0;
+    return BOSSX_OK;
+}
+
+int bossx_pack_reads2(const char *bases, int64_t n, uint8_t *dst, int32_t *dirty) {
+    if (n < 0 || (n > 0 && (!bases || !dst))) return BOSSX_E_INVALID;
+    const bool d = getenv("BOSSX_PACK_SCALAR") ? pack_read2_scalar(bases, size_t(n), dst) : pack_read2(bases, size_t(n), dst);
     if (dirty) *dirty = d ? 1 : 0;
     return BOSSX_OK;
 }
@@ -1670,7 +1785,7 @@ int bossx_ingest_staged(bossx_engine *h) {
     for (size_t i = 0; i < h->contigs.size(); ++i) h->contigs[i].cov_total += pb.emitted_per_contig[i];
     if (pb.total_emit == 0) return BOSSX_OK;
     if (st.ev_ready) HIPCHK(hipStreamWaitEvent(h->stream, st.ev_ready, 0));     // staged on stream_stage, consumed on the main stream
-    if (st.d_err) hipLaunchKernelGGL(merge_err_kernel, dim3(1), dim3(1), 0, h->stream, st.d_err, h->d_err);
+    h->pending_err_unmerged = st.d_err != nullptr;     // (joins the engine's error word in the sweep's prep launch — or in front of the fallback scatter)
     h->slots[size_t(h->slot)].busy = true;        // (until the sweep that applies it — or a fallback scatter — is behind ev_free)
     h->slots[size_t(h->slot)].ev_free_recorded = false;
     // the increments are applied by the next sweep, tile by tile (site_sweep_kernel prologue);
@@ -1800,6 +1915,8 @@ int launch_sweep(bossx_engine *h) {
         PR.tile_done = h->d_tile_done; PR.n_all = h->n_tiles; PR.full = full ? 1 : 0;
         PR.mark = publish ? 1 : 0;
         PR.work_ctr = h->d_work_ctr; PR.n_ctr = h->n_work_ctr + 4;      // (+ the write-back counts behind them)
+        PR.slot_err = nullptr; PR.err = h->d_err;
+        if (h->pending_slot >= 0 && h->pending_err_unmerged) { PR.slot_err = h->slots[size_t(h->pending_slot)].d_err; h->pending_err_unmerged = false; }
         h->work_ctr_used = 0;
         if (h->pending_slot >= 0) {
             const bossx_engine::Staged &st = h->slots[size_t(h->pending_slot)];

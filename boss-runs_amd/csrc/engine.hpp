@@ -90,7 +90,10 @@ struct TilePiece {
 // The read blob in HBM holds FOUR BITS per base (round 5: 12 MB instead of 24 over PCIe for a 4000-read batch — the upload was the
 // long pole of a lone update's staging): 0..3 = A C G T, 4..8 = the digits '0'..'4' and 9 = '7' (which the reference counts as
 // columns 0..4 and as a deletion, sequences.py:790, 803), kNibBad = any other byte (IndexError where it is aligned).  Blob indices
-// (MapPlan::seq_b / q0, EmitOp::qpos) are BASE indices: base i sits in byte i >> 1, low nibble first; every read starts on an even index.
+// (MapPlan::seq_b / q0, EmitOp::qpos) are BASE indices: base i sits in byte i >> 1, low nibble first; every read starts on an index that
+// is a multiple of four.  Round 6: a batch whose reads hold nothing but A C G T — every batch a basecaller writes — travels with TWO bits
+// per base (base i in byte i >> 2, bits 2 (i & 3) up; the same base indices): 6 MB instead of 12 over PCIe, whose reads by the upload
+// launches slow every kernel running next to them.  A batch with any other byte is packed again, as nibbles, once the gather has seen it.
 constexpr uint32_t kNibBad = 15;
 constexpr uint32_t kCodeSkip = 7;
 constexpr uint32_t kCodePad = 16;

@@ -118,13 +118,20 @@ int bossx_stage_batch_ptrs(bossx_engine *h, const char *paf, size_t paf_len,
                            const int32_t *barcodes, int32_t n_reads, int32_t min_len,
                            bossx_batch_summary *summary, int32_t *n_rec, int64_t *aligned_bases);
 int bossx_ingest_staged(bossx_engine *h);
-/* How the reads cross PCIe and lie in HBM: four bits per base, two bases per byte (low nibble first), every read from a byte
- * boundary on.  Codes: 0-3 = A C G T; 4-8 = '0'..'4' and 9 = '7' (the bytes np.fromstring of sequences.py:766 turns into a
+/* How the reads cross PCIe and lie in HBM when some read holds a byte other than A/C/G/T (otherwise: bossx_pack_reads2 below):
+ * four bits per base, two bases per byte (low nibble first), every read from a byte boundary on.  Codes: 0-3 = A C G T; 4-8 = '0'..'4' and 9 = '7' (the bytes np.fromstring of sequences.py:766 turns into a
  * base index, a deletion or the padding value: a digit in a read counts like the letter it would be translated to); 15 = any
  * other byte (never counted).  bossx_pack_reads writes the (n + 1) / 2 bytes of ONE read's n bases to `dst` exactly as the
  * staging does (an odd read's last high nibble is 15) and sets *dirty to 1 if some byte is not A/C/G/T.  Host only, no engine:
  * the CPU test-suite holds the vector and the scalar packer to one another with it.                                         */
 int bossx_pack_reads(const char *bases, int64_t n, uint8_t *dst, int32_t *dirty);
+/* Round 6: a batch in which every read with a mapping holds nothing but A/C/G/T — every batch a basecaller writes — crosses
+ * PCIe with TWO bits per base (base i of a read in byte i / 4, bits 2 (i mod 4) up, codes 0-3 as above; every read from a
+ * byte boundary on); a batch with any other byte in such a read is packed a second time, as nibbles, before anything reads
+ * it (BOSSX_BLOB_NIBBLES=1: always nibbles).  bossx_pack_reads2 writes the (n + 3) / 4 bytes of ONE read as the staging does
+ * (unused high bits of the last byte are 0) and sets *dirty to 1 if some byte is not A/C/G/T — the bytes written are then
+ * void.  Host only, no engine: vector packer against scalar packer in the CPU tier.                                           */
+int bossx_pack_reads2(const char *bases, int64_t n, uint8_t *dst, int32_t *dirty);
 /* Mapping choice only: Paf.parse_PAF filters + choose_best_mapper per read, summary arrays as
  * above, nothing staged or ingested.  This is what the simulation's decision step needs from
  * the truncated-read PAF (runs/simulation.py:63-75).  Reads are identified by name only.     */

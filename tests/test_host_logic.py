@@ -326,6 +326,45 @@ def test_native_parser_vs_oracle_expansion(threads, monkeypatch):
     assert np.array_equal(got["rev"], [int(r.rev) for r in recs])
 
 
+def test_read_packing_two_bits_per_base(monkeypatch):
+    """include/bossx.h (bossx_pack_reads2): a batch of nothing but A C G T crosses PCIe with two bits per base.  Vector packer
+    against scalar packer against numpy at every length 0..140 and two long ones; a read with any other byte is reported dirty
+    by both (its bytes are void: the staging packs the batch again as nibbles)."""
+    import ctypes as C
+    from boss_runs_amd import _lib
+    lib = _lib.load()
+    table = np.full(256, 255, np.uint8)
+    for ch, v in zip("ACGT", range(4)):
+        table[ord(ch)] = v
+    rng = np.random.default_rng(23)
+
+    def pack(raw):
+        nbytes = (len(raw) + 3) // 4
+        dst = np.full(nbytes + 16, 0xEE, np.uint8)
+        dirty = C.c_int32(-1)
+        assert lib.bossx_pack_reads2(raw, len(raw), dst.ctypes.data, C.byref(dirty)) == 0
+        assert np.all(dst[nbytes:] == 0xEE)           # nothing past the read's own bytes
+        return dst[:nbytes].copy(), dirty.value
+
+    for n in list(range(0, 141)) + [1000, 4099]:
+        clean = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), n))
+        c = table[np.frombuffer(clean, np.uint8)]
+        c = np.append(c, np.zeros((-n) % 4, np.uint8))
+        want = (c[0::4] | (c[1::4] << 2) | (c[2::4] << 4) | (c[3::4] << 6)).astype(np.uint8)
+        for scalar in (False, True):
+            if scalar:
+                monkeypatch.setenv("BOSSX_PACK_SCALAR", "1")
+            else:
+                monkeypatch.delenv("BOSSX_PACK_SCALAR", raising=False)
+            got, d = pack(clean)
+            assert d == 0 and np.array_equal(got, want), (n, scalar)
+            if n:
+                for alphabet in (b"0123456789", b"acgtN", bytes(range(1, 65)) + bytes(range(0x55, 256))):
+                    x = bytearray(clean)
+                    x[int(rng.integers(0, n))] = alphabet[int(rng.integers(0, len(alphabet)))]
+                    assert pack(bytes(x))[1] == 1, (n, scalar)
+
+
 def test_read_packing_four_bits_per_base(monkeypatch):
     """include/bossx.h (bossx_pack_reads): the reads cross PCIe as four bits per base.  The vector packer against the
     scalar table and both against a numpy restatement of the code table, at every length 0..130 (tails, odd lengths), with
