@@ -89,6 +89,7 @@ struct bossx_engine {
     int32_t spec_mismatches = 0;       // launches in which a segment's end value differed from the stitched one (each costs a serial rerun)
     int32_t spec_recent_fail = 0, spec_since_decay = 0;      // ... of those, the recent ones (note_spec_result)
     bool upd_launched = false, upd_done = false, upd_mirrored = false;    // bossx_update_launch / _collect
+    const uint8_t *mirror_valid = nullptr;     // the caller's buffer that holds d_strat's masks byte for byte (the last mask launch mirrored into it)
     double spec_est_us = 0, spec_est_serial_us = 0;     // what finalize expects of the two forms of the chain (microseconds)
     double spec_plain_share = 0;       // of all chunks the stitch adds the plain way, the fraction that falls on the longest chain's wave
     int32_t spec_pause = 0;            // updates left on the serial chain: too many chunks had to be added the plain way last time
@@ -202,6 +203,7 @@ struct bossx_engine {
     char *d_paf = nullptr; size_t d_paf_cap = 0;
     uint8_t *h_plan_pin = nullptr; size_t plan_pin_cap = 0;   // MapPlan[] + TileRef[] + read-back block
     MapPlan *d_plans = nullptr; size_t d_plans_cap = 0;
+    unsigned long long *d_walk_probe = nullptr; size_t d_walk_probe_cap = 0;    // -DBOSSX_WALK_PROBE builds
     uint64_t nibble_repacks = 0;       // batches packed a second time, four bits per base (a byte other than A C G T in a read with a mapping)
     uint32_t walk_token = 0; uint64_t walk_spin_timeouts = 0;   // the token the walk stores behind its totals; spins that gave up (0 expected)
     bool walk_zeroed = false;          // d_walk is all zero (filled behind the batch before)
@@ -1455,7 +1457,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                 if (two_pass && (rc2 = grow_dev(h, &h->d_lane_scan, &h->d_lane_scan_cap, size_t(n_plans) * 64 * 3, 4096))) return rc2;
                 if ((rc2 = grow_dev(h, &st.d_tiles, &st.tiles_cap, size_t(pbe.total_emit / kEmitTile) + 2, 64))) return rc2;
                 const size_t n_walk_front = (size_t(n_plans) * 3 + 1 + size_t(n_groups) * 2 + 4 + 1) & ~size_t(1);     // (what follows is 64-bit words)
-                const size_t n_walk = n_walk_front + 2 * (size_t(n_plans) / 64 + 1);
+                const size_t n_walk = n_walk_front + 2 * (size_t(n_plans) / 64 + 1) + 2 * size_t(n_plans);          // (group_state | base_state)
                 { const uint32_t *was = h->d_walk; if ((rc2 = grow_dev(h, &h->d_walk, &h->d_walk_cap, n_walk, 64))) return rc2; if (h->d_walk != was) h->walk_zeroed = false; }
                 // the groups travel as the bitmap of touched (tile, barcode) keys + the rank of every word: build_groups_kernel writes the list
                 const size_t n_words = pbe.marks.size();
@@ -1505,6 +1507,7 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                     // stream waits for the text
                     W.scan_state = reinterpret_cast<unsigned long long *>(h->d_walk);
                     W.group_state = reinterpret_cast<unsigned long long *>(h->d_walk + n_walk_front);
+                    W.base_state = W.group_state + (size_t(n_plans) / 64 + 1);
                     W.n_runs = nullptr; W.ops_off = nullptr; W.lane_scan = nullptr;
                     W.walk_err = h->d_walk + 2 * size_t(n_plans);
                     W.group_count = h->d_walk + 3 * size_t(n_plans) + 1; W.group_cursor = W.group_count + n_groups;
@@ -1521,6 +1524,11 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                     hipLaunchKernelGGL(plan_groups_kernel, dim3((n_plans + 255) / 256), dim3(256), 0, h->stream_stage, W);
                     hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, h->stream_stage, W);
                     HIPCHK(hipStreamWaitEvent(h->stream_stage, h->ev_txt, 0));
+#ifdef BOSSX_WALK_PROBE
+                    if ((rc2 = grow_dev(h, &h->d_walk_probe, &h->d_walk_probe_cap, size_t(n_plans) * 8, 64))) return rc2;
+                    HIPCHK(hipMemsetAsync(h->d_walk_probe, 0, size_t(n_plans) * 64, h->stream_stage));
+                    W.probe = h->d_walk_probe;
+#endif
                     hipLaunchKernelGGL(cigar_walk_fused_kernel, grid, block, 0, h->stream_stage, W);
                 }
                 HIPCHK(hipGetLastError());
@@ -1641,6 +1649,33 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                 }
             if (best_gi >= 0) return fail(h, BOSSX_E_RANGE, msg);
         }
+#ifdef BOSSX_WALK_PROBE
+        if (W.probe) {
+            // 100-MHz stamps per mapping: 0 start | 1 plan + step back | 2 count loop | 3 wave scans + checks | 4 base known | 5 emit loop | 6 end
+            HIPCHK(hipStreamSynchronize(h->stream_stage));
+            std::vector<unsigned long long> pr(size_t(n_plans) * 8);
+            HIPCHK(hipMemcpy(pr.data(), W.probe, pr.size() * 8, hipMemcpyDeviceToHost));
+            unsigned long long t00 = ~0ull;
+            for (uint32_t i = 0; i < n_plans; ++i) if (pr[size_t(i) * 8]) t00 = std::min(t00, pr[size_t(i) * 8]);
+            double mx[7] = {0}, mean[7] = {0}; uint32_t arg[7] = {0}; double dmx[7] = {0}; uint32_t n_ok = 0;
+            for (uint32_t i = 0; i < n_plans; ++i) {
+                const unsigned long long *q = &pr[size_t(i) * 8];
+                if (!q[6]) continue;
+                ++n_ok;
+                for (int k = 0; k < 7; ++k) {
+                    const double at = double(q[k] - t00) * 0.01;
+                    if (at > mx[k]) mx[k] = at;
+                    if (k) { const double dd = double(q[k] - q[k - 1]) * 0.01; mean[k] += dd; if (dd > dmx[k]) { dmx[k] = dd; arg[k] = i; } }
+                    else { mean[0] += at; if (at > dmx[0]) { dmx[0] = at; arg[0] = i; } }
+                }
+            }
+            fprintf(stderr, "[walk probe] %u of %u mappings emitted; latest stamp per phase (us from the first wave's start): start %.1f | plan %.1f | count %.1f | scans %.1f | base %.1f | emit %.1f | end %.1f\n",
+                    n_ok, n_plans, mx[0], mx[1], mx[2], mx[3], mx[4], mx[5], mx[6]);
+            fprintf(stderr, "[walk probe]   phase mean / longest (us), CIGAR bytes of the longest: plan %.1f / %.1f (%u) | count %.1f / %.1f (%u) | scans %.1f / %.1f | base wait %.1f / %.1f (mapping %u) | emit %.1f / %.1f (%u) | pieces %.1f / %.1f (%u)\n",
+                    mean[1] / n_ok, dmx[1], pb.plans[arg[1]].cg_len, mean[2] / n_ok, dmx[2], pb.plans[arg[2]].cg_len, mean[3] / n_ok, dmx[3],
+                    mean[4] / n_ok, dmx[4], arg[4], mean[5] / n_ok, dmx[5], pb.plans[arg[5]].cg_len, mean[6] / n_ok, dmx[6], pb.plans[arg[6]].cg_len);
+        }
+#endif
         pb.n_ops = totals[0];
         dev_n_segs = totals[1];
         if (getenv("BOSSX_CHECK_DEVICE_WALK") && (rc = check_device_walk(h, st, in, pb, totals[1]))) return rc;
@@ -2451,8 +2486,12 @@ void launch_fold(bossx_engine *h, bool to_limbs, bool to_canon, int gate) {
 // `use_codes`: the threshold in the control block was picked ON THE DEVICE from the histogram pass that also left d_bcode (the
 // kernel then compares one code byte per element instead of a double wherever Ctrl::thr_code allows)
 int launch_mask(bossx_engine *h, int gate, bool with_tails = false, const PickParams *pick = nullptr,
-                unsigned long long *host_result = nullptr, uint8_t *host_strat = nullptr, bool use_codes = false) {
+                unsigned long long *host_result = nullptr, uint8_t *host_strat = nullptr, bool use_codes = false, bool delta = false) {
     MaskParams P;
+    // (only what changes crosses PCIe — if the caller's buffer is the one this engine mirrored the masks into last time, nothing has
+    // written d_strat since, and the caller says it has not written into the buffer either: BOSSX_UPDATE_STRAT_DELTA)
+    P.host_delta = (delta && host_strat && host_strat == h->mirror_valid && !getenv("BOSSX_NO_MASK_DELTA")) ? 1 : 0;
+    h->mirror_valid = host_strat;
     P.do_pick = pick ? 1 : 0;
     if (pick) P.pick = *pick; else P.pick = PickParams{};
     P.host_result = host_result; P.dev_result = reinterpret_cast<const unsigned long long *>(h->d_result);
@@ -2602,7 +2641,8 @@ static void launch_tails(bossx_engine *h) {
     P.B = h->B; P.NBK = h->NBK; P.rows = h->rows; P.nb = h->nb; P.gate = 1; P.ctrl = h->d_ctrl;
     P.tails = nullptr; P.tail_k = int32_t(h->filt.size());
     P.do_pick = 0; P.pick = PickParams{};
-    P.host_result = nullptr; P.dev_result = nullptr; P.result_words = 0; P.host_strat = nullptr;
+    P.host_result = nullptr; P.dev_result = nullptr; P.result_words = 0; P.host_strat = nullptr; P.host_delta = 0;
+    h->mirror_valid = nullptr;
     hipLaunchKernelGGL(export_tails_kernel, dim3(64), dim3(256), 0, h->stream, P, h->d_tails);
 }
 
@@ -3102,7 +3142,7 @@ int update_run(bossx_engine *h, const bossx_update_params *up, uint8_t *strat_al
                     if (strat_all >= blk.first && strat_all + h->strat_bytes <= blk.first + blk.second) mirror = strat_all;
             }
             mirrored = mirror != nullptr;
-            if ((rc = launch_mask(h, 1, false, &PP, reinterpret_cast<unsigned long long *>(pin), mirror, /*use_codes=*/true))) return rc;
+            if ((rc = launch_mask(h, 1, false, &PP, reinterpret_cast<unsigned long long *>(pin), mirror, /*use_codes=*/true, (up->flags & BOSSX_UPDATE_STRAT_DELTA) != 0))) return rc;
         }
         HIPCHK(hipGetLastError());
         // results
@@ -3379,6 +3419,7 @@ int bossx_import(bossx_engine *h, int32_t contig, int32_t which, const void *src
         case 9: {
             if (src_bytes != size_t(c.T * 2 * nb)) return fail(h, BOSSX_E_INVALID, "import size mismatch");
             HIPCHK(hipMemcpy(h->d_strat + c.strat_off, src, src_bytes, hipMemcpyHostToDevice));
+            h->mirror_valid = nullptr;
             break;
         }
         default:

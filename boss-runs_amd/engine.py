@@ -504,6 +504,9 @@ class Engine:
             if getattr(self, "strat_all", None) is None:
                 self.strat_all = self._host_buffer(max(int(self.lib.bossx_strat_bytes(self.h)), 1), 1)
             masks = self.strat_all
+            # BOSSX_UPDATE_STRAT_DELTA: nobody but the engine writes into strat_all (the views handed out are read-only), so an update
+            # need only write the masks that changed since the one before
+            up.flags |= 16
         on = np.zeros(len(self.names), dtype=np.uint8)
         res = _lib.UpdateResult()
         counts = fg = ub = None
@@ -556,6 +559,7 @@ class Engine:
             off = int(self.lib.bossx_strat_offset(self.h, contig))
             T = self.lengths[contig] // 100
             v = cache[contig] = self.strat_all[off: off + T * 2 * self.nb].view(np.bool_).reshape(T, 2, self.nb)
+            v.setflags(write=False)          # (the buffer mirrors the device's masks: see BOSSX_UPDATE_STRAT_DELTA)
         return v
 
     def strat_offset(self, contig):

@@ -249,6 +249,11 @@ int bossx_apply_threshold(bossx_engine *h, double threshold);
 #define BOSSX_UPDATE_SWEEP_DONE   1  /* bossx_update_begin already enqueued sweep + bucket switches */
 #define BOSSX_UPDATE_BENEFIT_DONE 2  /* bossx_update_benefit already enqueued the move_sum chain     */
 #define BOSSX_UPDATE_STRAT_BITS   4  /* `strat_all` receives the masks packed 8:1 (bossx_get_strat_bits) */
+#define BOSSX_UPDATE_STRAT_DELTA  16 /* round 6: the caller has not written into `strat_all` since the previous bossx_update
+                                      * filled it (a bossx_host_alloc buffer in byte form): where the engine, too, knows the buffer
+                                      * to hold the device's masks byte for byte, only the groups of rows whose masks change are
+                                      * written — a few per cent of the 2.2 MB of chr20+21 between two updates.  Without the flag,
+                                      * or after anything else wrote the masks (import, a different buffer), every mask is written. */
 #define BOSSX_UPDATE_FHAT_RESIDENT 8 /* fhat_c is NULL: the posterior is rebuilt on the device from the resident
                                       * read-start counts (bossx_fhat_reset / bossx_fhat_add) and the fhat_* scalars */
 typedef struct bossx_update_params {
