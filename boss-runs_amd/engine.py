@@ -652,6 +652,11 @@ class Engine:
             raise ValueError(which)
         code = 9 if which == "strat" else EXPORT[which]
         self._ck(self.lib.bossx_import(self.h, contig, code, raw.ctypes.data, raw.nbytes))
+        if which == "strat" and getattr(self, "strat_all", None) is not None:
+            # strat_all mirrors the device's masks (Contig.strat views point into it): masks that come in from outside go there too
+            # — an update only writes the rows of switched-on buckets, and with BOSSX_UPDATE_STRAT_DELTA only the rows that change
+            off = int(self.lib.bossx_strat_offset(self.h, contig))
+            self.strat_all[off: off + raw.size] = raw.reshape(-1)
 
     def preload_coverage(self, depth, seed=1):
         self._ck(self.lib.bossx_preload_coverage(self.h, float(depth), int(seed)))

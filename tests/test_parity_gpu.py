@@ -925,6 +925,46 @@ def test_mask_views_outlive_the_engine(in_tmp):
         assert np.array_equal(v, copies[n])
 
 
+@pytest.mark.parametrize("nb", [1, 2])
+def test_mask_mirror_deltas_equal_the_device_masks(nb, in_tmp, monkeypatch):
+    """include/bossx.h (BOSSX_UPDATE_STRAT_DELTA): from the second update on only the groups of rows whose masks changed are
+    written into the host's mirror.  After every update the mirror (Contig.strat views) equals the masks read back from the
+    device in full (bossx_get_strat) — through an import of other masks in between, which voids the mirror — and equals what
+    the same run gives with the deltas switched off (BOSSX_NO_MASK_DELTA=1)."""
+    contigs = e2e_reference()
+    seen, moved = {}, []
+    for delta_off in (False, True):
+        if delta_off:
+            monkeypatch.setenv("BOSSX_NO_MASK_DELTA", "1")
+        runs = _product(1, nb, in_tmp)
+        eng = runs.engine
+        for b in range(E2E_BATCHES):
+            batch = e2e_batch(contigs, b, nb)
+            runs.rl_dist.update(batch["read_lengths"])
+            runs.process_batch_paf(batch["paf"], batch["seqs"], barcodes=batch.get("barcodes") if nb > 1 else None)
+            changed = 0
+            for ci, (n, c) in enumerate(runs.contigs_filt.items()):
+                dev = eng.get_strat(eng.names.index(n))
+                assert np.array_equal(np.asarray(c.strat).reshape(-1), np.asarray(dev).reshape(-1).astype(bool)), (delta_off, b, n)
+                key = (b, n)
+                if delta_off:
+                    assert np.array_equal(seen[key], np.asarray(c.strat)), key
+                else:
+                    seen[key] = np.asarray(c.strat).copy()
+                    if b:
+                        changed += int((seen[key] != seen[(b - 1, n)]).sum())
+            if b and not delta_off:
+                moved.append(changed)
+            if b == 2:
+                # other masks come in from outside: the engine no longer knows the mirror to be current, the next update writes all
+                n0 = next(iter(runs.contigs_filt))
+                i0 = eng.names.index(n0)
+                eng.import_state(i0, "strat", (~np.asarray(eng.get_strat(i0)).astype(bool)).astype(np.uint8))
+        runs.engine.close()
+        monkeypatch.delenv("BOSSX_NO_MASK_DELTA", raising=False)
+    assert any(moved), moved          # (masks did move between updates: the deltas had something to write)
+
+
 def test_reference_loop_through_the_boundary(in_tmp):
     """SURVEY §8b on the device: `Boss.process_batch(BossRuns.process_batch_runs)` with a mapper of
     the reference's shape (boss/mapper.py:27-108), then `update_strategy()` (BASELINE.json's name
