@@ -80,6 +80,7 @@ PROTOTYPES = {
     "bossx_paf_summary": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int32,
                                     C.c_int32, C.POINTER(BatchSummary), C.POINTER(C.c_int32)]),
     "bossx_pack_reads": (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int32)]),
+    "bossx_stage_stream": (C.c_int, [C.c_void_p, C.c_int32]),
     "bossx_pack_reads2": (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int32)]),
     "bossx_paf_select_lines": (C.c_int, [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                          C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),

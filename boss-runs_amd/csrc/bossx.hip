@@ -28,6 +28,16 @@
 
 using namespace bossx;
 
+// The names of the last launches, in a ring: what BOSSX_BACKTRACE=1 prints next to the native frames when the process dies (a GPU memory
+// fault arrives on a runtime thread, long after the launch that caused it returned: the frames alone say nothing about the kernel).
+namespace { const char *g_launch_ring[64]; std::atomic<unsigned> g_launch_at{0}; }
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                                     \
+    do {                                                                                                \
+        g_launch_ring[g_launch_at.fetch_add(1u, std::memory_order_relaxed) & 63u] = #kernel;            \
+        kernel<<<(grid), (block), (shmem), (stream)>>>(__VA_ARGS__);                                    \
+    } while (0)
+
 struct bossx_engine {
     bossx_config cfg{};
     std::string err;
@@ -48,7 +58,9 @@ struct bossx_engine {
     // its own: it touches the slot's buffers and the staging scratch only, never the site state, so the NEXT batch
     // can be staged while the update of the current one (sweep, chain) is still running on `stream`.  The consumer
     // (bossx_ingest_staged) makes `stream` wait for the slot's `ev_ready`.
-    hipStream_t stream_stage = nullptr;
+    hipStream_t stream_stage = nullptr;       // the stream the staging's kernels go to: stream_stage_own, or the main stream (bossx_stage_stream)
+    hipStream_t stream_stage_own = nullptr;
+    bool stage_on_main = false;
     hipEvent_t ev_begin = nullptr, ev_chain = nullptr, ev_sweep = nullptr, ev_fhat = nullptr;
     // The read-start posterior depends on nothing but the batch's read starts: its launches (the counts' atomic adds, the terms, the
     // scaling: ~30 us behind a gap) run on a stream of their own NEXT TO the sweep and the chain, and the histogram waits for one event
@@ -513,6 +525,13 @@ void crash_backtrace(int sig) {
     const char msg[] = "[bossx] fatal signal, native frames:\n";
     (void)!write(2, msg, sizeof(msg) - 1);
     backtrace_symbols_fd(frames, n, 2);
+    const char msg2[] = "[bossx] the last launches, oldest first:\n";
+    (void)!write(2, msg2, sizeof(msg2) - 1);
+    const unsigned at = g_launch_at.load();
+    for (unsigned k = at > 40u ? at - 40u : 0u; k < at; ++k) {
+        const char *nm = g_launch_ring[k & 63u];
+        if (nm) { (void)!write(2, "   ", 3); (void)!write(2, nm, strlen(nm)); (void)!write(2, "\n", 1); }
+    }
     signal(sig, SIG_DFL);
     raise(sig);
 }
@@ -554,8 +573,9 @@ int bossx_create(const bossx_config *cfg, bossx_engine **out) {
         hipStreamCreateWithFlags(&h->stream_up, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&h->stream_txt, hipStreamNonBlocking) != hipSuccess ||
-        create_stage_stream(&h->stream_stage) != hipSuccess ||
+        create_stage_stream(&h->stream_stage_own) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_txt, hipEventDisableTiming) != hipSuccess) return BOSSX_E_HIP;
+    h->stream_stage = h->stream_stage_own;
     h->stream_ups[0] = h->stream_up; h->ev_ups[0] = h->ev_up;
     for (int i = 1; i < bossx_engine::kUpStreams; ++i)
         if (hipStreamCreateWithFlags(&h->stream_ups[i], hipStreamNonBlocking) != hipSuccess ||
@@ -579,7 +599,7 @@ void bossx_destroy(bossx_engine *h) {
         if (h->ev_ups[i]) hipEventDestroy(h->ev_ups[i]);
     }
     if (h->stream_txt) { hipStreamSynchronize(h->stream_txt); hipStreamDestroy(h->stream_txt); }
-    if (h->stream_stage) { hipStreamSynchronize(h->stream_stage); hipStreamDestroy(h->stream_stage); }
+    if (h->stream_stage_own) { hipStreamSynchronize(h->stream_stage_own); hipStreamDestroy(h->stream_stage_own); }
     if (h->ev_txt) hipEventDestroy(h->ev_txt);
     if (h->ev_walk) hipEventDestroy(h->ev_walk);
     if (h->ev_begin) hipEventDestroy(h->ev_begin);
@@ -1282,6 +1302,12 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
     // stream may still read THIS slot's buffers (not when the caller stages ahead into another slot)
     HIPCHK(hipStreamSynchronize(h->stream_stage));
     {
+        // bossx_stage_stream: a batch that is consumed right away is staged on the main stream — the sweep then follows the expansion in
+        // ONE queue (a wait across queues stood between them: ~25 us of an idle GPU per lone update); BOSSX_STAGE_OWN_STREAM=1: never
+        hipStream_t want = (h->stage_on_main && !getenv("BOSSX_STAGE_OWN_STREAM")) ? h->stream : h->stream_stage_own;
+        if (want != h->stream_stage) { h->stream_stage = want; HIPCHK(hipStreamSynchronize(want)); }
+    }
+    {
         bossx_engine::Staged &cur = h->slots[size_t(h->slot)];
         // (busy without a recorded event: the batch was handed to the main stream, bossx_ingest_staged, and its reader — the sweep or the
         // fallback scatter — has not been enqueued yet: only the stream itself can be waited for)
@@ -1458,7 +1484,9 @@ int stage_core(bossx_engine *h, const char *paf, size_t paf_len, const char *nam
                 if ((rc2 = grow_dev(h, &st.d_tiles, &st.tiles_cap, size_t(pbe.total_emit / kEmitTile) + 2, 64))) return rc2;
                 const size_t n_walk_front = (size_t(n_plans) * 3 + 1 + size_t(n_groups) * 2 + 4 + 1) & ~size_t(1);     // (what follows is 64-bit words)
                 const size_t n_walk = n_walk_front + 2 * (size_t(n_plans) / 64 + 1) + 2 * size_t(n_plans);          // (group_state | base_state)
-                { const uint32_t *was = h->d_walk; if ((rc2 = grow_dev(h, &h->d_walk, &h->d_walk_cap, n_walk, 64))) return rc2; if (h->d_walk != was) h->walk_zeroed = false; }
+                // (a regrown buffer is not zero — and may well sit at the address of the one just freed: the capacity tells, not the pointer.
+                // Compared by pointer, a follower of the walk read a stale base out of the new buffer's tail and wrote its runs into the blue.)
+                { const size_t was_cap = h->d_walk_cap; if ((rc2 = grow_dev(h, &h->d_walk, &h->d_walk_cap, n_walk, 64))) return rc2; if (h->d_walk_cap != was_cap) { h->walk_zeroed = false; if (getenv("BOSSX_POISON_GROWN")) HIPCHK(hipMemset(h->d_walk, 0xff, h->d_walk_cap * sizeof(uint32_t))); } }     // (tests: a regrown buffer full of ones — what is not zeroed again shows)
                 // the groups travel as the bitmap of touched (tile, barcode) keys + the rank of every word: build_groups_kernel writes the list
                 const size_t n_words = pbe.marks.size();
                 const size_t marks_bytes = n_words * sizeof(uint64_t), rank_bytes = ((n_words + 1) * sizeof(uint32_t) + 7) & ~size_t(7);
@@ -1800,6 +1828,12 @@ int bossx_paf_summary(bossx_engine *h, const char *paf, size_t paf_len, const ch
     int rc = parse_paf_batch(in, h->contigs, h->index, summary, pb, err);
     if (rc) return fail(h, rc, err);
     if (n_rec) *n_rec = pb.n_rec;
+    return BOSSX_OK;
+}
+
+int bossx_stage_stream(bossx_engine *h, int32_t on_main) {
+    if (!h) return BOSSX_E_INVALID;
+    h->stage_on_main = on_main != 0;
     return BOSSX_OK;
 }
 

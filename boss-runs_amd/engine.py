@@ -156,6 +156,10 @@ class Engine:
 
     def stage_batch(self, paf_text, seqs, barcodes=None, min_len=200, ingest=False, packed=None):
         """Parse + upload one batch.  Returns dict of per-mapping summary arrays."""
+        # (bossx_stage_stream: a batch consumed right away is staged on the main stream, one staged ahead on the staging stream)
+        if self.__dict__.get("_stage_main") is not bool(ingest):
+            self._stage_main = bool(ingest)
+            self._ck(self.lib.bossx_stage_stream(self.h, 1 if ingest else 0))
         if packed is None and not ingest:
             return self._stage_batch_ptrs(paf_text, seqs, barcodes, min_len)
         if packed is None and ingest:

@@ -177,6 +177,11 @@ int bossx_host_parse(const char *const *contig_names, const int64_t *contig_leng
 /* Staged batches live in numbered slots (default 0) so several batches can be resident in HBM
  * at once; selects the slot the next stage/ingest call uses.                                */
 int bossx_select_batch(bossx_engine *h, int32_t slot);
+/* Round 6: which queue the staging's kernels (walk, expansion) go to from the next bossx_stage_batch* on.  0 (default): the
+ * engine's staging stream — a batch staged AHEAD runs next to the update in flight on the main stream.  1: the main stream —
+ * for a batch that bossx_ingest_staged / bossx_update_begin consume right away: the sweep then follows the expansion in one
+ * queue instead of behind a wait across queues (~25 us per lone update).  Results do not depend on it.                       */
+int bossx_stage_stream(bossx_engine *h, int32_t on_main);
 int bossx_ingest_paf(bossx_engine *h, const char *paf, size_t paf_len,
                      const char *names, const int64_t *name_off,
                      const char *seqs, const int64_t *seq_off,

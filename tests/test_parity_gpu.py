@@ -965,6 +965,37 @@ def test_mask_mirror_deltas_equal_the_device_masks(nb, in_tmp, monkeypatch):
     assert any(moved), moved          # (masks did move between updates: the deltas had something to write)
 
 
+def test_growing_batches_with_poisoned_regrown_buffers_vs_oracle(in_tmp, monkeypatch):
+    """The device walk's state words are zeroed BEHIND the batch that used them (round 6); a buffer regrown for a larger batch is not
+    zero, and may sit at the address of the one just freed (found as an intermittent GPU fault: a mapping read a stale base out of
+    the regrown buffer's tail).  BOSSX_POISON_GROWN=1 fills every regrown walk buffer with ones: batches that grow 40 -> 200 ->
+    900 -> 60 -> 2500 reads must equal the oracle update by update."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.config import BossConfig
+    from boss_runs_amd.runs import BossRuns
+    from oracle.pipeline import OracleRuns
+    monkeypatch.setenv("BOSSX_POISON_GROWN", "1")
+    contigs = synth.make_reference([700_000, 250_000], seed=77, names=["g1", "g2"])
+    strs = [(n, synth.codes_to_str(c)) for n, c in contigs]
+    args = BossConfig()
+    args.general.name = "grow"
+    args.optional.bucket_threshold = 1
+    runs = BossRuns(args)
+    runs.init(contigs=strs)
+    o = OracleRuns(strs, ploidy=1, nbarcodes=1, bucket_threshold=1)
+    for b, n_reads in enumerate([40, 200, 900, 60, 2500]):
+        batch = synth.make_batch(contigs, n_reads, seed=7700 + b, mean_len=4000.0, nbarcodes=1)
+        o.process_batch(batch["paf"], batch["seqs"], read_lengths=batch["read_lengths"])
+        runs.rl_dist.update(batch["read_lengths"])
+        runs.process_batch_paf(batch["paf"], batch["seqs"])
+        assert runs.threshold == o.threshold, b
+        for n, oc in o.contigs.items():
+            pc = runs.contigs[n]
+            assert np.array_equal(pc.coverage, oc.coverage), (b, n)
+            assert np.array_equal(pc.strat, oc.strat), (b, n)
+    runs.engine.close()
+
+
 def test_reference_loop_through_the_boundary(in_tmp):
     """SURVEY §8b on the device: `Boss.process_batch(BossRuns.process_batch_runs)` with a mapper of
     the reference's shape (boss/mapper.py:27-108), then `update_strategy()` (BASELINE.json's name
