@@ -10,11 +10,11 @@ ends = [i for i, r in enumerate(rows) if "strategy_mask_kernel" in r["Kernel_Nam
 spans, spans_g, dur = [], [], collections.defaultdict(list)
 for a, b in zip(ends[skip:-1], ends[skip + 1:]):
     sel = rows[a + 1:b + 1]
-    if not any(("build_groups_kernel" in r["Kernel_Name"] or "front_prep_kernel" in r["Kernel_Name"]) for r in sel):
+    if not any("build_groups_kernel" in r["Kernel_Name"] for r in sel):
         continue
     t_end = int(sel[-1]["End_Timestamp"])
     t_up = int(sel[0]["Start_Timestamp"])
-    t_bg = min(int(r["Start_Timestamp"]) for r in sel if ("build_groups_kernel" in r["Kernel_Name"] or "front_prep_kernel" in r["Kernel_Name"]))
+    t_bg = min(int(r["Start_Timestamp"]) for r in sel if "build_groups_kernel" in r["Kernel_Name"])
     spans.append((t_end - t_up) / 1e3); spans_g.append((t_end - t_bg) / 1e3)
     per = collections.defaultdict(float)
     for r in sel:
