@@ -13,6 +13,7 @@
 #include "bossx_py.h"
 
 #include <sched.h>
+#include <immintrin.h>
 
 #include <algorithm>
 #include <cstdlib>
@@ -38,6 +39,9 @@ namespace bossx {
 namespace {
 
 struct Rec {
+    // (copies, not views into the text: the grouping — ONE thread — compares the names of 4000 records, and their copies lie side by side
+    // in the heap of the worker that parsed them, while the names in the text lie a line, 1.4 KB, apart: as views the grouping took
+    // 0.25 ms longer, a cache miss per record — tried in round 6)
     std::string qname, tname;
     int32_t cidx = -1;               // index of tname in the contig table (-1: not there), resolved by the line task
     int64_t qlen, qstart, qend, tstart, tend, alnlen, mapq, as;
@@ -118,6 +122,19 @@ std::string_view strip(std::string_view s) {      // str.strip()
 // says that the value does not fit an int64 (where numpy is handed it: OverflowError), `*canon` gets
 // str(int(s)).
 bool parse_int(std::string_view s, int64_t &v, bool *big = nullptr, std::string *canon = nullptr) {
+    // (what a mapper writes: up to eighteen ASCII digits and nothing else — below 10^18, inside int64 and below the clamp further
+    // down; seven columns and a tag per line go through here, and the general path below — code points, underscores, 128-bit
+    // arithmetic, a std::string of digits — was the largest single item of a line task)
+    if (!canon && !s.empty() && s.size() <= 18) {
+        uint64_t x = 0;
+        size_t i = 0;
+        for (; i < s.size(); ++i) {
+            const unsigned d = unsigned(static_cast<unsigned char>(s[i])) - unsigned('0');
+            if (d > 9u) break;
+            x = x * 10u + d;
+        }
+        if (i == s.size()) { v = int64_t(x); if (big) *big = false; return true; }
+    }
     s = strip(s);
     size_t i = 0;
     const size_t n = s.size();
@@ -194,6 +211,11 @@ bool parse_float(std::string_view s, double &d) {
 
 // PafLine stores names as str(conv_type(x, int)): "007" becomes "7" (paf.py:55-56, 103-108).
 std::string normalise_name(std::string_view s) {
+    if (!s.empty()) {
+        // (int() takes nothing that starts with any other ASCII character: whitespace is stripped, then a sign or a digit — of any script)
+        const unsigned char c = static_cast<unsigned char>(s[0]);
+        if (!(c >= 0x80 || (c >= '0' && c <= '9') || c == '+' || c == '-' || c <= ' ')) return std::string(s);
+    }
     int64_t v;
     std::string canon;
     if (parse_int(s, v, nullptr, &canon)) return canon;
@@ -261,22 +283,93 @@ struct LineOut {
 //   alignment block length that is not an integer   TypeError      (str < int, paf.py:666)
 // Other non-integer columns stay strings there and only matter if the path computes with them
 // (Rec::bad_cols; the unused ones — tlen, number of matches — never do).
+// One pass over a line (round 6): the offsets of its tabs and colons up to the newline.  The fields used to be found by a memchr for the
+// newline, a find per tab and — for every tag — finds for its colons, the third of them over the whole 1.2-KB CIGAR string: every byte of
+// the text was looked at three times (1.05 of the 2.9 ms a 6-MB batch takes one thread; one pass: 0.43).  Returns the newline (or `end`);
+// `n` > kLineSpecials: too many for the table — the caller splits that line the old way.
+constexpr int kLineSpecials = 192;
+struct LineSpecials { uint32_t off[kLineSpecials]; int n; };
+__attribute__((target("avx2"))) const char *scan_line_avx2(const char *p, const char *end, LineSpecials &sp) {
+    const __m256i vt = _mm256_set1_epi8('\t'), vc = _mm256_set1_epi8(':'), vn = _mm256_set1_epi8('\n');
+    const char *q = p;
+    int n = 0;
+    for (; q + 32 <= end; q += 32) {
+        const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(q));
+        const unsigned mn = unsigned(_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, vn)));
+        unsigned m = unsigned(_mm256_movemask_epi8(_mm256_or_si256(_mm256_cmpeq_epi8(v, vt), _mm256_cmpeq_epi8(v, vc))));
+        if (mn) m &= (mn & (0u - mn)) - 1u;                     // only what stands in front of the first newline
+        while (m) {
+            const int b = __builtin_ctz(m);
+            m &= m - 1u;
+            if (n < kLineSpecials) sp.off[n] = uint32_t(q - p) + uint32_t(b);
+            ++n;
+        }
+        if (mn) { sp.n = n; return q + __builtin_ctz(mn); }
+    }
+    for (; q < end; ++q) {
+        const char c = *q;
+        if (c == '\n') { sp.n = n; return q; }
+        if (c == '\t' || c == ':') { if (n < kLineSpecials) sp.off[n] = uint32_t(q - p); ++n; }
+    }
+    sp.n = n;
+    return end;
+}
+const char *scan_line_scalar(const char *p, const char *end, LineSpecials &sp) {
+    int n = 0;
+    const char *q = p;
+    for (; q < end; ++q) {
+        const char c = *q;
+        if (c == '\n') break;
+        if (c == '\t' || c == ':') { if (n < kLineSpecials) sp.off[n] = uint32_t(q - p); ++n; }
+    }
+    sp.n = n;
+    return q;
+}
+
 void parse_lines(const char *p, const char *end, int64_t min_len, LineOut &lo, const std::unordered_map<std::string, int32_t> *contig_index = nullptr) {
+    static const bool has_avx2 = __builtin_cpu_supports("avx2");
+    const bool avx2 = has_avx2 && !getenv("BOSSX_PARSE_SCALAR");       // (the variable: tests hold the two scanners to each other)
     std::vector<std::string_view> f;
+    std::vector<uint32_t> fc;        // per field: its first two colons (offsets inside the field, ~0u: none) and how many it holds
+    LineSpecials sp;
     auto fail = [&](int code, const char *msg) { lo.err_line = lo.n_lines; lo.err_code = code; lo.err_msg = msg; };
     while (p < end) {
-        const char *nl = static_cast<const char *>(memchr(p, '\n', size_t(end - p)));
-        const char *le = nl ? nl : end;
+        const char *le = avx2 ? scan_line_avx2(p, end, sp) : scan_line_scalar(p, end, sp);
+        const char *nl = le < end ? le : nullptr;
         std::string_view line = strip(std::string_view(p, size_t(le - p)));
+        const char *const line0 = p;
         p = nl ? nl + 1 : end;
         ++lo.n_lines;
-        f.clear();
-        size_t s = 0;
-        while (true) {
-            size_t t = line.find('\t', s);
-            if (t == std::string_view::npos) { f.push_back(line.substr(s)); break; }
-            f.push_back(line.substr(s, t - s));
-            s = t + 1;
+        f.clear(); fc.clear();
+        if (sp.n <= kLineSpecials) {
+            // the fields of the STRIPPED line, from the table: tabs outside it (str.strip() takes them) split nothing
+            const uint32_t a = uint32_t(line.data() - line0), b = a + uint32_t(line.size());
+            uint32_t fs = a, c1 = ~0u, c2 = ~0u, nc = 0;
+            for (int k = 0; k < sp.n; ++k) {
+                const uint32_t o = sp.off[k];
+                if (o < a || o >= b) continue;
+                if (line0[o] == '\t') {
+                    f.push_back(std::string_view(line0 + fs, o - fs)); fc.push_back(c1); fc.push_back(c2); fc.push_back(nc);
+                    fs = o + 1; c1 = c2 = ~0u; nc = 0;
+                } else {
+                    if (nc == 0) c1 = o - fs; else if (nc == 1) c2 = o - fs;
+                    ++nc;
+                }
+            }
+            f.push_back(std::string_view(line0 + fs, b - fs)); fc.push_back(c1); fc.push_back(c2); fc.push_back(nc);
+        } else {
+            size_t s = 0;
+            while (true) {
+                size_t t = line.find('\t', s);
+                const std::string_view fld = t == std::string_view::npos ? line.substr(s) : line.substr(s, t - s);
+                const size_t k1 = fld.find(':'), k2 = k1 == std::string_view::npos ? k1 : fld.find(':', k1 + 1);
+                const bool third = k2 != std::string_view::npos && fld.find(':', k2 + 1) != std::string_view::npos;
+                f.push_back(fld);
+                fc.push_back(k1 == std::string_view::npos ? ~0u : uint32_t(k1)); fc.push_back(k2 == std::string_view::npos ? ~0u : uint32_t(k2));
+                fc.push_back(k1 == std::string_view::npos ? 0u : k2 == std::string_view::npos ? 1u : third ? 3u : 2u);
+                if (t == std::string_view::npos) break;
+                s = t + 1;
+            }
         }
         if (f.size() < 12) return fail(BOSSX_E_RANGE, ": fewer than 12 columns");
         Rec r;
@@ -292,11 +385,8 @@ void parse_lines(const char *p, const char *end, int64_t min_len, LineOut &lo, c
         std::string_view as_val;
         for (size_t k = 12; k < f.size(); ++k) {
             std::string_view tag = f[k];
-            size_t c1 = tag.find(':');
-            size_t c2 = c1 == std::string_view::npos ? c1 : tag.find(':', c1 + 1);
-            if (c1 == std::string_view::npos || c2 == std::string_view::npos ||
-                tag.find(':', c2 + 1) != std::string_view::npos)
-                return fail(BOSSX_E_PARSE, ": malformed tag");   // x.split(':') unpack
+            const size_t c1 = fc[3 * k], c2 = fc[3 * k + 1];
+            if (fc[3 * k + 2] != 2u) return fail(BOSSX_E_PARSE, ": malformed tag");   // x.split(':') unpack: exactly two colons
             std::string_view key = tag.substr(0, c1), typ = tag.substr(c1 + 1, c2 - c1 - 1), val = tag.substr(c2 + 1);
             if (!(typ.size() == 1 && (typ[0] == 'i' || typ[0] == 'A' || typ[0] == 'f' || typ[0] == 'Z')))
                 return fail(BOSSX_E_KEY, ": unknown tag type");

@@ -640,9 +640,76 @@ def test_native_front_end_error_classes_equal_the_reference(plan_range, monkeypa
     assert not bad, bad
 
 
-@pytest.mark.parametrize("plan_range", [None, "1"])
+def test_line_scanner_vector_equals_scalar_on_long_and_odd_lines(monkeypatch):
+    """paf_host.cpp: scan_line_avx2 / scan_line_scalar (round 6: ONE pass over a line for its tabs and colons instead of a memchr for
+    the newline, a find per tab and finds for every tag's colons).  Realistic batches (CIGAR tags of 1-6 KB: tabs, colons and newlines at
+    every offset inside the 32-byte blocks) plus lines bent on purpose — extra colons in tags and in names, colons inside the CIGAR
+    value, tags and tabs by the hundred (more specials than the scanner's table holds: the old splitting takes over), blank lines,
+    whitespace at the ends, no newline at the end — give the same summary, the same expansion or the same exception with either form."""
+    from boss_runs_amd import synth
+    from boss_runs_amd.engine import host_parse
+    contigs = synth.make_reference([120_000, 60_000], seed=5, names=["s1", "s2"])
+    clist = [(n, c.shape[0], 0) for n, c in contigs]
+    rng = np.random.default_rng(99)
+    batch = synth.make_batch(contigs, 60, seed=77, mean_len=6000.0)
+    lines = batch["paf"].split("\n")
+    if lines and not lines[-1]:
+        lines.pop()
+
+    def variants():
+        yield "plain", "\n".join(lines) + "\n"
+        yield "no final newline", "\n".join(lines)
+        for trial in range(40):
+            ls = list(lines)
+            k = int(rng.integers(0, len(ls)))
+            f = ls[k].split("\t")
+            kind = trial % 8
+            if kind == 0:
+                f.append("zz:Z:" + ":".join("x" * int(rng.integers(0, 40)) for _ in range(int(rng.integers(2, 5)))))      # too many colons
+            elif kind == 1:
+                f[0] = f[0] + ":a:b"                                                                          # colons in a name: nothing
+            elif kind == 2:
+                f = [x.replace("cg:Z:", "cg:Z::") if x.startswith("cg:Z:") else x for x in f]                  # a colon inside the value
+            elif kind == 3:
+                f += ["t%d:i:%d" % (j, j) for j in range(int(rng.integers(60, 120)))]                        # > 192 specials
+            elif kind == 4:
+                f += [""] * int(rng.integers(200, 260))                                                        # tabs by the hundred: empty tags
+            elif kind == 5:
+                ls.insert(k, "")                                                                               # a blank line
+                yield "blank %d" % trial, "\n".join(ls) + "\n"
+                continue
+            elif kind == 6:
+                ls[k] = " \t" + ls[k] + "\t \r"                                                                 # stripped like str.strip()
+                yield "ws %d" % trial, "\n".join(ls) + "\n"
+                continue
+            else:
+                f.append("AS:i:" + "9" * int(rng.integers(1, 25)))                                             # 1-24 digits: fast path and beyond
+            ls[k] = "\t".join(f)
+            yield "kind%d %d" % (kind, trial), "\n".join(ls) + "\n"
+
+    def run(text):
+        try:
+            out = host_parse(clist, text, batch["seqs"], n_threads=2, min_len=200)
+            return ("ok", out["read_idx"].tobytes(), out["tstart"].tobytes(), out["pos"].tobytes(), out["code"].tobytes())
+        except Exception as e:          # noqa: BLE001
+            return ("error", type(e).__name__)
+
+    seen_err = seen_ok = 0
+    for name, text in variants():
+        monkeypatch.delenv("BOSSX_PARSE_SCALAR", raising=False)
+        a = run(text)
+        monkeypatch.setenv("BOSSX_PARSE_SCALAR", "1")
+        b = run(text)
+        assert a == b, name
+        seen_err += a[0] == "error"
+        seen_ok += a[0] == "ok"
+    assert seen_err >= 5 and seen_ok >= 10, (seen_err, seen_ok)
+
+
+@pytest.mark.parametrize("plan_range", [None, "1", "scalar_scan"])
 def test_native_front_end_fuzz_error_classes_equal_the_reference(plan_range, monkeypatch):
-    """(`plan_range` = "1": the pre-pass over the chosen mappings split into ranges of ONE record on the pool's threads — the form a
+    """(`plan_range` = "scalar_scan": BOSSX_PARSE_SCALAR=1 — the line scanner's byte loop instead of its AVX2 form: one pass over a line
+    for its tabs and colons, round 6.)  (`plan_range` = "1": the pre-pass over the chosen mappings split into ranges of ONE record on the pool's threads — the form a
     4000-read batch takes with ranges of 256+, forced onto these small batches: the first failure in record order, the summary, the
     running sums and the bitmap of touched tiles must come out as from the single range.)
     The native PAF / CIGAR front end (bossx_host_parse: line parser, grouping, pre-pass, host walk, and the plans
@@ -653,7 +720,9 @@ def test_native_front_end_fuzz_error_classes_equal_the_reference(plan_range, mon
     import json
     from scenarios import GOLDEN, digest, fuzz_error_cases
     from boss_runs_amd.engine import host_parse
-    if plan_range:
+    if plan_range == "scalar_scan":
+        monkeypatch.setenv("BOSSX_PARSE_SCALAR", "1")
+    elif plan_range:
         monkeypatch.setenv("BOSSX_PLAN_RANGE", plan_range)
     contigs, cases = fuzz_error_cases()
     gold = json.load(open(os.path.join(GOLDEN, "g_errors_fuzz.json")))
