@@ -444,6 +444,9 @@ struct Plan {
     int64_t q_first, q_len;  // read[q_first] is the first base the walk reads ('-': walks down from there), q_len how many the slice holds
     uint64_t span_add = 0;   // what it adds to the emit order / to the run capacity (0 for a mapping the walk is not given): summed in
     size_t ops_add = 0;      // record order once every mapping has been looked at (the look itself runs in parallel)
+    // what the device walk's MapPlan needs of the record, copied while the pre-pass has it in its cache: the records lie all over the
+    // line tasks' vectors, and the MapPlan loops used to take a second round of cache misses over them
+    const char *cg = nullptr; size_t cg_len = 0; bool rev = false;
 };
 
 // seq[start:end] of a Python sequence of n elements: first index and length.
@@ -1120,6 +1123,7 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             }
             pl.span_add = uint64_t(pl.thi - pl.tlo);
             pl.ops_add = r.cg_len / 2 + 1;            // every run is at least one digit + one letter
+            pl.cg = r.cg; pl.cg_len = r.cg_len; pl.rev = r.rev;
         }
         return true;
     };
@@ -1178,8 +1182,8 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
         for (size_t i = 0; i < plans.size(); ++i) {
             const Plan &pl = plans[i];
             if (pl.cidx < 0) continue;
-            const Rec &r = *pl.rec;
-            if (r.cg_len > size_t(UINT32_MAX) || pl.thi - pl.tlo > int64_t(UINT32_MAX)) {
+            if (pl.cg_len > size_t(UINT32_MAX) || pl.thi - pl.tlo > int64_t(UINT32_MAX)) {
+                const Rec &r = *pl.rec;
                 if (!pre_err.code || pl.gi < pre_err.group) {
                     pre_err.group = pl.gi;
                     pre_err.code = check_cigar_text(r.cg, r.cg_len, pl.q_len, pl.thi - pl.tlo, true, true, pre_err.msg);
@@ -1201,17 +1205,15 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
             size_t seg_sum = 0;
             std::vector<uint64_t> &emitted = emit_part[size_t(k)];
             for (size_t i = plans.size() * size_t(k) / n_cr, ie = plans.size() * (size_t(k) + 1) / n_cr; i < ie; ++i) {
-                if (i + 8 < ie) { const char *nx = reinterpret_cast<const char *>(plans[i + 8].rec); __builtin_prefetch(nx); __builtin_prefetch(nx + 64); __builtin_prefetch(nx + 128); }
                 if (slot[i] == UINT32_MAX) continue;
                 const Plan &pl = plans[i];
-                const Rec &r = *pl.rec;
                 const ContigInfo &c = contigs[size_t(pl.cidx)];
                 const int64_t seq_b = in.seq_off[pl.read], seq_len = in.seq_len ? in.seq_len[pl.read] : in.seq_off[pl.read + 1] - seq_b;
                 const int64_t tlo = pl.tlo, thi = pl.thi;
                 const int64_t q = pl.q_first, q_need = pl.q_len;
                 MapPlan mp{};
-                mp.cg_off = uint32_t(size_t(r.cg - in.paf) + size_t(in.paf_base));
-                mp.cg_len = uint32_t(r.cg_len);
+                mp.cg_off = uint32_t(size_t(pl.cg - in.paf) + size_t(in.paf_base));
+                mp.cg_len = uint32_t(pl.cg_len);
                 mp.emit0 = uint32_t(pl.emit0);
                 mp.span = uint32_t(thi - tlo);
                 mp.site0 = uint64_t(c.site_off + tlo);
@@ -1222,8 +1224,8 @@ int parse_paf_batch(const ParseInput &in, const std::vector<ContigInfo> &contigs
                 mp.seq_len = uint32_t(seq_len);
                 const int64_t room = c.length - tlo;
                 mp.room = uint32_t(room < 0 ? 0 : (room > int64_t(UINT32_MAX) ? int64_t(UINT32_MAX) : room));
-                mp.ops_cap = uint32_t(r.cg_len / 2 + 1);
-                mp.flags = uint32_t(pl.bc & 0xff) | (r.rev ? kPlanRev : 0u) | (q_need == 1 ? kPlanBroadcast : 0u);      // (kPlanCheckBases: below, once the reads have been looked at)
+                mp.ops_cap = uint32_t(pl.cg_len / 2 + 1);
+                mp.flags = uint32_t(pl.bc & 0xff) | (pl.rev ? kPlanRev : 0u) | (q_need == 1 ? kPlanBroadcast : 0u);      // (kPlanCheckBases: below, once the reads have been looked at)
                 // groups: every sweep tile the stretch [site0, site0 + span) touches, for this barcode.
                 // A stretch that runs past its contig (an IndexError reported by the device walk) is
                 // clipped here so that no key outside the table is marked.
